@@ -1,0 +1,161 @@
+"""Oracle: Gramian, weightings and combine for the K-loss gradient aggregation (TEST
+INFRASTRUCTURE, see oracle/__init__.py).
+
+MGDA / Aligned-MTL follow the reference's in-tree code and are pinned by
+tests/golden/weightings.npz (generated from that code).  UPGrad / Mean / Sum follow torchjd's
+published algorithm (third-party, absent: parity unpinned beyond the docstring KAT
+utils/torchmoo/nupgrad.py:58-62, ``UPGrad()([[-4,1,1],[6,1,1]]) = [0.2929, 1.9004, 1.9004]``).
+"""
+import itertools
+
+import numpy as np
+import torch
+
+
+def gramian(J):
+    """torchjd GramianWeightedAggregator: G = J J^T in the Jacobian's dtype (fp32)."""
+    return J @ J.T
+
+
+# ---- UPGrad -----------------------------------------------------------------------------
+def _qp_lower_bounded(G, u):
+    """argmin_w 1/2 w^T G w  s.t.  w >= u   (G symmetric positive definite, float64).
+
+    Exact active-set enumeration: with v = w - u >= 0 the KKT system is
+        v_F = -G_FF^{-1} (G u)_F,  v_A = 0,  (G (u + v))_A >= 0,  v_F >= 0
+    for exactly one partition (F free, A active) because the problem is strictly convex.
+    quadprog's Goldfarb-Idnani iteration (what torchjd calls through qpsolvers) converges to the
+    same unique point.
+    """
+    K = len(u)
+    c = G @ u
+    best, best_viol = None, np.inf
+    for r in range(K + 1):
+        for F in itertools.combinations(range(K), r):
+            F = list(F)
+            v = np.zeros(K)
+            if F:
+                v[F] = np.linalg.solve(G[np.ix_(F, F)], -c[F])
+            grad = G @ v + c
+            A = [i for i in range(K) if i not in F]
+            viol = max([0.0] + [-v[i] for i in F] + [-grad[i] for i in A])
+            if viol < best_viol:
+                best, best_viol = u + v, viol
+            if viol <= 1e-12 * max(1.0, np.abs(c).max()):
+                return u + v
+    return best
+
+
+def upgrad_weights(G, norm_eps=1e-4, reg_eps=1e-4, pref=None):
+    """torchjd UPGrad weighting (constructed at main.py:1195): trace-normalise, regularise,
+    project every row of U = diag(pref or 1/K) onto the dual cone, sum the rows.
+    Arithmetic in float64 on the host like torchjd's numpy path; result cast to G's dtype."""
+    Gd = np.asarray(G.detach().cpu().numpy() if isinstance(G, torch.Tensor) else G, dtype=np.float64)
+    K = Gd.shape[0]
+    tr = np.trace(Gd)
+    Gn = np.zeros_like(Gd) if tr < norm_eps else Gd / tr
+    Gn = Gn + reg_eps * np.eye(K)
+    u_diag = np.full(K, 1.0 / K) if pref is None else np.asarray(pref, dtype=np.float64)
+    W = np.zeros((K, K))
+    for i in range(K):
+        u = np.zeros(K)
+        u[i] = u_diag[i]
+        W[i] = _qp_lower_bounded(Gn, u)
+    return W.sum(axis=0)
+
+
+# ---- MGDA (utils/torchmoo/mgda.py:221-367) ---------------------------------------------
+def mgda_weights(G, norm_type="none", losses=None, epsilon=1e-5, max_iters=250,
+                 stable=False, min_eigenvalue_eps=1e-10, return_iters=False):
+    G = np.asarray(G, dtype=np.float32)
+    K = G.shape[0]
+    if norm_type in ("l2", "loss+"):
+        n = np.sqrt(np.maximum(np.diag(G), np.float32(1e-20))).astype(np.float32)
+    if norm_type in ("loss", "loss+"):
+        if losses is None:
+            raise RuntimeError("Losses must be set before calling forward()")
+        ls = np.maximum(np.asarray(losses, dtype=np.float32), np.float32(1e-20))
+    if norm_type == "l2":
+        G = G / np.outer(n, n)
+    elif norm_type == "loss":
+        G = G / np.outer(ls, ls)
+    elif norm_type == "loss+":
+        c = (ls * n).astype(np.float32)
+        G = G / np.outer(c, c)
+    G = G.astype(np.float32)
+    if stable:  # mgda.py:287-317
+        lam, V = np.linalg.eigh(G)
+        lam = np.maximum(lam, np.float32(min_eigenvalue_eps))
+        G = (V @ (lam[:, None] * V.T)).astype(np.float32)
+    alpha = np.full(K, 1.0 / K, dtype=np.float32)
+    it = 0
+    for it in range(max_iters):
+        Ga = G @ alpha
+        t = int(np.argmin(Ga))
+        a = np.float32(alpha @ G[:, t])
+        b = np.float32(alpha @ Ga)
+        c = G[t, t]
+        if c <= a:
+            gamma = np.float32(1.0)
+        elif b <= a:
+            gamma = np.float32(0.0)
+        else:
+            gamma = np.float32((b - a) / (b + c - 2 * a))
+        alpha = ((1 - gamma) * alpha).astype(np.float32)
+        alpha[t] += gamma
+        if gamma < epsilon:
+            break
+    return (alpha, it + 1) if return_iters else alpha
+
+
+# ---- Aligned-MTL (utils/torchmoo/aligned_mtl.py:97-133) ------------------------------------
+def aligned_mtl_weights(G, scale_mode="min", pref=None):
+    G = np.asarray(G, dtype=np.float32)
+    K = G.shape[0]
+    w0 = np.full(K, 1.0 / K, dtype=np.float32) if pref is None else np.asarray(pref, dtype=np.float32)
+    lam, V = np.linalg.eigh(G, UPLO="U")
+    tol = lam.max() * K * np.finfo(np.float32).eps
+    rank = int((lam > tol).sum())
+    if rank == 0:
+        return w0
+    order = np.argsort(-lam, kind="stable")
+    lam, V = lam[order][:rank], V[:, order][:, :rank]
+    if scale_mode == "min":
+        scale = lam[-1]
+    elif scale_mode == "median":
+        scale = np.sort(lam)[(rank - 1) // 2]  # torch.median returns the lower middle
+    elif scale_mode == "rmse":
+        scale = lam.mean()
+    else:
+        raise ValueError(f"Invalid scale_mode={scale_mode!r}")
+    B = np.sqrt(scale) * (V @ np.diag(1 / np.sqrt(lam)) @ V.T)
+    return (B @ w0).astype(np.float32)
+
+
+# ---- factory mirroring main.py:1191-1246 --------------------------------------------------------
+def make_weighting(name, **kw):
+    """Returns f(G, losses) -> weights (numpy)."""
+    n = name.lower()
+    if n == "upgrad":
+        return lambda G, losses=None: upgrad_weights(G, kw.get("norm_eps", 1e-4), kw.get("reg_eps", 1e-4))
+    if n in ("aligned_mtl", "aligned_mtl_min", "amtl", "amtl_min"):
+        return lambda G, losses=None: aligned_mtl_weights(G, "min")
+    if n == "aligned_mtl_median":
+        return lambda G, losses=None: aligned_mtl_weights(G, "median")
+    if n == "aligned_mtl_rmse":
+        return lambda G, losses=None: aligned_mtl_weights(G, "rmse")
+    mg = {"mgda": "none", "mgda_ln": "l2", "mgda_gn": "loss", "mgda_lgn": "loss+"}
+    if n in mg:
+        return lambda G, losses=None: mgda_weights(G, mg[n], losses, kw.get("epsilon", 1e-5), kw.get("max_iters", 250))
+    if n == "mean":
+        return lambda G, losses=None: np.full(len(G), 1.0 / len(G))
+    if n == "jd_sum":
+        return lambda G, losses=None: np.ones(len(G))
+    raise ValueError(f"Aggregator {name} not supported")
+
+
+def aggregate(J, weighting, losses=None):
+    """aggregator(J) = weighting(J J^T) @ J; returns (g, w, G)."""
+    G = gramian(J)
+    w = torch.as_tensor(np.asarray(weighting(G.detach().cpu().numpy(), losses)), dtype=J.dtype)
+    return w @ J, w, G
