@@ -1,0 +1,165 @@
+/*
+ * movae.h -- C ABI of libmovae_hip.so: the MI355X (gfx950) kernels under MO-VAE's per-step
+ * training hot path.  The reference has no native boundary of its own
+ * (it is pure Python on ATen + torchjd); each entry point below names the reference call whose
+ * device arithmetic it replaces (paths relative to the reference root).  INTEGRATION.md shows
+ * the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a caller-owned DEVICE pointer (fp32 unless stated); nothing is allocated,
+ *     freed or synchronised inside; work is enqueued on `stream` (a hipStream_t, may be NULL);
+ *   - activations are NHWC ("channels_last"): x[n][h][w][c]; conv weights are [Co][KH][KW][Ci]
+ *     and transposed-conv weights [Ci][KH][KW][Co] in memory (the channels_last image of the
+ *     reference's OIHW / IOHW parameter shapes), Linear weights [out][in];
+ *   - `ws`/`ws_bytes`: scratch for split-K partials; may be NULL/0 (then no split-K);
+ *   - return 0 on success, <0 on invalid argument (-1), unsupported shape (-2) or launch
+ *     failure (-3); movae_last_error() gives the text for the calling thread.
+ */
+#ifndef MOVAE_H
+#define MOVAE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* movae_stream_t; /* hipStream_t */
+
+enum movae_act { MOVAE_ACT_NONE = 0, MOVAE_ACT_LRELU = 1, MOVAE_ACT_RELU = 2, MOVAE_ACT_TANH = 3, MOVAE_ACT_SIGMOID = 4 };
+enum movae_recon { MOVAE_RECON_MSE = 0, MOVAE_RECON_BCE = 1, MOVAE_RECON_L1 = 2, MOVAE_RECON_SMOOTH_L1 = 3 };
+enum movae_mgda_norm { MOVAE_MGDA_NONE = 0, MOVAE_MGDA_L2 = 1, MOVAE_MGDA_LOSS = 2, MOVAE_MGDA_LOSS_PLUS = 3 };
+enum movae_amtl_scale { MOVAE_AMTL_MIN = 0, MOVAE_AMTL_MEDIAN = 1, MOVAE_AMTL_RMSE = 2 };
+
+int movae_version(void);
+const char* movae_last_error(void);
+
+/* ---- layout ------------------------------------------------------------------------------
+ * NCHW <-> NHWC transposes at the model boundary (main.py:155 hands NCHW images; nn.Flatten /
+ * nn.Unflatten in models/vae.py:128,143 order features NCHW). */
+int movae_nchw_to_nhwc(const float* src, float* dst, int n, int c, int h, int w, movae_stream_t stream);
+int movae_nhwc_to_nchw(const float* src, float* dst, int n, int c, int h, int w, movae_stream_t stream);
+
+/* ---- convolutions (implicit GEMM on v_mfma_f32_32x32x2_f32) -----------------------------------
+ * conv2d      : nn.Conv2d forward/backward      models/vae.py:121,170; vq_vae.py:232-257; vq_vae2.py:36-47; betatc_vae.py:104-110
+ * convT2d     : nn.ConvTranspose2d              models/vae.py:151-156,163-168; vq_vae.py:287-300; vq_vae2.py:75-88
+ * linear      : nn.Linear == conv2d with h=w=kh=kw=1   models/vae.py:133-137; betatc_vae.py:124-131
+ * `act`/`slope` fuse the following nn.LeakyReLU/ReLU/Tanh/Sigmoid into the epilogue.
+ * y[n][ho][wo][co] with ho = (hi + 2*pad - kh)/stride + 1 (conv) or (hi-1)*stride - 2*pad + kh + out_pad (convT). */
+int movae_conv2d_fwd(const float* x, const float* w, const float* bias, float* y,
+                     int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad,
+                     int act, float slope, void* ws, size_t ws_bytes, movae_stream_t stream);
+int movae_conv2d_dgrad(const float* dy, const float* w, float* dx,
+                       int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad,
+                       void* ws, size_t ws_bytes, movae_stream_t stream);
+/* dw[co][kh][kw][ci] (+)= sum dy * x ; dbias[co] (+)= sum dy (dbias may be NULL). accumulate!=0 adds to dw/dbias. */
+int movae_conv2d_wgrad(const float* dy, const float* x, float* dw, float* dbias,
+                       int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad,
+                       int accumulate, void* ws, size_t ws_bytes, movae_stream_t stream);
+int movae_convT2d_fwd(const float* x, const float* w, const float* bias, float* y,
+                      int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad,
+                      int act, float slope, void* ws, size_t ws_bytes, movae_stream_t stream);
+int movae_convT2d_dgrad(const float* dy, const float* w, float* dx,
+                        int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad,
+                        void* ws, size_t ws_bytes, movae_stream_t stream);
+int movae_convT2d_wgrad(const float* dy, const float* x, float* dw, float* dbias,
+                        int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad,
+                        int accumulate, void* ws, size_t ws_bytes, movae_stream_t stream);
+
+/* ---- BatchNorm2d (training statistics) + activation ------------------------------------------
+ * nn.BatchNorm2d + nn.LeakyReLU   models/vae.py:123-125,157-158,169-170   (eps 1e-5, momentum 0.1)
+ * y is the conv output [rows][c]; stats are accumulated in fp64.  `ws` must hold
+ * movae_bn_ws_bytes(rows, c) bytes. */
+size_t movae_bn_ws_bytes(int rows, int c);
+int movae_bn_act_fwd(const float* y, const float* gamma, const float* beta, float* out,
+                     float* save_mean, float* save_rstd, float* running_mean, float* running_var,
+                     int rows, int c, float eps, float momentum, int training, int act, float slope,
+                     void* ws, size_t ws_bytes, movae_stream_t stream);
+/* dy = d(loss)/d(conv output); dgamma/dbeta written (or accumulated when accumulate!=0). */
+int movae_bn_act_bwd(const float* dout, const float* y, const float* gamma, const float* beta,
+                     const float* save_mean, const float* save_rstd, float* dy, float* dgamma, float* dbeta,
+                     int rows, int c, int act, float slope, int accumulate,
+                     void* ws, size_t ws_bytes, movae_stream_t stream);
+
+/* ---- element-wise ---------------------------------------------------------------------------- */
+int movae_act_fwd(const float* x, float* y, size_t n, int act, float slope, movae_stream_t stream);
+/* dx = dy * act'(.) evaluated from the activation OUTPUT `out` (valid for all five kinds) */
+int movae_act_bwd(const float* dy, const float* out, float* dx, size_t n, int act, float slope, movae_stream_t stream);
+int movae_add(const float* a, const float* b, float* y, size_t n, movae_stream_t stream);
+int movae_axpby(float alpha, const float* a, float beta, const float* b, float* y, size_t n, movae_stream_t stream);
+/* channel concat / split of NHWC tensors: dst[rows][c_dst], src[rows][c_src] placed at channel offset */
+int movae_copy_channels(const float* src, float* dst, int rows, int c_src, int c_dst, int src_off, int dst_off, int c_copy, movae_stream_t stream);
+/* column sums: out[c] (+)= sum_rows x[rows][c]   (bias gradients) */
+int movae_colsum(const float* x, float* out, int rows, int c, int accumulate, void* ws, size_t ws_bytes, movae_stream_t stream);
+
+/* reparameterize  z = mu + eps * exp(0.5 * log_var)      models/vae.py:187-192, betatc_vae.py:206-216 */
+int movae_reparam_fwd(const float* mu, const float* log_var, const float* eps, float* z, size_t n, movae_stream_t stream);
+int movae_reparam_bwd(const float* dz, const float* log_var, const float* eps, float* dmu, float* dlog_var, size_t n, movae_stream_t stream);
+
+/* ---- losses -------------------------------------------------------------------------------------
+ * recon: utils/objectives.py:95-97 (mse), 108-110 (bce), 129-131 (l1), 134-136 (smooth_l1): mean over all
+ * elements; out[0] = scale * loss.  ws >= movae_reduce_ws_bytes(n). */
+size_t movae_reduce_ws_bytes(size_t n);
+int movae_recon_loss_fwd(const float* recons, const float* inputs, float* out, size_t n, int kind, float scale,
+                         void* ws, size_t ws_bytes, movae_stream_t stream);
+/* drecons = (*gscale_dev) * scale * d(mean loss)/d(recons) ; gscale_dev may be NULL (=1) */
+int movae_recon_loss_bwd(const float* recons, const float* inputs, const float* gscale_dev, float* drecons,
+                         size_t n, int kind, float scale, movae_stream_t stream);
+/* kl: utils/objectives.py:141-144, out[0] = scale * mean_b(-0.5 sum_d(1 + lv - mu^2 - e^lv)) */
+int movae_kl_fwd(const float* mu, const float* log_var, float* out, int b, int d, float scale,
+                 void* ws, size_t ws_bytes, movae_stream_t stream);
+int movae_kl_bwd(const float* mu, const float* log_var, const float* gscale_dev, float* dmu, float* dlog_var,
+                 int b, int d, float scale, movae_stream_t stream);
+/* Beta-TC decomposition: models/betatc_vae.py:262-296.  out[0..2] = mi, tc, kld (unweighted means).
+ * log_iw is the [b][b] fp32 log-importance-weight matrix of betatc_vae.py:275-289. */
+int movae_tc_decomp_fwd(const float* z, const float* mu, const float* log_var, const float* log_iw, float* out,
+                        float* lse_joint, float* lse_marg, int b, int d, void* ws, size_t ws_bytes, movae_stream_t stream);
+/* g[0..2] = upstream gradients of (mi, tc, kld) on device */
+int movae_tc_decomp_bwd(const float* z, const float* mu, const float* log_var, const float* log_iw,
+                        const float* lse_joint, const float* lse_marg, const float* g,
+                        float* dz, float* dmu, float* dlog_var, int b, int d, movae_stream_t stream);
+
+/* ---- vector quantiser ------------------------------------------------------------------------------
+ * models/vq_vae.py:27-64: nearest code under ||x||^2 + ||e||^2 - 2 x.e (first index on ties), gather, and
+ * sse[0] = sum (q - x)^2 (commitment and embedding losses are both sse/numel).  x,q: [rows][d], e: [k][d]. */
+int movae_vq_nearest_fwd(const float* x, const float* e, float* q, int64_t* idx, float* sse, int32_t* used_count,
+                         int rows, int k, int d, void* ws, size_t ws_bytes, movae_stream_t stream);
+/* dx = dq + gc * 2 (x - q)/numel ; de[idx] += ge * 2 (q - x)/numel   (gc, ge: device scalars, may be NULL = 0) */
+int movae_vq_bwd(const float* x, const float* q, const int64_t* idx, const float* dq, const float* gc, const float* ge,
+                 float* dx, float* de, int rows, int k, int d, movae_stream_t stream);
+
+/* ---- K-loss gradient aggregation ---------------------------------------------------------------------
+ * torchjd GramianWeightedAggregator (base of utils/torchmoo/mgda.py:12, aligned_mtl.py:39): G = J J^T,
+ * w = weighting(G), g = w @ J.   J is [k][m] row-major with leading dimension ldj, k <= MOVAE_MAX_K. */
+#define MOVAE_MAX_K 8
+size_t movae_gram_ws_bytes(int k, size_t m);
+int movae_gram(const float* J, size_t ldj, int k, size_t m, float* G, void* ws, size_t ws_bytes, movae_stream_t stream);
+/* UPGrad (torchjd; constructed main.py:1195): G/tr(G) (0 if tr<norm_eps) + reg_eps I; for each i solve
+ * min 1/2 w'Gw s.t. w >= u_i e_i; sum rows.  pref may be NULL (u = 1/k).  Solved in fp64 on device. */
+int movae_weights_upgrad(const float* G, int k, float norm_eps, float reg_eps, const float* pref, float* w, movae_stream_t stream);
+/* MGDA Frank-Wolfe (utils/torchmoo/mgda.py:221-367); losses may be NULL for norm NONE/L2. info[0]=iterations */
+int movae_weights_mgda(const float* G, int k, int norm, const float* losses, float epsilon, int max_iters,
+                       float* w, int32_t* info, movae_stream_t stream);
+/* Aligned-MTL (utils/torchmoo/aligned_mtl.py:97-133) */
+int movae_weights_amtl(const float* G, int k, int scale_mode, const float* pref, float* w, movae_stream_t stream);
+/* constant weightings (torchjd Sum / Mean) */
+int movae_weights_const(int k, float value, float* w, movae_stream_t stream);
+/* g[m] (+)= sum_i w[i] J[i][:]  ; also usable as the hook's J.T @ w (main.py:112-118) */
+int movae_combine(const float* J, size_t ldj, int k, size_t m, const float* w, float* g, int accumulate, movae_stream_t stream);
+/* cos(J.T @ w, mean_rows(J)) -> out[0] (main.py:108-119) */
+int movae_gd_similarity(const float* J, size_t ldj, int k, size_t m, const float* w, float* out,
+                        void* ws, size_t ws_bytes, movae_stream_t stream);
+
+/* ---- optimizer tail (torch.optim.Adam semantics, main.py:1169-1178,214) ------------------
+ * flat multi-tensor Adam over one contiguous fp32 arena; step_dev holds the step count as float. */
+int movae_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int decoupled_wd, int step, movae_stream_t stream);
+/* sumsq of a flat arena into out[0] (clip_grad_norm_, main.py:211-212) */
+int movae_sumsq(const float* x, size_t n, float* out, void* ws, size_t ws_bytes, movae_stream_t stream);
+int movae_scale_by_clip(float* g, size_t n, const float* sumsq_dev, float max_norm, movae_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOVAE_H */

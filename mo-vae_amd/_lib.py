@@ -1,0 +1,134 @@
+"""ctypes binding of libmovae_hip.so (include/movae.h).
+
+The product path has no CPU fallback: if the library cannot be loaded every op raises.
+"""
+import ctypes as C
+import os
+import threading
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmovae_hip.so")
+
+ACT = {"none": 0, None: 0, "lrelu": 1, "relu": 2, "tanh": 3, "sigmoid": 4}
+RECON = {"mse": 0, "bce": 1, "l1": 2, "smooth_l1": 3}
+MGDA_NORM = {"none": 0, "l2": 1, "loss": 2, "loss+": 3}
+AMTL_SCALE = {"min": 0, "median": 1, "rmse": 2}
+MAX_K = 8
+
+_p, _i, _f, _z, _l = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_long
+
+_conv_fwd = [_p, _p, _p, _p] + [_i] * 11 + [_i, _f, _p, _z, _p]
+_conv_dgrad = [_p, _p, _p] + [_i] * 11 + [_p, _z, _p]
+_conv_wgrad = [_p, _p, _p, _p] + [_i] * 11 + [_i, _p, _z, _p]
+
+SIGNATURES = {
+    "movae_version": ([], _i),
+    "movae_last_error": ([], C.c_char_p),
+    "movae_nchw_to_nhwc": ([_p, _p, _i, _i, _i, _i, _p], _i),
+    "movae_nhwc_to_nchw": ([_p, _p, _i, _i, _i, _i, _p], _i),
+    "movae_conv2d_fwd": (_conv_fwd, _i),
+    "movae_conv2d_dgrad": (_conv_dgrad, _i),
+    "movae_conv2d_wgrad": (_conv_wgrad, _i),
+    "movae_convT2d_fwd": (_conv_fwd, _i),
+    "movae_convT2d_dgrad": (_conv_dgrad, _i),
+    "movae_convT2d_wgrad": (_conv_wgrad, _i),
+    "movae_bn_ws_bytes": ([_i, _i], _z),
+    "movae_bn_act_fwd": ([_p] * 8 + [_i, _i, _f, _f, _i, _i, _f, _p, _z, _p], _i),
+    "movae_bn_act_bwd": ([_p] * 9 + [_i, _i, _i, _f, _i, _p, _z, _p], _i),
+    "movae_act_fwd": ([_p, _p, _z, _i, _f, _p], _i),
+    "movae_act_bwd": ([_p, _p, _p, _z, _i, _f, _p], _i),
+    "movae_add": ([_p, _p, _p, _z, _p], _i),
+    "movae_axpby": ([_f, _p, _f, _p, _p, _z, _p], _i),
+    "movae_copy_channels": ([_p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
+    "movae_colsum": ([_p, _p, _i, _i, _i, _p, _z, _p], _i),
+    "movae_reparam_fwd": ([_p, _p, _p, _p, _z, _p], _i),
+    "movae_reparam_bwd": ([_p, _p, _p, _p, _p, _z, _p], _i),
+    "movae_reduce_ws_bytes": ([_z], _z),
+    "movae_recon_loss_fwd": ([_p, _p, _p, _z, _i, _f, _p, _z, _p], _i),
+    "movae_recon_loss_bwd": ([_p, _p, _p, _p, _z, _i, _f, _p], _i),
+    "movae_kl_fwd": ([_p, _p, _p, _i, _i, _f, _p, _z, _p], _i),
+    "movae_kl_bwd": ([_p, _p, _p, _p, _p, _i, _i, _f, _p], _i),
+    "movae_tc_decomp_fwd": ([_p] * 7 + [_i, _i, _p, _z, _p], _i),
+    "movae_tc_decomp_bwd": ([_p] * 10 + [_i, _i, _p], _i),
+    "movae_vq_nearest_fwd": ([_p] * 6 + [_i, _i, _i, _p, _z, _p], _i),
+    "movae_vq_bwd": ([_p] * 8 + [_i, _i, _i, _p], _i),
+    "movae_gram_ws_bytes": ([_i, _z], _z),
+    "movae_gram": ([_p, _z, _i, _z, _p, _p, _z, _p], _i),
+    "movae_weights_upgrad": ([_p, _i, _f, _f, _p, _p, _p], _i),
+    "movae_weights_mgda": ([_p, _i, _i, _p, _f, _i, _p, _p, _p], _i),
+    "movae_weights_amtl": ([_p, _i, _i, _p, _p, _p], _i),
+    "movae_weights_const": ([_i, _f, _p, _p], _i),
+    "movae_combine": ([_p, _z, _i, _z, _p, _p, _i, _p], _i),
+    "movae_gd_similarity": ([_p, _z, _i, _z, _p, _p, _p, _z, _p], _i),
+    "movae_adam_step": ([_p, _p, _p, _p, _z, _f, _f, _f, _f, _f, _i, _i, _p], _i),
+    "movae_sumsq": ([_p, _z, _p, _p, _z, _p], _i),
+    "movae_scale_by_clip": ([_p, _z, _p, _f, _p], _i),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """Loads the shared library (building it with hipcc when the toolchain is present and the
+    .so is absent).  Raises RuntimeError otherwise -- there is deliberately no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            try:
+                from . import build as _build
+
+                _build.build(verbose=False)
+            except Exception as e:  # noqa: BLE001
+                raise RuntimeError(
+                    f"libmovae_hip.so is missing at {LIB_PATH} and could not be built ({e}); "
+                    "the MI355X kernels are required -- there is no CPU fallback") from e
+        try:
+            lib = C.CDLL(LIB_PATH)
+        except OSError as e:
+            raise RuntimeError(f"cannot load {LIB_PATH}: {e}; the MI355X kernels are required") from e
+        for name, (args, res) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the .so does not export the declared symbol
+            fn.argtypes = args
+            fn.restype = res
+        _lib = lib
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().movae_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what or 'movae'} failed (rc={rc}): {msg}")
+
+
+def stream_ptr(device=None):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+_workspaces = {}
+WS_BYTES = 96 << 20
+
+
+def workspace(device):
+    """Persistent per-device scratch (split-K slabs, reduction partials).  Stream-ordered reuse."""
+    key = (device.type, device.index)
+    ws = _workspaces.get(key)
+    if ws is None:
+        ws = torch.empty(WS_BYTES, dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def require_gpu(t):
+    if not t.is_cuda:
+        raise RuntimeError("mo-vae_amd ops run on an MI355X (cuda/HIP device) only; got a CPU tensor -- there is no CPU path")
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()

@@ -1,0 +1,503 @@
+// K-loss gradient aggregation on device: Gramian of the K x m Jacobian, the K x K weight solves
+// (UPGrad dual-cone projection, MGDA Frank-Wolfe, Aligned-MTL eigen balance) and the combine.
+// Gram / combine / similarity are pure HBM streams over J (K <= 8 rows, so no MFMA: the
+// arithmetic intensity is K/4 flop per byte); the solves are single-wave kernels in fp64 so the
+// reference's host round trip (GPU -> numpy float64 -> quadprog -> GPU) never happens.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXK = MOVAE_MAX_K;
+constexpr int GRAM_BLOCKS = 1024;
+
+inline int gram_blocks(size_t m) {
+    size_t g = (m + 2047) / 2048;
+    return (int)(g > GRAM_BLOCKS ? GRAM_BLOCKS : (g < 1 ? 1 : g));
+}
+
+template <int K, bool VEC>
+__global__ __launch_bounds__(256) void gram_partial(const float* __restrict__ J, long ldj, long m, double* __restrict__ part) {
+    constexpr int NP = K * (K + 1) / 2;
+    double acc[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) acc[q] = 0.0;
+    const long stride = (long)gridDim.x * blockDim.x;
+    if (VEC) {
+        const long nv = m / 4;
+        for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < nv; c += stride) {
+            f32x4 v[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) v[i] = reinterpret_cast<const f32x4*>(J + i * ldj)[c];
+            int q = 0;
+#pragma unroll
+            for (int i = 0; i < K; ++i)
+#pragma unroll
+                for (int j = i; j < K; ++j) {
+                    const f32x4 p = v[i] * v[j];
+                    acc[q] += (double)p[0] + (double)p[1] + (double)p[2] + (double)p[3];
+                    ++q;
+                }
+        }
+        // tail (m % 4) handled by thread 0 of block 0
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            for (long c = nv * 4; c < m; ++c) {
+                int q = 0;
+                for (int i = 0; i < K; ++i)
+                    for (int j = i; j < K; ++j) acc[q++] += (double)(J[i * ldj + c] * J[j * ldj + c]);
+            }
+    } else {
+        for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < m; c += stride) {
+            float v[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) v[i] = J[i * ldj + c];
+            int q = 0;
+#pragma unroll
+            for (int i = 0; i < K; ++i)
+#pragma unroll
+                for (int j = i; j < K; ++j) acc[q++] += (double)(v[i] * v[j]);
+        }
+    }
+    __shared__ double sh[4];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const double s = block_sum_256(acc[q], sh);
+        if (threadIdx.x == 0) part[(long)blockIdx.x * NP + q] = s;
+    }
+}
+
+__global__ void gram_final(const double* __restrict__ part, int nblk, int K, float* __restrict__ G) {
+    const int NP = K * (K + 1) / 2;
+    const int q = threadIdx.x;
+    if (q >= NP) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += part[(long)b * NP + q];
+    int i = 0, rem = q;
+    while (rem >= K - i) {
+        rem -= K - i;
+        ++i;
+    }
+    const int j = i + rem;
+    G[i * K + j] = (float)s;
+    G[j * K + i] = (float)s;
+}
+
+template <int K, bool VEC>
+__global__ __launch_bounds__(256) void combine_k(const float* __restrict__ J, long ldj, long m, const float* __restrict__ w,
+                                                 float* __restrict__ g, int accumulate) {
+    float wv[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) wv[i] = w[i];
+    const long stride = (long)gridDim.x * blockDim.x;
+    if (VEC) {
+        const long nv = m / 4;
+        for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < nv; c += stride) {
+            f32x4 s = accumulate ? reinterpret_cast<const f32x4*>(g)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < K; ++i) s += wv[i] * reinterpret_cast<const f32x4*>(J + i * ldj)[c];
+            reinterpret_cast<f32x4*>(g)[c] = s;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            for (long c = nv * 4; c < m; ++c) {
+                float s = accumulate ? g[c] : 0.f;
+                for (int i = 0; i < K; ++i) s += wv[i] * J[i * ldj + c];
+                g[c] = s;
+            }
+    } else {
+        for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < m; c += stride) {
+            float s = accumulate ? g[c] : 0.f;
+#pragma unroll
+            for (int i = 0; i < K; ++i) s += wv[i] * J[i * ldj + c];
+            g[c] = s;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void similarity_partial(const float* __restrict__ J, long ldj, int K, long m,
+                                                          const float* __restrict__ w, double* __restrict__ part) {
+    __shared__ double sh[4];
+    double ab = 0.0, aa = 0.0, bb = 0.0;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < m; c += stride) {
+        float a = 0.f, b = 0.f;
+        for (int i = 0; i < K; ++i) {
+            const float v = J[i * ldj + c];
+            a += w[i] * v;
+            b += v;
+        }
+        b /= (float)K;
+        ab += (double)a * b;
+        aa += (double)a * a;
+        bb += (double)b * b;
+    }
+    ab = block_sum_256(ab, sh);
+    aa = block_sum_256(aa, sh);
+    bb = block_sum_256(bb, sh);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 3 + 0] = ab;
+        part[blockIdx.x * 3 + 1] = aa;
+        part[blockIdx.x * 3 + 2] = bb;
+    }
+}
+
+__global__ void similarity_final(const double* __restrict__ part, int nblk, float* __restrict__ out) {
+    if (threadIdx.x != 0) return;
+    double ab = 0, aa = 0, bb = 0;
+    for (int b = 0; b < nblk; ++b) {
+        ab += part[b * 3];
+        aa += part[b * 3 + 1];
+        bb += part[b * 3 + 2];
+    }
+    const double na = fmax(sqrt(aa), 1e-8), nb = fmax(sqrt(bb), 1e-8);  // F.cosine_similarity eps
+    out[0] = (float)(ab / (na * nb));
+}
+
+// ---- UPGrad --------------------------------------------------------------------------------------
+// One wave; lane s evaluates the active-set candidate whose free set is the bit mask s (s += 64
+// until 2^K), solves the free block by Cholesky in fp64 and scores the KKT violation; the wave
+// keeps the least-violating candidate (the unique KKT point of the strictly convex QP).
+__global__ __launch_bounds__(64) void upgrad_k(const float* __restrict__ Gin, int K, float norm_eps, float reg_eps,
+                                               const float* __restrict__ pref, float* __restrict__ wout) {
+    const int lane = threadIdx.x;
+    double G[MAXK][MAXK];
+    double tr = 0.0;
+    for (int i = 0; i < K; ++i) tr += (double)Gin[i * K + i];
+    const bool zero = tr < (double)norm_eps;
+    for (int i = 0; i < K; ++i)
+        for (int j = 0; j < K; ++j) G[i][j] = (zero ? 0.0 : (double)Gin[i * K + j] / tr) + (i == j ? (double)reg_eps : 0.0);
+    double wsum[MAXK];
+    for (int i = 0; i < K; ++i) wsum[i] = 0.0;
+    const int nsub = 1 << K;
+    for (int row = 0; row < K; ++row) {
+        const double ui = pref ? (double)pref[row] : 1.0 / K;
+        double c[MAXK];
+        for (int i = 0; i < K; ++i) c[i] = G[i][row] * ui;
+        double cmax = 1.0;
+        for (int i = 0; i < K; ++i) cmax = fmax(cmax, fabs(c[i]));
+        double best_viol = 1e300;
+        int best_mask = 0;
+        double best_v[MAXK];
+        for (int i = 0; i < K; ++i) best_v[i] = 0.0;
+        for (int mask = lane; mask < nsub; mask += 64) {
+            int idx[MAXK], nf = 0;
+            for (int i = 0; i < K; ++i)
+                if (mask >> i & 1) idx[nf++] = i;
+            double L[MAXK][MAXK], y[MAXK], v[MAXK];
+            bool ok = true;
+            for (int a = 0; a < nf; ++a) {
+                for (int b = 0; b <= a; ++b) {
+                    double s = G[idx[a]][idx[b]];
+                    for (int q = 0; q < b; ++q) s -= L[a][q] * L[b][q];
+                    if (a == b) {
+                        if (s <= 0.0) { ok = false; s = 1.0; }
+                        L[a][a] = sqrt(s);
+                    } else {
+                        L[a][b] = s / L[b][b];
+                    }
+                }
+            }
+            for (int a = 0; a < nf; ++a) {
+                double s = -c[idx[a]];
+                for (int q = 0; q < a; ++q) s -= L[a][q] * y[q];
+                y[a] = s / L[a][a];
+            }
+            for (int i = 0; i < K; ++i) v[i] = 0.0;
+            for (int a = nf - 1; a >= 0; --a) {
+                double s = y[a];
+                for (int q = a + 1; q < nf; ++q) s -= L[q][a] * v[idx[q]];
+                v[idx[a]] = s / L[a][a];
+            }
+            double viol = ok ? 0.0 : 1e200;
+            for (int i = 0; i < K; ++i) {
+                if (mask >> i & 1) {
+                    viol = fmax(viol, -v[i]);
+                } else {
+                    double gr = c[i];
+                    for (int j = 0; j < K; ++j) gr += G[i][j] * v[j];
+                    viol = fmax(viol, -gr);
+                }
+            }
+            if (viol < best_viol) {
+                best_viol = viol;
+                best_mask = mask;
+                for (int i = 0; i < K; ++i) best_v[i] = v[i];
+            }
+        }
+        // wave arg-min on (violation, mask)
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ov = __shfl_xor(best_viol, o, 64);
+            const int om = __shfl_xor(best_mask, o, 64);
+            double tmp[MAXK];
+            for (int i = 0; i < K; ++i) tmp[i] = __shfl_xor(best_v[i], o, 64);
+            if (ov < best_viol || (ov == best_viol && om < best_mask)) {
+                best_viol = ov;
+                best_mask = om;
+                for (int i = 0; i < K; ++i) best_v[i] = tmp[i];
+            }
+        }
+        for (int i = 0; i < K; ++i) wsum[i] += best_v[i] + (i == row ? ui : 0.0);
+        (void)cmax;
+    }
+    if (lane == 0)
+        for (int i = 0; i < K; ++i) wout[i] = (float)wsum[i];
+}
+
+// ---- MGDA Frank-Wolfe (fp32, op order of utils/torchmoo/mgda.py:241-265) ------------------------------
+__global__ void mgda_k(const float* __restrict__ Gin, int K, int norm, const float* __restrict__ losses, float epsilon,
+                       int max_iters, float* __restrict__ wout, int* __restrict__ info) {
+    if (threadIdx.x != 0) return;
+    float G[MAXK][MAXK], nrm[MAXK], ls[MAXK];
+    for (int i = 0; i < K; ++i) {
+        nrm[i] = sqrtf(fmaxf(Gin[i * K + i], 1e-20f));
+        ls[i] = losses ? fmaxf(losses[i], 1e-20f) : 1.f;
+    }
+    for (int i = 0; i < K; ++i)
+        for (int j = 0; j < K; ++j) {
+            float d = 1.f;
+            if (norm == MOVAE_MGDA_L2) d = nrm[i] * nrm[j];
+            else if (norm == MOVAE_MGDA_LOSS) d = ls[i] * ls[j];
+            else if (norm == MOVAE_MGDA_LOSS_PLUS) d = (ls[i] * nrm[i]) * (ls[j] * nrm[j]);
+            G[i][j] = Gin[i * K + j] / d;
+        }
+    float alpha[MAXK], Ga[MAXK];
+    for (int i = 0; i < K; ++i) alpha[i] = 1.f / K;
+    int it = 0;
+    for (it = 0; it < max_iters; ++it) {
+        int t = 0;
+        for (int i = 0; i < K; ++i) {
+            float s = 0.f;
+            for (int j = 0; j < K; ++j) s += G[i][j] * alpha[j];
+            Ga[i] = s;
+            if (s < Ga[t]) t = i;  // first minimum
+        }
+        float a = 0.f, b = 0.f;
+        for (int i = 0; i < K; ++i) {
+            a += alpha[i] * G[i][t];
+            b += alpha[i] * Ga[i];
+        }
+        const float c = G[t][t];
+        float gamma;
+        if (c <= a) gamma = 1.f;
+        else if (b <= a) gamma = 0.f;
+        else gamma = (b - a) / (b + c - 2.f * a);
+        for (int i = 0; i < K; ++i) alpha[i] = (1.f - gamma) * alpha[i];
+        alpha[t] += gamma;
+        if (gamma < epsilon) { ++it; break; }
+    }
+    for (int i = 0; i < K; ++i) wout[i] = alpha[i];
+    if (info) info[0] = it > max_iters ? max_iters : it;
+}
+
+// ---- Aligned-MTL: cyclic Jacobi eigen-decomposition in fp64 + balance transformation ------------------------
+__global__ void amtl_k(const float* __restrict__ Gin, int K, int scale_mode, const float* __restrict__ pref,
+                       float* __restrict__ wout) {
+    if (threadIdx.x != 0) return;
+    double A[MAXK][MAXK], V[MAXK][MAXK];
+    for (int i = 0; i < K; ++i)
+        for (int j = 0; j < K; ++j) {
+            // eigh(UPLO="U") reads the upper triangle only
+            A[i][j] = (double)(i <= j ? Gin[i * K + j] : Gin[j * K + i]);
+            V[i][j] = i == j ? 1.0 : 0.0;
+        }
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int i = 0; i < K; ++i)
+            for (int j = 0; j < K; ++j) (i == j ? diag : off) += A[i][j] * A[i][j];
+        if (off <= 1e-30 * (diag + 1e-300)) break;
+        for (int p = 0; p < K - 1; ++p)
+            for (int q = p + 1; q < K; ++q) {
+                if (A[p][q] == 0.0) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / sqrt(tt * tt + 1.0), sn = tt * cs;
+                for (int k = 0; k < K; ++k) {
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = cs * akp - sn * akq;
+                    A[k][q] = sn * akp + cs * akq;
+                }
+                for (int k = 0; k < K; ++k) {
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = cs * apk - sn * aqk;
+                    A[q][k] = sn * apk + cs * aqk;
+                }
+                for (int k = 0; k < K; ++k) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = cs * vkp - sn * vkq;
+                    V[k][q] = sn * vkp + cs * vkq;
+                }
+            }
+    }
+    double lam[MAXK];
+    int order[MAXK];
+    double lmax = -1e300;
+    for (int i = 0; i < K; ++i) {
+        lam[i] = A[i][i];
+        order[i] = i;
+        lmax = fmax(lmax, lam[i]);
+    }
+    double w0[MAXK];
+    for (int i = 0; i < K; ++i) w0[i] = pref ? (double)pref[i] : 1.0 / K;
+    const double tol = lmax * K * 1.1920928955078125e-07;  // torch.finfo(float32).eps
+    int rank = 0;
+    for (int i = 0; i < K; ++i) rank += lam[i] > tol;
+    if (rank == 0) {
+        for (int i = 0; i < K; ++i) wout[i] = (float)w0[i];
+        return;
+    }
+    for (int i = 1; i < K; ++i) {  // descending insertion sort of indices
+        const int oi = order[i];
+        int j = i - 1;
+        while (j >= 0 && lam[order[j]] < lam[oi]) {
+            order[j + 1] = order[j];
+            --j;
+        }
+        order[j + 1] = oi;
+    }
+    double scale;
+    if (scale_mode == MOVAE_AMTL_MEDIAN) {
+        scale = lam[order[rank - 1 - (rank - 1) / 2]];  // lower middle of the kept (ascending) values
+    } else if (scale_mode == MOVAE_AMTL_RMSE) {
+        scale = 0.0;
+        for (int r = 0; r < rank; ++r) scale += lam[order[r]];
+        scale /= rank;
+    } else {
+        scale = lam[order[rank - 1]];
+    }
+    // alpha = sqrt(scale) * V diag(lam^-1/2) V^T w0   over the kept eigen-pairs
+    double out[MAXK];
+    for (int i = 0; i < K; ++i) out[i] = 0.0;
+    for (int r = 0; r < rank; ++r) {
+        const int e = order[r];
+        double proj = 0.0;
+        for (int k = 0; k < K; ++k) proj += V[k][e] * w0[k];
+        proj /= sqrt(lam[e]);
+        for (int i = 0; i < K; ++i) out[i] += V[i][e] * proj;
+    }
+    const double sc = sqrt(scale);
+    for (int i = 0; i < K; ++i) wout[i] = (float)(sc * out[i]);
+}
+
+__global__ void const_k(int K, float value, float* __restrict__ w) {
+    if (threadIdx.x < K) w[threadIdx.x] = value;
+}
+
+template <int K>
+int launch_gram_k(const float* J, size_t ldj, size_t m, double* part, int nb, bool vec, hipStream_t st) {
+    if (vec)
+        hipLaunchKernelGGL((gram_partial<K, true>), dim3(nb), dim3(256), 0, st, J, (long)ldj, (long)m, part);
+    else
+        hipLaunchKernelGGL((gram_partial<K, false>), dim3(nb), dim3(256), 0, st, J, (long)ldj, (long)m, part);
+    MOVAE_CHECK_LAUNCH("gram_partial");
+    return MOVAE_OK;
+}
+
+template <int K>
+int launch_combine_k(const float* J, size_t ldj, size_t m, const float* w, float* g, int acc, bool vec, hipStream_t st) {
+    const int nb = gram_blocks(m);
+    if (vec)
+        hipLaunchKernelGGL((combine_k<K, true>), dim3(nb), dim3(256), 0, st, J, (long)ldj, (long)m, w, g, acc);
+    else
+        hipLaunchKernelGGL((combine_k<K, false>), dim3(nb), dim3(256), 0, st, J, (long)ldj, (long)m, w, g, acc);
+    MOVAE_CHECK_LAUNCH("combine");
+    return MOVAE_OK;
+}
+
+#define DISPATCH_K(k, CALL)                                      \
+    switch (k) {                                                 \
+        case 1: return CALL(1);                                  \
+        case 2: return CALL(2);                                  \
+        case 3: return CALL(3);                                  \
+        case 4: return CALL(4);                                  \
+        case 5: return CALL(5);                                  \
+        case 6: return CALL(6);                                  \
+        case 7: return CALL(7);                                  \
+        case 8: return CALL(8);                                  \
+        default: break;                                          \
+    }
+
+}  // namespace
+
+extern "C" {
+
+size_t movae_gram_ws_bytes(int k, size_t m) {
+    if (k <= 0) return 0;
+    return (size_t)gram_blocks(m) * (size_t)(k * (k + 1) / 2) * sizeof(double);
+}
+
+int movae_gram(const float* J, size_t ldj, int k, size_t m, float* G, void* ws, size_t ws_bytes, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(J && G && m > 0 && ldj >= m, "movae_gram: bad argument");
+    MOVAE_CHECK_ARG(k >= 1 && k <= MAXK, "movae_gram: k=%d outside 1..%d", k, MAXK);
+    MOVAE_CHECK_ARG(ws && ws_bytes >= movae_gram_ws_bytes(k, m), "movae_gram: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    double* part = static_cast<double*>(ws);
+    const int nb = gram_blocks(m);
+    const bool vec = (ldj % 4 == 0) && (reinterpret_cast<uintptr_t>(J) & 15) == 0;
+    int rc = MOVAE_EINVAL;
+#define CALL_GRAM(KK) launch_gram_k<KK>(J, ldj, m, part, nb, vec, st)
+    rc = [&]() -> int { DISPATCH_K(k, CALL_GRAM) return MOVAE_EINVAL; }();
+#undef CALL_GRAM
+    if (rc) return rc;
+    hipLaunchKernelGGL(gram_final, dim3(1), dim3(64), 0, st, part, nb, k, G);
+    MOVAE_CHECK_LAUNCH("gram_final");
+    return MOVAE_OK;
+}
+
+int movae_combine(const float* J, size_t ldj, int k, size_t m, const float* w, float* g, int accumulate, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(J && w && g && m > 0 && ldj >= m, "movae_combine: bad argument");
+    MOVAE_CHECK_ARG(k >= 1 && k <= MAXK, "movae_combine: k=%d outside 1..%d", k, MAXK);
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = (ldj % 4 == 0) && ((reinterpret_cast<uintptr_t>(J) | reinterpret_cast<uintptr_t>(g)) & 15) == 0;
+#define CALL_COMB(KK) launch_combine_k<KK>(J, ldj, m, w, g, accumulate, vec, st)
+    return [&]() -> int { DISPATCH_K(k, CALL_COMB) return MOVAE_EINVAL; }();
+#undef CALL_COMB
+}
+
+int movae_gd_similarity(const float* J, size_t ldj, int k, size_t m, const float* w, float* out, void* ws, size_t ws_bytes,
+                        movae_stream_t stream) {
+    MOVAE_CHECK_ARG(J && w && out && m > 0 && k >= 1 && k <= MAXK, "movae_gd_similarity: bad argument");
+    const int nb = gram_blocks(m);
+    MOVAE_CHECK_ARG(ws && ws_bytes >= (size_t)nb * 3 * sizeof(double), "movae_gd_similarity: workspace too small");
+    double* part = static_cast<double*>(ws);
+    hipLaunchKernelGGL(similarity_partial, dim3(nb), dim3(256), 0, (hipStream_t)stream, J, (long)ldj, k, (long)m, w, part);
+    MOVAE_CHECK_LAUNCH("similarity_partial");
+    hipLaunchKernelGGL(similarity_final, dim3(1), dim3(64), 0, (hipStream_t)stream, part, nb, out);
+    MOVAE_CHECK_LAUNCH("similarity_final");
+    return MOVAE_OK;
+}
+
+int movae_weights_upgrad(const float* G, int k, float norm_eps, float reg_eps, const float* pref, float* w, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(G && w, "movae_weights_upgrad: null pointer");
+    MOVAE_CHECK_ARG(k >= 1 && k <= MAXK, "movae_weights_upgrad: k=%d outside 1..%d", k, MAXK);
+    hipLaunchKernelGGL(upgrad_k, dim3(1), dim3(64), 0, (hipStream_t)stream, G, k, norm_eps, reg_eps, pref, w);
+    MOVAE_CHECK_LAUNCH("upgrad");
+    return MOVAE_OK;
+}
+
+int movae_weights_mgda(const float* G, int k, int norm, const float* losses, float epsilon, int max_iters, float* w,
+                       int32_t* info, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(G && w, "movae_weights_mgda: null pointer");
+    MOVAE_CHECK_ARG(k >= 1 && k <= MAXK, "movae_weights_mgda: k=%d outside 1..%d", k, MAXK);
+    MOVAE_CHECK_ARG(norm >= 0 && norm <= 3, "movae_weights_mgda: unknown norm %d", norm);
+    MOVAE_CHECK_ARG(!(norm >= MOVAE_MGDA_LOSS && !losses),
+                    "Losses must be set before calling forward() when using norm_type='loss'/'loss+'");
+    hipLaunchKernelGGL(mgda_k, dim3(1), dim3(64), 0, (hipStream_t)stream, G, k, norm, losses, epsilon, max_iters, w, info);
+    MOVAE_CHECK_LAUNCH("mgda");
+    return MOVAE_OK;
+}
+
+int movae_weights_amtl(const float* G, int k, int scale_mode, const float* pref, float* w, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(G && w, "movae_weights_amtl: null pointer");
+    MOVAE_CHECK_ARG(k >= 1 && k <= MAXK, "movae_weights_amtl: k=%d outside 1..%d", k, MAXK);
+    MOVAE_CHECK_ARG(scale_mode >= 0 && scale_mode <= 2, "Invalid scale_mode=%d. Expected 'min', 'median', or 'rmse'.", scale_mode);
+    hipLaunchKernelGGL(amtl_k, dim3(1), dim3(64), 0, (hipStream_t)stream, G, k, scale_mode, pref, w);
+    MOVAE_CHECK_LAUNCH("amtl");
+    return MOVAE_OK;
+}
+
+int movae_weights_const(int k, float value, float* w, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(w && k >= 1 && k <= MAXK, "movae_weights_const: bad argument");
+    hipLaunchKernelGGL(const_k, dim3(1), dim3(64), 0, (hipStream_t)stream, k, value, w);
+    MOVAE_CHECK_LAUNCH("const_w");
+    return MOVAE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,265 @@
+// BatchNorm2d (training statistics) + activation over NHWC activations viewed as [rows][C].
+// HBM-bound: the statistics pass reads y once (fp64 accumulation, deterministic two-stage
+// reduction), the apply pass reads y and writes out once.  Backward mirrors it.
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_PARTS = 512;
+
+__host__ __device__ inline int pow2_ge(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+struct Split {
+    int CB;          // columns handled per pass (power of two <= 256)
+    int RG;          // row groups per block = 256 / CB
+    int rows_per_block;
+    int nblk;
+};
+
+inline Split make_split(int rows, int c) {
+    Split s;
+    s.CB = pow2_ge(c) < 256 ? pow2_ge(c) : 256;
+    s.RG = 256 / s.CB;
+    int rpb = ceil_div(rows, MAX_PARTS);
+    rpb = ceil_div(rpb, s.RG) * s.RG;
+    if (rpb < s.RG * 4) rpb = s.RG * 4;
+    s.rows_per_block = rpb;
+    s.nblk = ceil_div(rows, rpb);
+    return s;
+}
+
+// partial[blk][c][2] = (sum y, sum y^2) over the block's rows
+__global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict__ y, double* __restrict__ part, int rows,
+                                                        int C, int CB, int rows_per_block) {
+    __shared__ double sh[2][256];
+    const int t = threadIdx.x;
+    const int RG = 256 / CB;
+    const int cl = t % CB, rg = t / CB;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min((long)rows, r0 + rows_per_block);
+    for (int cb = 0; cb < C; cb += CB) {
+        const int c = cb + cl;
+        double s = 0.0, q = 0.0;
+        if (c < C)
+            for (long r = r0 + rg; r < r1; r += RG) {
+                const double v = y[r * C + c];
+                s += v;
+                q += v * v;
+            }
+        sh[0][t] = s;
+        sh[1][t] = q;
+        __syncthreads();
+        if (rg == 0 && c < C) {
+            for (int i = 1; i < RG; ++i) {
+                s += sh[0][i * CB + cl];
+                q += sh[1][i * CB + cl];
+            }
+            part[((long)blockIdx.x * C + c) * 2 + 0] = s;
+            part[((long)blockIdx.x * C + c) * 2 + 1] = q;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void bn_stats_final(const double* __restrict__ part, int nblk, int rows, int C, float eps, float momentum,
+                               float* __restrict__ save_mean, float* __restrict__ save_rstd,
+                               float* __restrict__ running_mean, float* __restrict__ running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s += part[((long)b * C + c) * 2 + 0];
+        q += part[((long)b * C + c) * 2 + 1];
+    }
+    const double mean = s / rows;
+    double var = q / rows - mean * mean;
+    if (var < 0.0) var = 0.0;
+    save_mean[c] = (float)mean;
+    save_rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unb = rows > 1 ? var * ((double)rows / (rows - 1)) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+    }
+}
+
+__global__ void bn_eval_prepare(const float* __restrict__ running_mean, const float* __restrict__ running_var, float eps,
+                                float* __restrict__ save_mean, float* __restrict__ save_rstd, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    save_mean[c] = running_mean[c];
+    save_rstd[c] = 1.f / sqrtf(running_var[c] + eps);
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_apply(const float* __restrict__ y, const float* __restrict__ gamma,
+                                                const float* __restrict__ beta, const float* __restrict__ mean,
+                                                const float* __restrict__ rstd, float* __restrict__ out, long total, int C,
+                                                int act, float slope) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    if (VEC) {
+        const long nv = total / 4;
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
+            const int c = (int)((i * 4) % C);
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                o[j] = apply_act((v[j] - mean[c + j]) * rstd[c + j] * gamma[c + j] + beta[c + j], act, slope);
+            reinterpret_cast<f32x4*>(out)[i] = o;
+        }
+    } else {
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+            const int c = (int)(i % C);
+            out[i] = apply_act((y[i] - mean[c]) * rstd[c] * gamma[c] + beta[c], act, slope);
+        }
+    }
+}
+
+// backward partials: (sum dz, sum dz * xhat)
+__global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ dout, const float* __restrict__ y,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      double* __restrict__ part, int rows, int C, int CB,
+                                                      int rows_per_block, int act, float slope) {
+    __shared__ double sh[2][256];
+    const int t = threadIdx.x;
+    const int RG = 256 / CB;
+    const int cl = t % CB, rg = t / CB;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min((long)rows, r0 + rows_per_block);
+    for (int cb = 0; cb < C; cb += CB) {
+        const int c = cb + cl;
+        double s = 0.0, q = 0.0;
+        if (c < C) {
+            const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
+            for (long r = r0 + rg; r < r1; r += RG) {
+                const float xh = (y[r * C + c] - mu) * rs;
+                const float o = apply_act(xh * ga + be, act, slope);
+                const float dz = dout[r * C + c] * act_grad_from_out(o, act, slope);
+                s += dz;
+                q += (double)dz * xh;
+            }
+        }
+        sh[0][t] = s;
+        sh[1][t] = q;
+        __syncthreads();
+        if (rg == 0 && c < C) {
+            for (int i = 1; i < RG; ++i) {
+                s += sh[0][i * CB + cl];
+                q += sh[1][i * CB + cl];
+            }
+            part[((long)blockIdx.x * C + c) * 2 + 0] = s;
+            part[((long)blockIdx.x * C + c) * 2 + 1] = q;
+        }
+        __syncthreads();
+    }
+}
+
+// sums[c] = (mean dz, mean dz*xhat) ; dgamma / dbeta written
+__global__ void bn_bwd_final(const double* __restrict__ part, int nblk, int rows, int C, float* __restrict__ sums,
+                             float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s += part[((long)b * C + c) * 2 + 0];
+        q += part[((long)b * C + c) * 2 + 1];
+    }
+    sums[2 * c + 0] = (float)(s / rows);
+    sums[2 * c + 1] = (float)(q / rows);
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)q : (float)q;
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s : (float)s;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ dout, const float* __restrict__ y,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                    const float* __restrict__ sums, float* __restrict__ dy, long total,
+                                                    int C, int act, float slope) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c = (int)(i % C);
+        const float xh = (y[i] - mean[c]) * rstd[c];
+        const float o = apply_act(xh * gamma[c] + beta[c], act, slope);
+        const float dz = dout[i] * act_grad_from_out(o, act, slope);
+        dy[i] = gamma[c] * rstd[c] * (dz - sums[2 * c] - xh * sums[2 * c + 1]);
+    }
+}
+
+inline int grid_for(long total) {
+    long g = (total + 255) / 256;
+    return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t movae_bn_ws_bytes(int rows, int c) {
+    if (rows <= 0 || c <= 0) return 0;
+    const Split s = make_split(rows, c);
+    return (size_t)s.nblk * c * 2 * sizeof(double) + (size_t)c * 2 * sizeof(float) + 64;
+}
+
+int movae_bn_act_fwd(const float* y, const float* gamma, const float* beta, float* out, float* save_mean, float* save_rstd,
+                     float* running_mean, float* running_var, int rows, int c, float eps, float momentum, int training,
+                     int act, float slope, void* ws, size_t ws_bytes, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(y && gamma && beta && out && save_mean && save_rstd, "movae_bn_act_fwd: null pointer");
+    MOVAE_CHECK_ARG(rows > 0 && c > 0, "movae_bn_act_fwd: bad shape rows=%d c=%d", rows, c);
+    hipStream_t st = (hipStream_t)stream;
+    if (training) {
+        MOVAE_CHECK_ARG(ws && ws_bytes >= movae_bn_ws_bytes(rows, c), "movae_bn_act_fwd: workspace too small");
+        const Split s = make_split(rows, c);
+        double* part = static_cast<double*>(ws);
+        hipLaunchKernelGGL(bn_stats_partial, dim3(s.nblk), dim3(256), 0, st, y, part, rows, c, s.CB, s.rows_per_block);
+        MOVAE_CHECK_LAUNCH("bn_stats_partial");
+        hipLaunchKernelGGL(bn_stats_final, dim3(ceil_div(c, 128)), dim3(128), 0, st, part, s.nblk, rows, c, eps, momentum,
+                           save_mean, save_rstd, running_mean, running_var);
+        MOVAE_CHECK_LAUNCH("bn_stats_final");
+    } else {
+        MOVAE_CHECK_ARG(running_mean && running_var, "movae_bn_act_fwd: eval mode needs running statistics");
+        hipLaunchKernelGGL(bn_eval_prepare, dim3(ceil_div(c, 128)), dim3(128), 0, st, running_mean, running_var, eps,
+                           save_mean, save_rstd, c);
+        MOVAE_CHECK_LAUNCH("bn_eval_prepare");
+    }
+    const long total = (long)rows * c;
+    const bool vec = (c % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    if (vec)
+        hipLaunchKernelGGL(bn_apply<true>, dim3(grid_for(total / 4)), dim3(256), 0, st, y, gamma, beta, save_mean, save_rstd,
+                           out, total, c, act, slope);
+    else
+        hipLaunchKernelGGL(bn_apply<false>, dim3(grid_for(total)), dim3(256), 0, st, y, gamma, beta, save_mean, save_rstd,
+                           out, total, c, act, slope);
+    MOVAE_CHECK_LAUNCH("bn_apply");
+    return MOVAE_OK;
+}
+
+int movae_bn_act_bwd(const float* dout, const float* y, const float* gamma, const float* beta, const float* save_mean,
+                     const float* save_rstd, float* dy, float* dgamma, float* dbeta, int rows, int c, int act, float slope,
+                     int accumulate, void* ws, size_t ws_bytes, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(dout && y && gamma && beta && save_mean && save_rstd && dy, "movae_bn_act_bwd: null pointer");
+    MOVAE_CHECK_ARG(rows > 0 && c > 0, "movae_bn_act_bwd: bad shape rows=%d c=%d", rows, c);
+    MOVAE_CHECK_ARG(ws && ws_bytes >= movae_bn_ws_bytes(rows, c), "movae_bn_act_bwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const Split s = make_split(rows, c);
+    double* part = static_cast<double*>(ws);
+    float* sums = reinterpret_cast<float*>(part + (size_t)s.nblk * c * 2);
+    hipLaunchKernelGGL(bn_bwd_partial, dim3(s.nblk), dim3(256), 0, st, dout, y, gamma, beta, save_mean, save_rstd, part, rows,
+                       c, s.CB, s.rows_per_block, act, slope);
+    MOVAE_CHECK_LAUNCH("bn_bwd_partial");
+    hipLaunchKernelGGL(bn_bwd_final, dim3(ceil_div(c, 128)), dim3(128), 0, st, part, s.nblk, rows, c, sums, dgamma, dbeta,
+                       accumulate);
+    MOVAE_CHECK_LAUNCH("bn_bwd_final");
+    const long total = (long)rows * c;
+    hipLaunchKernelGGL(bn_bwd_apply, dim3(grid_for(total)), dim3(256), 0, st, dout, y, gamma, beta, save_mean, save_rstd, sums,
+                       dy, total, c, act, slope);
+    MOVAE_CHECK_LAUNCH("bn_bwd_apply");
+    return MOVAE_OK;
+}
+
+}  // extern "C"

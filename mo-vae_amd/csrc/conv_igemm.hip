@@ -1,0 +1,679 @@
+// Implicit-GEMM convolution family for gfx950 (MI355X), fp32 in / fp32 accumulate on
+// v_mfma_f32_32x32x2_f32 (exact fp32 fma chains -- the reference path is fp32 end to end).
+//
+// Three gather forms cover every conv / transposed-conv / linear pass of the hot path:
+//   FWD   y[p][n]  = sum_{tap,c} x[p*s - pad + tap][c] * W[n][tap][c]        conv fwd, convT dgrad, linear fwd
+//   BWD   y[p][n]  = sum_{tap,c} x[(p + pad - tap)/s][c] * W[c][tap][n]      conv dgrad, convT fwd, linear dgrad
+//                    (decomposed into s*s output-parity classes so no zero taps are multiplied)
+//   WGRAD dW[a][tap][b] = sum_p S[p][a] * Bg[p*s - pad + tap][b]             conv/convT/linear wgrad (split-K)
+// Activations are NHWC so the reduction channel is the contiguous axis of every gather; weights
+// are kept in the channels_last image of the reference's parameter shapes so no repacking pass
+// exists.  Block = 256 threads (4 waves), tile BM x BN x 16, operands staged k-major in LDS
+// (conflict-free ds_read_b32 per MFMA operand), global loads for tile t+1 issued before the
+// MFMAs of tile t.
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 16;
+
+struct Geom {
+    int Nimg;
+    int Hi, Wi, Cr;  // gathered tensor: spatial dims, reduction channels
+    int Ho, Wo, Nn;  // output pixel grid, output channels
+    int KH, KW, stride, pad;
+};
+
+struct Epilogue {
+    const float* bias;  // [Nn] or null
+    int act;
+    float slope;
+};
+
+template <int TM>
+__device__ __forceinline__ void mma_tile(const float* __restrict__ As, const float* __restrict__ Bs, int lda, int ldb,
+                                         int a_off, int b_off, f32x16 (&acc)[TM]) {
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+        const float b = Bs[(2 * kk + half) * ldb + b_off + l31];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const float a = As[(2 * kk + half) * lda + a_off + tm * 32 + l31];
+            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[tm], 0, 0, 0);
+        }
+    }
+}
+
+template <int BM, int BN>
+struct Tile {
+    static constexpr int WN = BN / 32;        // waves along N
+    static constexpr int WM = 4 / WN;         // waves along M
+    static constexpr int TM = BM / (WM * 32); // 32-row MFMA tiles per wave
+    static constexpr int LDA = BM + 2;        // k-major leading dims (+2 keeps the transposing store conflict-free)
+    static constexpr int LDB = BN + 2;
+    static_assert(TM >= 1, "tile");
+};
+
+// ------------------------------------------------------------------------------------------------
+// FWD form
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, bool VEC>
+__global__ __launch_bounds__(256) void igemm_fwd(const float* __restrict__ X, const float* __restrict__ W,
+                                                 float* __restrict__ Y, Geom g, Epilogue ep, int M, int K,
+                                                 int ktiles_per_split, float* __restrict__ slab) {
+    using T = Tile<BM, BN>;
+    __shared__ float As[BK * T::LDA];
+    __shared__ float Bs[BK * T::LDB];
+    const int t = threadIdx.x;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int N = g.Nn;
+    constexpr int AR = BM / 64;
+    constexpr int BR = (BN + 63) / 64;
+    const int kq = t & 3, r4 = t >> 2;
+
+    const float* a_base[AR];
+    int a_h0[AR], a_w0[AR];
+    bool a_ok[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        const int m = m0 + r4 + i * 64;
+        a_ok[i] = m < M;
+        const int mm = a_ok[i] ? m : 0;
+        const int hw = g.Ho * g.Wo;
+        const int img = mm / hw, rem = mm - img * hw;
+        const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
+        a_h0[i] = ho * g.stride - g.pad;
+        a_w0[i] = wo * g.stride - g.pad;
+        a_base[i] = X + (long)img * g.Hi * g.Wi * g.Cr;
+    }
+    const bool b_thread = (BN >= 64) || (r4 < BN);
+    bool b_ok[BR];
+    const float* b_base[BR];
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+        const int n = n0 + r4 + i * 64;
+        b_ok[i] = b_thread && n < N;
+        b_base[i] = W + (long)(b_ok[i] ? n : 0) * K;
+    }
+
+    const int nk_total = (K + BK - 1) / BK;
+    const int kt_begin = blockIdx.z * ktiles_per_split;
+    const int kt_end = min(nk_total, kt_begin + ktiles_per_split);
+
+    f32x4 ra[AR], rb[BR];
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK;
+        if (VEC) {
+            const int tap = k0 / g.Cr, c0 = k0 - tap * g.Cr;
+            const int kh = tap / g.KW, kw = tap - kh * g.KW;
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                const int h = a_h0[i] + kh, w = a_w0[i] + kw;
+                const bool v = a_ok[i] && h >= 0 && h < g.Hi && w >= 0 && w < g.Wi;
+                ra[i] = v ? *reinterpret_cast<const f32x4*>(a_base[i] + ((long)h * g.Wi + w) * g.Cr + c0 + kq * 4)
+                          : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int i = 0; i < BR; ++i)
+                rb[i] = b_ok[i] ? *reinterpret_cast<const f32x4*>(b_base[i] + k0 + kq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + kq * 4 + j;
+                const bool kv = k < K;
+                const int kk = kv ? k : 0;
+                const int tap = kk / g.Cr, c = kk - tap * g.Cr;
+                const int kh = tap / g.KW, kw = tap - kh * g.KW;
+#pragma unroll
+                for (int i = 0; i < AR; ++i) {
+                    const int h = a_h0[i] + kh, w = a_w0[i] + kw;
+                    const bool v = kv && a_ok[i] && h >= 0 && h < g.Hi && w >= 0 && w < g.Wi;
+                    ra[i][j] = v ? a_base[i][((long)h * g.Wi + w) * g.Cr + c] : 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < BR; ++i) rb[i][j] = (kv && b_ok[i]) ? b_base[i][kk] : 0.f;
+            }
+        }
+    };
+
+    f32x16 acc[T::TM];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    const int wave = t >> 6;
+    const int wm = wave / T::WN, wn = wave % T::WN;
+    if (kt_begin < kt_end) load_tile(kt_begin);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < AR; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) As[(kq * 4 + j) * T::LDA + r4 + i * 64] = ra[i][j];
+        if (b_thread) {
+#pragma unroll
+            for (int i = 0; i < BR; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Bs[(kq * 4 + j) * T::LDB + r4 + i * 64] = rb[i][j];
+        }
+        __syncthreads();
+        if (kt + 1 < kt_end) load_tile(kt + 1);
+        mma_tile<T::TM>(As, Bs, T::LDA, T::LDB, wm * T::TM * 32, wn * 32, acc);
+    }
+
+    const int lane = t & 63, half = lane >> 5, l31 = lane & 31;
+    const int n = n0 + wn * 32 + l31;
+    if (n >= N) return;
+    const bool to_slab = slab != nullptr;
+    const float bv = (!to_slab && ep.bias) ? ep.bias[n] : 0.f;
+    float* out = to_slab ? slab + (long)blockIdx.z * M * N : Y;
+#pragma unroll
+    for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * T::TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m < M) {
+                float v = acc[tm][r];
+                if (!to_slab) v = apply_act(v + bv, ep.act, ep.slope);
+                out[(long)m * N + n] = v;
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BWD form (one output-parity class per blockIdx.z)
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, bool VEC>
+__global__ __launch_bounds__(256) void igemm_bwd(const float* __restrict__ X, const float* __restrict__ W,
+                                                 float* __restrict__ Y, Geom g, Epilogue ep) {
+    using T = Tile<BM, BN>;
+    __shared__ float As[BK * T::LDA];
+    __shared__ float Bs[BK * T::LDB];
+    const int t = threadIdx.x;
+    const int s = g.stride;
+    const int ph = blockIdx.z / s, pw = blockIdx.z % s;
+    const int Hoc = (g.Ho - ph + s - 1) / s, Woc = (g.Wo - pw + s - 1) / s;
+    const int M = g.Nimg * Hoc * Woc;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    if (m0 >= M) return;
+    const int N = g.Nn;
+    const int kh0 = (ph + g.pad) % s, kw0 = (pw + g.pad) % s;
+    const int nA = kh0 < g.KH ? (g.KH - kh0 + s - 1) / s : 0;
+    const int nB = kw0 < g.KW ? (g.KW - kw0 + s - 1) / s : 0;
+    const int qh = (ph + g.pad - kh0) / s, qw = (pw + g.pad - kw0) / s;
+    const int K = nA * nB * g.Cr;
+    const int taps = g.KH * g.KW;
+
+    constexpr int AR = BM / 64;
+    const int kq = t & 3, r4 = t >> 2;
+    const float* a_base[AR];
+    int a_h0[AR], a_w0[AR];
+    bool a_ok[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        const int m = m0 + r4 + i * 64;
+        a_ok[i] = m < M;
+        const int mm = a_ok[i] ? m : 0;
+        const int hw = Hoc * Woc;
+        const int img = mm / hw, rem = mm - img * hw;
+        const int hc = rem / Woc, wc = rem - hc * Woc;
+        a_h0[i] = hc + qh;
+        a_w0[i] = wc + qw;
+        a_base[i] = X + (long)img * g.Hi * g.Wi * g.Cr;
+    }
+    // B tile: BK rows x BN cols, n contiguous
+    constexpr int BQ = BN / 4;  // float4 per k-row
+    const int bk = t / BQ, bnq = t % BQ;
+    const bool b_thread = bk < BK;
+
+    f32x4 ra[AR], rb;
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK;
+        if (VEC) {
+            const int tt = k0 / g.Cr, c0 = k0 - tt * g.Cr;
+            const int a = tt / nB, b = tt - a * nB;
+            const int kh = kh0 + s * a, kw = kw0 + s * b;
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                const int h = a_h0[i] - a, w = a_w0[i] - b;
+                const bool v = a_ok[i] && h >= 0 && h < g.Hi && w >= 0 && w < g.Wi;
+                ra[i] = v ? *reinterpret_cast<const f32x4*>(a_base[i] + ((long)h * g.Wi + w) * g.Cr + c0 + kq * 4)
+                          : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (b_thread) {
+                const int c = c0 + bk;
+                const int n = n0 + bnq * 4;
+                const float* src = W + ((long)c * taps + kh * g.KW + kw) * N + n;
+                if (n + 3 < N)
+                    rb = *reinterpret_cast<const f32x4*>(src);
+                else
+                    for (int j = 0; j < 4; ++j) rb[j] = (n + j < N) ? src[j] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + kq * 4 + j;
+                const bool kv = k < K;
+                const int kk = kv ? k : 0;
+                const int tt = kk / g.Cr, c = kk - tt * g.Cr;
+                const int a = nB > 0 ? tt / nB : 0, b = tt - a * nB;
+#pragma unroll
+                for (int i = 0; i < AR; ++i) {
+                    const int h = a_h0[i] - a, w = a_w0[i] - b;
+                    const bool v = kv && a_ok[i] && h >= 0 && h < g.Hi && w >= 0 && w < g.Wi;
+                    ra[i][j] = v ? a_base[i][((long)h * g.Wi + w) * g.Cr + c] : 0.f;
+                }
+            }
+            if (b_thread) {
+                const int k = k0 + bk;
+                const bool kv = k < K;
+                const int kk = kv ? k : 0;
+                const int tt = kk / g.Cr, c = kk - tt * g.Cr;
+                const int a = nB > 0 ? tt / nB : 0, b = tt - a * nB;
+                const int kh = kh0 + s * a, kw = kw0 + s * b;
+                const float* src = W + ((long)c * taps + kh * g.KW + kw) * N;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n0 + bnq * 4 + j;
+                    rb[j] = (kv && n < N) ? src[n] : 0.f;
+                }
+            }
+        }
+    };
+
+    f32x16 acc[T::TM];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    const int wave = t >> 6;
+    const int wm = wave / T::WN, wn = wave % T::WN;
+    const int nk = (K + BK - 1) / BK;
+    if (nk > 0) load_tile(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < AR; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) As[(kq * 4 + j) * T::LDA + r4 + i * 64] = ra[i][j];
+        if (b_thread) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Bs[bk * T::LDB + bnq * 4 + j] = rb[j];
+        }
+        __syncthreads();
+        if (kt + 1 < nk) load_tile(kt + 1);
+        mma_tile<T::TM>(As, Bs, T::LDA, T::LDB, wm * T::TM * 32, wn * 32, acc);
+    }
+
+    const int lane = t & 63, half = lane >> 5, l31 = lane & 31;
+    const int n = n0 + wn * 32 + l31;
+    if (n >= N) return;
+    const float bv = ep.bias ? ep.bias[n] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * T::TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m < M) {
+                const int hw = Hoc * Woc;
+                const int img = m / hw, rem = m - img * hw;
+                const int hc = rem / Woc, wc = rem - hc * Woc;
+                const long p = ((long)img * g.Ho + (hc * s + ph)) * g.Wo + (wc * s + pw);
+                Y[p * N + n] = apply_act(acc[tm][r] + bv, ep.act, ep.slope);
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// WGRAD form: dW[a][tap][b] = sum_p S[p][a] * Bg[p*s - pad + tap][b]   (M = Cs, N = taps*Cb, K = pixels)
+// ------------------------------------------------------------------------------------------------
+struct WGeom {
+    int Nimg;
+    int Hs, Ws, Cs;  // small-side tensor (conv: dy; convT: x)
+    int Hb, Wb, Cb;  // big-side tensor   (conv: x;  convT: dy)
+    int KH, KW, stride, pad;
+};
+
+template <int BM, int BN, bool VEC>
+__global__ __launch_bounds__(256) void igemm_wgrad(const float* __restrict__ S, const float* __restrict__ Bg,
+                                                   float* __restrict__ out, WGeom g, int K, int kchunk, int to_slab) {
+    using T = Tile<BM, BN>;
+    __shared__ float As[BK * T::LDA];
+    __shared__ float Bs[BK * T::LDB];
+    const int t = threadIdx.x;
+    const int M = g.Cs, N = g.KH * g.KW * g.Cb;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int k_begin = blockIdx.z * kchunk, k_end = min(K, k_begin + kchunk);
+
+    constexpr int AQ = BM / 4, BQ = BN / 4;  // float4 per k-row
+    constexpr int APASS = (BK * AQ + 255) / 256;
+    const int hw = g.Hs * g.Ws;
+
+    f32x4 ra[APASS], rb;
+    const int bk = t / BQ, bnq = t % BQ;
+    const bool b_thread = bk < BK;
+    // column (n) decode is loop invariant
+    int b_tap[4], b_c[4];
+    bool b_nv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + bnq * 4 + j;
+        b_nv[j] = n < N;
+        const int nn = b_nv[j] ? n : 0;
+        b_tap[j] = nn / g.Cb;
+        b_c[j] = nn - b_tap[j] * g.Cb;
+    }
+    const int tap0_kh = b_tap[0] / g.KW, tap0_kw = b_tap[0] - tap0_kh * g.KW;
+
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int pss = 0; pss < APASS; ++pss) {
+            const int id = t + pss * 256;
+            const int ak = id / AQ, amq = id % AQ;
+            const int k = k0 + ak, m = m0 + amq * 4;
+            if (ak < BK) {
+                if (VEC) {
+                    ra[pss] = (k < k_end && m < M) ? *reinterpret_cast<const f32x4*>(S + (long)k * M + m)
+                                                 : f32x4{0.f, 0.f, 0.f, 0.f};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ra[pss][j] = (k < k_end && m + j < M) ? S[(long)k * M + m + j] : 0.f;
+                }
+            }
+        }
+        if (b_thread) {
+            const int k = k0 + bk;
+            const bool kv = k < k_end;
+            const int kk = kv ? k : 0;
+            const int img = kk / hw, rem = kk - img * hw;
+            const int hs = rem / g.Ws, ws = rem - hs * g.Ws;
+            const float* base = Bg + (long)img * g.Hb * g.Wb * g.Cb;
+            if (VEC) {
+                const int h = hs * g.stride - g.pad + tap0_kh, w = ws * g.stride - g.pad + tap0_kw;
+                const bool v = kv && b_nv[0] && h >= 0 && h < g.Hb && w >= 0 && w < g.Wb;
+                rb = v ? *reinterpret_cast<const f32x4*>(base + ((long)h * g.Wb + w) * g.Cb + b_c[0])
+                       : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int kh = b_tap[j] / g.KW, kw = b_tap[j] - kh * g.KW;
+                    const int h = hs * g.stride - g.pad + kh, w = ws * g.stride - g.pad + kw;
+                    const bool v = kv && b_nv[j] && h >= 0 && h < g.Hb && w >= 0 && w < g.Wb;
+                    rb[j] = v ? base[((long)h * g.Wb + w) * g.Cb + b_c[j]] : 0.f;
+                }
+            }
+        }
+    };
+
+    f32x16 acc[T::TM];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    const int wave = t >> 6;
+    const int wm = wave / T::WN, wn = wave % T::WN;
+    if (k_begin < k_end) load_tile(k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+        __syncthreads();
+#pragma unroll
+        for (int pss = 0; pss < APASS; ++pss) {
+            const int id = t + pss * 256;
+            const int ak = id / AQ, amq = id % AQ;
+            if (ak < BK) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) As[ak * T::LDA + amq * 4 + j] = ra[pss][j];
+            }
+        }
+        if (b_thread) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Bs[bk * T::LDB + bnq * 4 + j] = rb[j];
+        }
+        __syncthreads();
+        if (k0 + BK < k_end) load_tile(k0 + BK);
+        mma_tile<T::TM>(As, Bs, T::LDA, T::LDB, wm * T::TM * 32, wn * 32, acc);
+    }
+
+    const int lane = t & 63, half = lane >> 5, l31 = lane & 31;
+    const int n = n0 + wn * 32 + l31;
+    if (n >= N) return;
+    float* dst = to_slab ? out + (long)blockIdx.z * M * N : out;
+#pragma unroll
+    for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * T::TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m < M) dst[(long)m * N + n] = acc[tm][r];
+        }
+}
+
+// out[i] = (accumulate ? out[i] : 0) + sum_z slab[z][i], then optional bias (per column n = i % N) + activation
+__global__ void splitk_reduce(const float* __restrict__ slab, float* __restrict__ out, long total, int S, int N,
+                              const float* __restrict__ bias, int act, float slope, int accumulate) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    float v = 0.f;
+    for (int z = 0; z < S; ++z) v += slab[(long)z * total + i];
+    if (bias) v += bias[i % N];
+    v = apply_act(v, act, slope);
+    out[i] = accumulate ? out[i] + v : v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host dispatch
+// ------------------------------------------------------------------------------------------------
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <int BM, int BN>
+int launch_fwd_t(const float* X, const float* W, float* Y, const Geom& g, const Epilogue& ep, int M, int K, bool vec,
+                 void* ws, size_t ws_bytes, hipStream_t st) {
+    const int gx = ceil_div(M, BM), gy = ceil_div(g.Nn, BN);
+    const int nk = ceil_div(K, BK);
+    int S = 1;
+    const long tiles = (long)gx * gy;
+    if (tiles < 128 && nk >= 8 && ws) {
+        S = (int)min((long)(512 / tiles), (long)(nk / 4));
+        const size_t per = (size_t)M * g.Nn * sizeof(float);
+        while (S > 1 && per * S > ws_bytes) --S;
+        if (S < 2) S = 1;
+    }
+    const int per_split = ceil_div(nk, S);
+    S = ceil_div(nk, per_split);
+    float* slab = S > 1 ? static_cast<float*>(ws) : nullptr;
+    dim3 grid(gx, gy, S);
+    if (vec)
+        hipLaunchKernelGGL((igemm_fwd<BM, BN, true>), grid, dim3(256), 0, st, X, W, Y, g, ep, M, K, per_split, slab);
+    else
+        hipLaunchKernelGGL((igemm_fwd<BM, BN, false>), grid, dim3(256), 0, st, X, W, Y, g, ep, M, K, per_split, slab);
+    MOVAE_CHECK_LAUNCH("igemm_fwd");
+    if (S > 1) {
+        const long total = (long)M * g.Nn;
+        hipLaunchKernelGGL(splitk_reduce, dim3(ceil_div(total, 256)), dim3(256), 0, st, slab, Y, total, S, g.Nn, ep.bias,
+                           ep.act, ep.slope, 0);
+        MOVAE_CHECK_LAUNCH("splitk_reduce");
+    }
+    return MOVAE_OK;
+}
+
+int launch_fwd(const float* X, const float* W, float* Y, const Geom& g, const Epilogue& ep, void* ws, size_t ws_bytes,
+               hipStream_t st) {
+    const long Ml = (long)g.Nimg * g.Ho * g.Wo;
+    const long Kl = (long)g.KH * g.KW * g.Cr;
+    if (Ml <= 0 || g.Nn <= 0 || Kl <= 0 || Ml > 0x7fffffffL) {
+        movae_set_error("conv fwd-form: bad shape M=%ld N=%d K=%ld", Ml, g.Nn, Kl);
+        return MOVAE_EINVAL;
+    }
+    const int M = (int)Ml, K = (int)Kl;
+    const bool vec = (g.Cr % BK == 0) && aligned16(X) && aligned16(W);
+    if (g.Nn <= 32) return launch_fwd_t<128, 32>(X, W, Y, g, ep, M, K, vec, ws, ws_bytes, st);
+    if (Ml >= 128 * 512) return launch_fwd_t<128, 64>(X, W, Y, g, ep, M, K, vec, ws, ws_bytes, st);
+    return launch_fwd_t<64, 64>(X, W, Y, g, ep, M, K, vec, ws, ws_bytes, st);
+}
+
+template <int BM, int BN>
+int launch_bwd_t(const float* X, const float* W, float* Y, const Geom& g, const Epilogue& ep, bool vec, hipStream_t st) {
+    const int s = g.stride;
+    const long Mmax = (long)g.Nimg * ceil_div(g.Ho, s) * ceil_div(g.Wo, s);
+    dim3 grid(ceil_div(Mmax, BM), ceil_div(g.Nn, BN), s * s);
+    if (vec)
+        hipLaunchKernelGGL((igemm_bwd<BM, BN, true>), grid, dim3(256), 0, st, X, W, Y, g, ep);
+    else
+        hipLaunchKernelGGL((igemm_bwd<BM, BN, false>), grid, dim3(256), 0, st, X, W, Y, g, ep);
+    MOVAE_CHECK_LAUNCH("igemm_bwd");
+    return MOVAE_OK;
+}
+
+int launch_bwd(const float* X, const float* W, float* Y, const Geom& g, const Epilogue& ep, hipStream_t st) {
+    const long Ml = (long)g.Nimg * g.Ho * g.Wo;
+    if (Ml <= 0 || g.Nn <= 0 || g.Cr <= 0 || Ml > 0x7fffffffL) {
+        movae_set_error("conv bwd-form: bad shape M=%ld N=%d Cr=%d", Ml, g.Nn, g.Cr);
+        return MOVAE_EINVAL;
+    }
+    const bool vec = (g.Cr % BK == 0) && (g.Nn % 4 == 0) && aligned16(X) && aligned16(W);
+    const long Mc = Ml / (g.stride * g.stride);
+    if (g.Nn <= 32) return launch_bwd_t<128, 32>(X, W, Y, g, ep, vec, st);
+    if (Mc >= 128 * 512) return launch_bwd_t<128, 64>(X, W, Y, g, ep, vec, st);
+    return launch_bwd_t<64, 64>(X, W, Y, g, ep, vec, st);
+}
+
+template <int BM, int BN>
+int launch_wgrad_t(const float* S, const float* Bg, float* dW, const WGeom& g, int K, bool vec, int accumulate, void* ws,
+                   size_t ws_bytes, hipStream_t st) {
+    const int M = g.Cs, N = g.KH * g.KW * g.Cb;
+    const int gx = ceil_div(M, BM), gy = ceil_div(N, BN);
+    const long tiles = (long)gx * gy;
+    int Sp = 1;
+    if (ws) {
+        Sp = (int)max(1L, min((long)(1024 / tiles), (long)(K / (4 * BK))));
+        const size_t per = (size_t)M * N * sizeof(float);
+        while (Sp > 1 && per * Sp > ws_bytes) --Sp;
+    }
+    int kchunk = ceil_div(ceil_div(K, Sp), BK) * BK;
+    Sp = ceil_div(K, kchunk);
+    const bool slab = Sp > 1 || accumulate;
+    if (slab && (!ws || (size_t)M * N * sizeof(float) * Sp > ws_bytes)) {
+        movae_set_error("wgrad: workspace too small (%zu bytes) for %d splits of %dx%d", ws_bytes, Sp, M, N);
+        return MOVAE_EINVAL;
+    }
+    float* out = slab ? static_cast<float*>(ws) : dW;
+    dim3 grid(gx, gy, Sp);
+    if (vec)
+        hipLaunchKernelGGL((igemm_wgrad<BM, BN, true>), grid, dim3(256), 0, st, S, Bg, out, g, K, kchunk, slab ? 1 : 0);
+    else
+        hipLaunchKernelGGL((igemm_wgrad<BM, BN, false>), grid, dim3(256), 0, st, S, Bg, out, g, K, kchunk, slab ? 1 : 0);
+    MOVAE_CHECK_LAUNCH("igemm_wgrad");
+    if (slab) {
+        const long total = (long)M * N;
+        hipLaunchKernelGGL(splitk_reduce, dim3(ceil_div(total, 256)), dim3(256), 0, st, out, dW, total, Sp, N,
+                           (const float*)nullptr, 0, 0.f, accumulate);
+        MOVAE_CHECK_LAUNCH("splitk_reduce");
+    }
+    return MOVAE_OK;
+}
+
+int launch_wgrad(const float* S, const float* Bg, float* dW, const WGeom& g, int accumulate, void* ws, size_t ws_bytes,
+                 hipStream_t st) {
+    const long Kl = (long)g.Nimg * g.Hs * g.Ws;
+    if (Kl <= 0 || Kl > 0x7fffffffL || g.Cs <= 0 || g.Cb <= 0) {
+        movae_set_error("wgrad: bad shape K=%ld Cs=%d Cb=%d", Kl, g.Cs, g.Cb);
+        return MOVAE_EINVAL;
+    }
+    const bool vec = (g.Cs % 4 == 0) && (g.Cb % 4 == 0) && aligned16(S) && aligned16(Bg);
+    const int N = g.KH * g.KW * g.Cb;
+    if (N <= 32) return launch_wgrad_t<128, 32>(S, Bg, dW, g, (int)Kl, vec, accumulate, ws, ws_bytes, st);
+    return launch_wgrad_t<64, 64>(S, Bg, dW, g, (int)Kl, vec, accumulate, ws, ws_bytes, st);
+}
+
+int check_conv_shape(const char* who, int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride,
+                     int pad, bool transposed) {
+    if (n <= 0 || hi <= 0 || wi <= 0 || ci <= 0 || ho <= 0 || wo <= 0 || co <= 0 || kh <= 0 || kw <= 0 || stride <= 0 ||
+        pad < 0) {
+        movae_set_error("%s: non-positive dimension", who);
+        return MOVAE_EINVAL;
+    }
+    if (!transposed) {
+        if ((hi + 2 * pad - kh) / stride + 1 != ho || (wi + 2 * pad - kw) / stride + 1 != wo) {
+            movae_set_error("%s: output %dx%d inconsistent with input %dx%d k%dx%d s%d p%d", who, ho, wo, hi, wi, kh, kw,
+                            stride, pad);
+            return MOVAE_EINVAL;
+        }
+    } else {
+        const int op_h = ho - ((hi - 1) * stride - 2 * pad + kh), op_w = wo - ((wi - 1) * stride - 2 * pad + kw);
+        if (op_h < 0 || op_h >= stride || op_w < 0 || op_w >= stride) {
+            movae_set_error("%s: transposed output %dx%d inconsistent with input %dx%d k%dx%d s%d p%d", who, ho, wo, hi, wi,
+                            kh, kw, stride, pad);
+            return MOVAE_EINVAL;
+        }
+    }
+    return MOVAE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int movae_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int n, int hi, int wi, int ci, int ho,
+                     int wo, int co, int kh, int kw, int stride, int pad, int act, float slope, void* ws, size_t ws_bytes,
+                     movae_stream_t stream) {
+    MOVAE_CHECK_ARG(x && w && y, "movae_conv2d_fwd: null pointer");
+    if (int rc = check_conv_shape("movae_conv2d_fwd", n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, false)) return rc;
+    Geom g{n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad};
+    return launch_fwd(x, w, y, g, Epilogue{bias, act, slope}, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int movae_conv2d_dgrad(const float* dy, const float* w, float* dx, int n, int hi, int wi, int ci, int ho, int wo, int co,
+                       int kh, int kw, int stride, int pad, void* ws, size_t ws_bytes, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(dy && w && dx, "movae_conv2d_dgrad: null pointer");
+    if (int rc = check_conv_shape("movae_conv2d_dgrad", n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, false)) return rc;
+    // gathered tensor = dy (ho x wo x co), output grid = dx (hi x wi x ci); W[co][tap][ci] is the [Cr][tap][Nn] image
+    Geom g{n, ho, wo, co, hi, wi, ci, kh, kw, stride, pad};
+    (void)ws; (void)ws_bytes;
+    return launch_bwd(dy, w, dx, g, Epilogue{nullptr, MOVAE_ACT_NONE, 0.f}, (hipStream_t)stream);
+}
+
+int movae_conv2d_wgrad(const float* dy, const float* x, float* dw, float* dbias, int n, int hi, int wi, int ci, int ho,
+                       int wo, int co, int kh, int kw, int stride, int pad, int accumulate, void* ws, size_t ws_bytes,
+                       movae_stream_t stream) {
+    MOVAE_CHECK_ARG(dy && x && dw, "movae_conv2d_wgrad: null pointer");
+    if (int rc = check_conv_shape("movae_conv2d_wgrad", n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, false)) return rc;
+    WGeom g{n, ho, wo, co, hi, wi, ci, kh, kw, stride, pad};
+    if (int rc = launch_wgrad(dy, x, dw, g, accumulate, ws, ws_bytes, (hipStream_t)stream)) return rc;
+    if (dbias) return movae_colsum(dy, dbias, n * ho * wo, co, accumulate, ws, ws_bytes, stream);
+    return MOVAE_OK;
+}
+
+int movae_convT2d_fwd(const float* x, const float* w, const float* bias, float* y, int n, int hi, int wi, int ci, int ho,
+                      int wo, int co, int kh, int kw, int stride, int pad, int act, float slope, void* ws, size_t ws_bytes,
+                      movae_stream_t stream) {
+    MOVAE_CHECK_ARG(x && w && y, "movae_convT2d_fwd: null pointer");
+    if (int rc = check_conv_shape("movae_convT2d_fwd", n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, true)) return rc;
+    Geom g{n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad};
+    (void)ws; (void)ws_bytes;
+    return launch_bwd(x, w, y, g, Epilogue{bias, act, slope}, (hipStream_t)stream);
+}
+
+int movae_convT2d_dgrad(const float* dy, const float* w, float* dx, int n, int hi, int wi, int ci, int ho, int wo, int co,
+                        int kh, int kw, int stride, int pad, void* ws, size_t ws_bytes, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(dy && w && dx, "movae_convT2d_dgrad: null pointer");
+    if (int rc = check_conv_shape("movae_convT2d_dgrad", n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, true)) return rc;
+    // dx[p][ci] = sum dy[p*s - pad + tap][co] * W[ci][tap][co]  : FWD form over dy with W as [Nn=ci][tap][Cr=co]
+    Geom g{n, ho, wo, co, hi, wi, ci, kh, kw, stride, pad};
+    return launch_fwd(dy, w, dx, g, Epilogue{nullptr, MOVAE_ACT_NONE, 0.f}, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int movae_convT2d_wgrad(const float* dy, const float* x, float* dw, float* dbias, int n, int hi, int wi, int ci, int ho,
+                        int wo, int co, int kh, int kw, int stride, int pad, int accumulate, void* ws, size_t ws_bytes,
+                        movae_stream_t stream) {
+    MOVAE_CHECK_ARG(dy && x && dw, "movae_convT2d_wgrad: null pointer");
+    if (int rc = check_conv_shape("movae_convT2d_wgrad", n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, true)) return rc;
+    WGeom g{n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad};
+    if (int rc = launch_wgrad(x, dy, dw, g, accumulate, ws, ws_bytes, (hipStream_t)stream)) return rc;
+    if (dbias) return movae_colsum(dy, dbias, n * ho * wo, co, accumulate, ws, ws_bytes, stream);
+    return MOVAE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,249 @@
+// Element-wise / layout kernels (all HBM-bound; 16-byte accesses wherever alignment allows).
+#include "common.h"
+
+namespace {
+
+inline int grid_for(long total, int per = 256) {
+    long g = (total + per - 1) / per;
+    return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+
+inline bool al16(const void* a, const void* b = nullptr, const void* c = nullptr) {
+    return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
+}
+
+// per image: src [R][Cc] -> dst [Cc][R]  (batched 2-D transpose through a padded LDS tile)
+__global__ __launch_bounds__(256) void transpose_batched(const float* __restrict__ src, float* __restrict__ dst, int R, int Cc) {
+    __shared__ float tile[32][33];
+    const long img = blockIdx.z;
+    const float* s = src + img * (long)R * Cc;
+    float* d = dst + img * (long)R * Cc;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        const int r = r0 + ty + i, c = c0 + tx;
+        if (r < R && c < Cc) tile[ty + i][tx] = s[(long)r * Cc + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        const int c = c0 + ty + i, r = r0 + tx;
+        if (r < R && c < Cc) d[(long)c * R + r] = tile[tx][ty + i];
+    }
+}
+
+template <bool VEC>
+__global__ void act_fwd_k(const float* __restrict__ x, float* __restrict__ y, long n, int act, float slope) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    if (VEC) {
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n / 4; i += stride) {
+            f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], act, slope);
+            reinterpret_cast<f32x4*>(y)[i] = v;
+        }
+    } else {
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = apply_act(x[i], act, slope);
+    }
+}
+
+template <bool VEC>
+__global__ void act_bwd_k(const float* __restrict__ dy, const float* __restrict__ out, float* __restrict__ dx, long n,
+                          int act, float slope) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    if (VEC) {
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n / 4; i += stride) {
+            const f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
+            const f32x4 o = reinterpret_cast<const f32x4*>(out)[i];
+            f32x4 r;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = g[j] * act_grad_from_out(o[j], act, slope);
+            reinterpret_cast<f32x4*>(dx)[i] = r;
+        }
+    } else {
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+            dx[i] = dy[i] * act_grad_from_out(out[i], act, slope);
+    }
+}
+
+template <bool VEC>
+__global__ void axpby_k(float alpha, const float* __restrict__ a, float beta, const float* __restrict__ b,
+                        float* __restrict__ y, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    if (VEC) {
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n / 4; i += stride) {
+            const f32x4 u = reinterpret_cast<const f32x4*>(a)[i];
+            const f32x4 v = reinterpret_cast<const f32x4*>(b)[i];
+            reinterpret_cast<f32x4*>(y)[i] = alpha * u + beta * v;
+        }
+    } else {
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = alpha * a[i] + beta * b[i];
+    }
+}
+
+__global__ void copy_channels_k(const float* __restrict__ src, float* __restrict__ dst, long rows, int c_src, int c_dst,
+                                int src_off, int dst_off, int c_copy) {
+    const long total = rows * c_copy;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const long r = i / c_copy;
+        const int c = (int)(i - r * c_copy);
+        dst[r * c_dst + dst_off + c] = src[r * c_src + src_off + c];
+    }
+}
+
+// column sums, two-stage fp64
+__global__ __launch_bounds__(256) void colsum_partial(const float* __restrict__ x, double* __restrict__ part, int rows, int C,
+                                                      int CB, int rows_per_block) {
+    __shared__ double sh[256];
+    const int t = threadIdx.x;
+    const int RG = 256 / CB;
+    const int cl = t % CB, rg = t / CB;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min((long)rows, r0 + rows_per_block);
+    for (int cb = 0; cb < C; cb += CB) {
+        const int c = cb + cl;
+        double s = 0.0;
+        if (c < C)
+            for (long r = r0 + rg; r < r1; r += RG) s += x[r * C + c];
+        sh[t] = s;
+        __syncthreads();
+        if (rg == 0 && c < C) {
+            for (int i = 1; i < RG; ++i) s += sh[i * CB + cl];
+            part[(long)blockIdx.x * C + c] = s;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void colsum_final(const double* __restrict__ part, int nblk, int C, float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += part[(long)b * C + c];
+    out[c] = accumulate ? out[c] + (float)s : (float)s;
+}
+
+__global__ void reparam_fwd_k(const float* __restrict__ mu, const float* __restrict__ lv, const float* __restrict__ eps,
+                              float* __restrict__ z, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) z[i] = mu[i] + eps[i] * expf(0.5f * lv[i]);
+}
+
+__global__ void reparam_bwd_k(const float* __restrict__ dz, const float* __restrict__ lv, const float* __restrict__ eps,
+                              float* __restrict__ dmu, float* __restrict__ dlv, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float g = dz[i];
+        dmu[i] = g;
+        dlv[i] = g * eps[i] * expf(0.5f * lv[i]) * 0.5f;
+    }
+}
+
+inline int pow2_ge(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int movae_nchw_to_nhwc(const float* src, float* dst, int n, int c, int h, int w, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(src && dst && n > 0 && c > 0 && h > 0 && w > 0, "movae_nchw_to_nhwc: bad argument");
+    const int R = c, Cc = h * w;  // per image [C][HW] -> [HW][C]
+    dim3 grid(ceil_div(Cc, 32), ceil_div(R, 32), n);
+    hipLaunchKernelGGL(transpose_batched, grid, dim3(256), 0, (hipStream_t)stream, src, dst, R, Cc);
+    MOVAE_CHECK_LAUNCH("transpose_batched");
+    return MOVAE_OK;
+}
+
+int movae_nhwc_to_nchw(const float* src, float* dst, int n, int c, int h, int w, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(src && dst && n > 0 && c > 0 && h > 0 && w > 0, "movae_nhwc_to_nchw: bad argument");
+    const int R = h * w, Cc = c;  // per image [HW][C] -> [C][HW]
+    dim3 grid(ceil_div(Cc, 32), ceil_div(R, 32), n);
+    hipLaunchKernelGGL(transpose_batched, grid, dim3(256), 0, (hipStream_t)stream, src, dst, R, Cc);
+    MOVAE_CHECK_LAUNCH("transpose_batched");
+    return MOVAE_OK;
+}
+
+int movae_act_fwd(const float* x, float* y, size_t n, int act, float slope, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(x && y && n > 0, "movae_act_fwd: bad argument");
+    if (n % 4 == 0 && al16(x, y))
+        hipLaunchKernelGGL(act_fwd_k<true>, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, x, y, (long)n, act, slope);
+    else
+        hipLaunchKernelGGL(act_fwd_k<false>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, (long)n, act, slope);
+    MOVAE_CHECK_LAUNCH("act_fwd");
+    return MOVAE_OK;
+}
+
+int movae_act_bwd(const float* dy, const float* out, float* dx, size_t n, int act, float slope, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(dy && out && dx && n > 0, "movae_act_bwd: bad argument");
+    if (n % 4 == 0 && al16(dy, out, dx))
+        hipLaunchKernelGGL(act_bwd_k<true>, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, dy, out, dx, (long)n, act, slope);
+    else
+        hipLaunchKernelGGL(act_bwd_k<false>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dy, out, dx, (long)n, act, slope);
+    MOVAE_CHECK_LAUNCH("act_bwd");
+    return MOVAE_OK;
+}
+
+int movae_axpby(float alpha, const float* a, float beta, const float* b, float* y, size_t n, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(a && b && y && n > 0, "movae_axpby: bad argument");
+    if (n % 4 == 0 && al16(a, b, y))
+        hipLaunchKernelGGL(axpby_k<true>, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, alpha, a, beta, b, y, (long)n);
+    else
+        hipLaunchKernelGGL(axpby_k<false>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, alpha, a, beta, b, y, (long)n);
+    MOVAE_CHECK_LAUNCH("axpby");
+    return MOVAE_OK;
+}
+
+int movae_add(const float* a, const float* b, float* y, size_t n, movae_stream_t stream) {
+    return movae_axpby(1.f, a, 1.f, b, y, n, stream);
+}
+
+int movae_copy_channels(const float* src, float* dst, int rows, int c_src, int c_dst, int src_off, int dst_off, int c_copy,
+                        movae_stream_t stream) {
+    MOVAE_CHECK_ARG(src && dst && rows > 0 && c_copy > 0 && src_off >= 0 && dst_off >= 0 && src_off + c_copy <= c_src &&
+                        dst_off + c_copy <= c_dst,
+                    "movae_copy_channels: bad argument");
+    hipLaunchKernelGGL(copy_channels_k, dim3(grid_for((long)rows * c_copy)), dim3(256), 0, (hipStream_t)stream, src, dst,
+                       (long)rows, c_src, c_dst, src_off, dst_off, c_copy);
+    MOVAE_CHECK_LAUNCH("copy_channels");
+    return MOVAE_OK;
+}
+
+int movae_colsum(const float* x, float* out, int rows, int c, int accumulate, void* ws, size_t ws_bytes, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(x && out && rows > 0 && c > 0, "movae_colsum: bad argument");
+    const int CB = pow2_ge(c) < 256 ? pow2_ge(c) : 256;
+    const int RG = 256 / CB;
+    int rpb = ceil_div(rows, 256);
+    rpb = ceil_div(rpb, RG) * RG;
+    if (rpb < RG * 4) rpb = RG * 4;
+    const int nblk = ceil_div(rows, rpb);
+    MOVAE_CHECK_ARG(ws && ws_bytes >= (size_t)nblk * c * sizeof(double), "movae_colsum: workspace too small");
+    double* part = static_cast<double*>(ws);
+    hipLaunchKernelGGL(colsum_partial, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, part, rows, c, CB, rpb);
+    MOVAE_CHECK_LAUNCH("colsum_partial");
+    hipLaunchKernelGGL(colsum_final, dim3(ceil_div(c, 128)), dim3(128), 0, (hipStream_t)stream, part, nblk, c, out, accumulate);
+    MOVAE_CHECK_LAUNCH("colsum_final");
+    return MOVAE_OK;
+}
+
+int movae_reparam_fwd(const float* mu, const float* log_var, const float* eps, float* z, size_t n, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(mu && log_var && eps && z && n > 0, "movae_reparam_fwd: bad argument");
+    hipLaunchKernelGGL(reparam_fwd_k, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, mu, log_var, eps, z, (long)n);
+    MOVAE_CHECK_LAUNCH("reparam_fwd");
+    return MOVAE_OK;
+}
+
+int movae_reparam_bwd(const float* dz, const float* log_var, const float* eps, float* dmu, float* dlog_var, size_t n,
+                      movae_stream_t stream) {
+    MOVAE_CHECK_ARG(dz && log_var && eps && dmu && dlog_var && n > 0, "movae_reparam_bwd: bad argument");
+    hipLaunchKernelGGL(reparam_bwd_k, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dz, log_var, eps, dmu, dlog_var, (long)n);
+    MOVAE_CHECK_LAUNCH("reparam_bwd");
+    return MOVAE_OK;
+}
+
+}  // extern "C"

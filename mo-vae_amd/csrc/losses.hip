@@ -1,0 +1,362 @@
+// Loss terms of the ELBO family: reconstruction objectives, KL to N(0, I), and the Beta-TC
+// decomposition (mutual information / total correlation / dimension-wise KL).
+// Reductions: per-thread fp32 term -> fp64 wave shuffle reduction -> fp64 block partial ->
+// single-block final (deterministic).
+#include "common.h"
+
+namespace {
+
+constexpr int RED_BLOCKS = 1024;
+
+inline int red_blocks(size_t n) {
+    size_t g = (n + 1023) / 1024;
+    return (int)(g > RED_BLOCKS ? RED_BLOCKS : (g < 1 ? 1 : g));
+}
+
+__device__ __forceinline__ float recon_term(float r, float x, int kind) {
+    switch (kind) {
+        case MOVAE_RECON_BCE: {
+            const float l1 = fmaxf(logf(r), -100.f), l2 = fmaxf(logf(1.f - r), -100.f);
+            return -(x * l1 + (1.f - x) * l2);
+        }
+        case MOVAE_RECON_L1: return fabsf(r - x);
+        case MOVAE_RECON_SMOOTH_L1: {
+            const float d = fabsf(r - x);
+            return d < 1.f ? 0.5f * d * d : d - 0.5f;
+        }
+        default: {
+            const float d = r - x;
+            return d * d;
+        }
+    }
+}
+
+__device__ __forceinline__ float recon_dterm(float r, float x, int kind) {
+    switch (kind) {
+        case MOVAE_RECON_BCE: return (r - x) / fmaxf((1.f - r) * r, 1e-12f);  // ATen binary_cross_entropy_backward
+        case MOVAE_RECON_L1: {
+            const float d = r - x;
+            return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        }
+        case MOVAE_RECON_SMOOTH_L1: {
+            const float d = r - x;
+            return fabsf(d) < 1.f ? d : (d > 0.f ? 1.f : -1.f);
+        }
+        default: return 2.f * (r - x);
+    }
+}
+
+__global__ __launch_bounds__(256) void recon_partial(const float* __restrict__ r, const float* __restrict__ x,
+                                                     double* __restrict__ part, long n, int kind) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) s += recon_term(r[i], x[i], kind);
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+// out[0] = factor * sum(part)
+__global__ __launch_bounds__(256) void final_sum(const double* __restrict__ part, int nblk, double factor,
+                                                 float* __restrict__ out) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) s += part[i];
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) out[0] = (float)(s * factor);
+}
+
+__global__ void recon_bwd_k(const float* __restrict__ r, const float* __restrict__ x, const float* __restrict__ gs,
+                            float* __restrict__ dr, long n, int kind, float factor) {
+    const float f = factor * (gs ? gs[0] : 1.f);
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dr[i] = f * recon_dterm(r[i], x[i], kind);
+}
+
+__global__ __launch_bounds__(256) void kl_partial(const float* __restrict__ mu, const float* __restrict__ lv,
+                                                  double* __restrict__ part, long n) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float m = mu[i], l = lv[i];
+        s += 1.f + l - m * m - expf(l);
+    }
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ void kl_bwd_k(const float* __restrict__ mu, const float* __restrict__ lv, const float* __restrict__ gs,
+                         float* __restrict__ dmu, float* __restrict__ dlv, long n, float factor) {
+    const float f = factor * (gs ? gs[0] : 1.f);
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        dmu[i] = f * mu[i];
+        dlv[i] = f * 0.5f * (expf(lv[i]) - 1.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Beta-TC decomposition.  One block per sample i; wave w sweeps j = w, w+4, ...; lanes sweep d.
+// ------------------------------------------------------------------------------------------------
+constexpr int TC_DU = 8;  // D <= 64 * TC_DU
+constexpr float LOG_2PI = 1.8378770664093453f;
+
+struct Lse {
+    float m, s;
+    __device__ void init() { m = -INFINITY; s = 0.f; }
+    __device__ void add(float v) {
+        if (v > m) {
+            s = s * expf(m - v) + 1.f;
+            m = v;
+        } else {
+            s += expf(v - m);
+        }
+    }
+    __device__ void merge(float m2, float s2) {
+        if (m2 == -INFINITY) return;
+        if (m2 > m) {
+            s = s * expf(m - m2) + s2;
+            m = m2;
+        } else {
+            s += s2 * expf(m2 - m);
+        }
+    }
+    __device__ float value() const { return m + logf(s); }
+};
+
+__global__ __launch_bounds__(256) void tc_fwd_k(const float* __restrict__ z, const float* __restrict__ mu,
+                                                const float* __restrict__ lv, const float* __restrict__ liw,
+                                                float* __restrict__ lse_joint /* [B + B*B] */,
+                                                float* __restrict__ lse_marg /* [B][D] */, float* __restrict__ rows /* [B][3] */,
+                                                int B, int D) {
+    extern __shared__ float smem[];  // 4 waves x (2 + 2*D) floats
+    const int i = blockIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float zi[TC_DU];
+#pragma unroll
+    for (int u = 0; u < TC_DU; ++u) {
+        const int d = lane + 64 * u;
+        zi[u] = d < D ? z[(long)i * D + d] : 0.f;
+    }
+    Lse joint;
+    joint.init();
+    Lse marg[TC_DU];
+#pragma unroll
+    for (int u = 0; u < TC_DU; ++u) marg[u].init();
+    float own = 0.f;  // sum_d m_iid, accumulated by the wave that owns j == i
+    for (int j = w; j < B; j += 4) {
+        const float L = liw[(long)i * B + j];
+        float part = 0.f;
+#pragma unroll
+        for (int u = 0; u < TC_DU; ++u) {
+            const int d = lane + 64 * u;
+            if (d < D) {
+                const float l = lv[(long)j * D + d];
+                const float df = zi[u] - mu[(long)j * D + d];
+                const float m = -0.5f * (LOG_2PI + l) - 0.5f * (df * df * expf(-l));
+                part += m;
+                marg[u].add(m + L);
+            }
+        }
+        const float sum = wave_sum(part);
+        if (j == i) own = sum;
+        const float a = sum + (float)D * L;
+        joint.add(a);
+        if (lane == 0) lse_joint[B + (long)i * B + j] = a;
+    }
+    // merge the four waves
+    float* sj = smem;                 // [4][2]
+    float* sm = smem + 8;             // [4][D][2]
+    float* so = smem + 8 + 8 * D;     // [4]
+    if (lane == 0) {
+        sj[2 * w] = joint.m;
+        sj[2 * w + 1] = joint.s;
+        so[w] = own;
+    }
+#pragma unroll
+    for (int u = 0; u < TC_DU; ++u) {
+        const int d = lane + 64 * u;
+        if (d < D) {
+            sm[((long)w * D + d) * 2] = marg[u].m;
+            sm[((long)w * D + d) * 2 + 1] = marg[u].s;
+        }
+    }
+    __syncthreads();
+    if (w == 0) {
+        Lse J;
+        J.init();
+        for (int q = 0; q < 4; ++q) J.merge(sj[2 * q], sj[2 * q + 1]);
+        const float lqz = J.value();
+        float lp = 0.f, lpz = 0.f;
+#pragma unroll
+        for (int u = 0; u < TC_DU; ++u) {
+            const int d = lane + 64 * u;
+            if (d < D) {
+                Lse Mg;
+                Mg.init();
+                for (int q = 0; q < 4; ++q) Mg.merge(sm[((long)q * D + d) * 2], sm[((long)q * D + d) * 2 + 1]);
+                const float v = Mg.value();
+                lse_marg[(long)i * D + d] = v;
+                lp += v;
+                lpz += -0.5f * (LOG_2PI + zi[u] * zi[u]);
+            }
+        }
+        lp = wave_sum(lp);
+        lpz = wave_sum(lpz);
+        if (lane == 0) {
+            const float lqzx = so[0] + so[1] + so[2] + so[3];
+            lse_joint[i] = lqz;
+            rows[i * 3 + 0] = lqzx - lqz;
+            rows[i * 3 + 1] = lqz - lp;
+            rows[i * 3 + 2] = lp - lpz;
+        }
+    }
+}
+
+__global__ void tc_mean_k(const float* __restrict__ rows, float* __restrict__ out, int B) {
+    const int q = threadIdx.x;
+    if (q >= 3) return;
+    double s = 0.0;
+    for (int i = 0; i < B; ++i) s += rows[i * 3 + q];
+    out[q] = (float)(s / B);
+}
+
+// dz[i][d] : block per i, thread per d
+__global__ void tc_bwd_dz(const float* __restrict__ z, const float* __restrict__ mu, const float* __restrict__ lv,
+                          const float* __restrict__ liw, const float* __restrict__ lse_joint,
+                          const float* __restrict__ lse_marg, const float* __restrict__ g, float* __restrict__ dz, int B,
+                          int D) {
+    const int i = blockIdx.x;
+    const float gmi = g[0] / B, cq = (g[1] - g[0]) / B, cp = (g[2] - g[1]) / B, gk = g[2] / B;
+    const float lqz = lse_joint[i];
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        const float zi = z[(long)i * D + d], lm = lse_marg[(long)i * D + d];
+        float acc = 0.f;
+        for (int j = 0; j < B; ++j) {
+            const float l = lv[(long)j * D + d];
+            const float iv = expf(-l), df = zi - mu[(long)j * D + d];
+            const float m = -0.5f * (LOG_2PI + l) - 0.5f * (df * df * iv);
+            const float P = expf(lse_joint[B + (long)i * B + j] - lqz);
+            const float Q = expf(m + liw[(long)i * B + j] - lm);
+            const float wgt = cq * P + cp * Q + (j == i ? gmi : 0.f);
+            acc += wgt * (-df * iv);
+        }
+        dz[(long)i * D + d] = acc + gk * zi;
+    }
+}
+
+// dmu[j][d], dlv[j][d] : block per j, thread per d
+__global__ void tc_bwd_dparams(const float* __restrict__ z, const float* __restrict__ mu, const float* __restrict__ lv,
+                               const float* __restrict__ liw, const float* __restrict__ lse_joint,
+                               const float* __restrict__ lse_marg, const float* __restrict__ g, float* __restrict__ dmu,
+                               float* __restrict__ dlv, int B, int D) {
+    const int j = blockIdx.x;
+    const float gmi = g[0] / B, cq = (g[1] - g[0]) / B, cp = (g[2] - g[1]) / B;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        const float l = lv[(long)j * D + d], mj = mu[(long)j * D + d];
+        const float iv = expf(-l);
+        float am = 0.f, al = 0.f;
+        for (int i = 0; i < B; ++i) {
+            const float df = z[(long)i * D + d] - mj;
+            const float m = -0.5f * (LOG_2PI + l) - 0.5f * (df * df * iv);
+            const float P = expf(lse_joint[B + (long)i * B + j] - lse_joint[i]);
+            const float Q = expf(m + liw[(long)i * B + j] - lse_marg[(long)i * D + d]);
+            const float wgt = cq * P + cp * Q + (j == i ? gmi : 0.f);
+            am += wgt * (df * iv);
+            al += wgt * (-0.5f + 0.5f * df * df * iv);
+        }
+        dmu[(long)j * D + d] = am;
+        dlv[(long)j * D + d] = al;
+    }
+}
+
+inline int grid_for(long total) {
+    long gq = (total + 255) / 256;
+    return (int)(gq > 4096 ? 4096 : (gq < 1 ? 1 : gq));
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t movae_reduce_ws_bytes(size_t n) { return (size_t)red_blocks(n) * sizeof(double); }
+
+int movae_recon_loss_fwd(const float* recons, const float* inputs, float* out, size_t n, int kind, float scale, void* ws,
+                         size_t ws_bytes, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(recons && inputs && out && n > 0, "movae_recon_loss_fwd: bad argument");
+    MOVAE_CHECK_ARG(kind >= 0 && kind <= 3, "movae_recon_loss_fwd: unknown objective %d", kind);
+    MOVAE_CHECK_ARG(ws && ws_bytes >= movae_reduce_ws_bytes(n), "movae_recon_loss_fwd: workspace too small");
+    const int nb = red_blocks(n);
+    double* part = static_cast<double*>(ws);
+    hipLaunchKernelGGL(recon_partial, dim3(nb), dim3(256), 0, (hipStream_t)stream, recons, inputs, part, (long)n, kind);
+    MOVAE_CHECK_LAUNCH("recon_partial");
+    hipLaunchKernelGGL(final_sum, dim3(1), dim3(256), 0, (hipStream_t)stream, part, nb, (double)scale / (double)n, out);
+    MOVAE_CHECK_LAUNCH("final_sum");
+    return MOVAE_OK;
+}
+
+int movae_recon_loss_bwd(const float* recons, const float* inputs, const float* gscale_dev, float* drecons, size_t n, int kind,
+                         float scale, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(recons && inputs && drecons && n > 0, "movae_recon_loss_bwd: bad argument");
+    MOVAE_CHECK_ARG(kind >= 0 && kind <= 3, "movae_recon_loss_bwd: unknown objective %d", kind);
+    hipLaunchKernelGGL(recon_bwd_k, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, recons, inputs, gscale_dev, drecons,
+                       (long)n, kind, scale / (float)n);
+    MOVAE_CHECK_LAUNCH("recon_bwd");
+    return MOVAE_OK;
+}
+
+int movae_kl_fwd(const float* mu, const float* log_var, float* out, int b, int d, float scale, void* ws, size_t ws_bytes,
+                 movae_stream_t stream) {
+    MOVAE_CHECK_ARG(mu && log_var && out && b > 0 && d > 0, "movae_kl_fwd: bad argument");
+    const size_t n = (size_t)b * d;
+    MOVAE_CHECK_ARG(ws && ws_bytes >= movae_reduce_ws_bytes(n), "movae_kl_fwd: workspace too small");
+    const int nb = red_blocks(n);
+    double* part = static_cast<double*>(ws);
+    hipLaunchKernelGGL(kl_partial, dim3(nb), dim3(256), 0, (hipStream_t)stream, mu, log_var, part, (long)n);
+    MOVAE_CHECK_LAUNCH("kl_partial");
+    hipLaunchKernelGGL(final_sum, dim3(1), dim3(256), 0, (hipStream_t)stream, part, nb, -0.5 * (double)scale / (double)b, out);
+    MOVAE_CHECK_LAUNCH("final_sum");
+    return MOVAE_OK;
+}
+
+int movae_kl_bwd(const float* mu, const float* log_var, const float* gscale_dev, float* dmu, float* dlog_var, int b, int d,
+                 float scale, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(mu && log_var && dmu && dlog_var && b > 0 && d > 0, "movae_kl_bwd: bad argument");
+    const long n = (long)b * d;
+    hipLaunchKernelGGL(kl_bwd_k, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, mu, log_var, gscale_dev, dmu, dlog_var, n,
+                       scale / (float)b);
+    MOVAE_CHECK_LAUNCH("kl_bwd");
+    return MOVAE_OK;
+}
+
+int movae_tc_decomp_fwd(const float* z, const float* mu, const float* log_var, const float* log_iw, float* out,
+                        float* lse_joint, float* lse_marg, int b, int d, void* ws, size_t ws_bytes, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(z && mu && log_var && log_iw && out && lse_joint && lse_marg, "movae_tc_decomp_fwd: null pointer");
+    MOVAE_CHECK_ARG(b > 1 && d > 0 && d <= 64 * TC_DU, "movae_tc_decomp_fwd: need b > 1 and d <= %d (got b=%d d=%d)", 64 * TC_DU, b, d);
+    MOVAE_CHECK_ARG(ws && ws_bytes >= (size_t)b * 3 * sizeof(float), "movae_tc_decomp_fwd: workspace too small");
+    float* rows = static_cast<float*>(ws);
+    const size_t sh = (size_t)(8 + 8 * d + 4) * sizeof(float);
+    hipLaunchKernelGGL(tc_fwd_k, dim3(b), dim3(256), sh, (hipStream_t)stream, z, mu, log_var, log_iw, lse_joint, lse_marg, rows, b, d);
+    MOVAE_CHECK_LAUNCH("tc_fwd");
+    hipLaunchKernelGGL(tc_mean_k, dim3(1), dim3(64), 0, (hipStream_t)stream, rows, out, b);
+    MOVAE_CHECK_LAUNCH("tc_mean");
+    return MOVAE_OK;
+}
+
+int movae_tc_decomp_bwd(const float* z, const float* mu, const float* log_var, const float* log_iw, const float* lse_joint,
+                        const float* lse_marg, const float* g, float* dz, float* dmu, float* dlog_var, int b, int d,
+                        movae_stream_t stream) {
+    MOVAE_CHECK_ARG(z && mu && log_var && log_iw && lse_joint && lse_marg && g && dz && dmu && dlog_var,
+                    "movae_tc_decomp_bwd: null pointer");
+    MOVAE_CHECK_ARG(b > 1 && d > 0, "movae_tc_decomp_bwd: bad shape");
+    const int th = d >= 256 ? 256 : (d >= 128 ? 128 : 64);
+    hipLaunchKernelGGL(tc_bwd_dz, dim3(b), dim3(th), 0, (hipStream_t)stream, z, mu, log_var, log_iw, lse_joint, lse_marg, g, dz, b, d);
+    MOVAE_CHECK_LAUNCH("tc_bwd_dz");
+    hipLaunchKernelGGL(tc_bwd_dparams, dim3(b), dim3(th), 0, (hipStream_t)stream, z, mu, log_var, log_iw, lse_joint, lse_marg, g,
+                       dmu, dlog_var, b, d);
+    MOVAE_CHECK_LAUNCH("tc_bwd_dparams");
+    return MOVAE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,233 @@
+// Vector-quantiser codebook lookup (models/vq_vae.py:27-64) for gfx950.
+// Distances are the contraction  E[K x D] . X^T[D x rows]  on v_mfma_f32_32x32x2_f32 with the
+// CODE index on the accumulator rows and the LATENT row on the lane, so the arg-min over codes is
+// lane-local (16 registers + one cross-half exchange) -- no K-wide distance matrix, no one-hot
+// matrix and no one-hot GEMM ever touch HBM (the reference materialises two [rows x K] fp32
+// temporaries).  The codebook chunk is staged once per block in LDS with a +1 padded row.
+#include "common.h"
+
+namespace {
+
+constexpr int CH = 128;        // codes staged per chunk
+constexpr int ROWS_PER_BLOCK = 128;
+
+template <int D>
+__global__ __launch_bounds__(256) void vq_nearest_mfma(const float* __restrict__ x, const float* __restrict__ e,
+                                                       float* __restrict__ q, int64_t* __restrict__ idx,
+                                                       double* __restrict__ sse_part, int* __restrict__ used, int rows,
+                                                       int K) {
+    constexpr int LD = D + 1;
+    __shared__ float Es[CH * LD];
+    __shared__ float ee[CH];
+    __shared__ double shd[4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int rowbase = blockIdx.x * ROWS_PER_BLOCK + wave * 32;
+    const int row = rowbase + l31;
+    const bool rv = row < rows;
+    float xf[D / 2];
+    float xx = 0.f;
+#pragma unroll
+    for (int s = 0; s < D / 2; ++s) {
+        xf[s] = rv ? x[(long)row * D + 2 * s + half] : 0.f;
+        xx += xf[s] * xf[s];
+    }
+    xx += __shfl_xor(xx, 32, 64);
+
+    float best = INFINITY;
+    int besti = 0;
+    for (int c0 = 0; c0 < K; c0 += CH) {
+        __syncthreads();
+        for (int i = t; i < CH * D; i += 256) {
+            const int r = i / D, d = i - r * D;
+            Es[r * LD + d] = (c0 + r < K) ? e[(long)(c0 + r) * D + d] : 0.f;
+        }
+        __syncthreads();
+        if (t < CH) {
+            float s = 0.f;
+#pragma unroll 8
+            for (int d = 0; d < D; ++d) s += Es[t * LD + d] * Es[t * LD + d];
+            ee[t] = s;
+        }
+        __syncthreads();
+        const int ntile = min(CH, K - c0);
+        for (int ct = 0; ct * 32 < ntile; ++ct) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float* ep = Es + (ct * 32 + l31) * LD + half;
+#pragma unroll
+            for (int s = 0; s < D / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ep[2 * s], xf[s], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cl = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int code = c0 + cl;
+                if (code < K) {
+                    const float dist = (xx + ee[cl]) - 2.f * acc[r];
+                    if (dist < best) {
+                        best = dist;
+                        besti = code;
+                    }
+                }
+            }
+        }
+    }
+    {   // merge the two halves of the wave (same latent row, disjoint code sets)
+        const float ob = __shfl_xor(best, 32, 64);
+        const int oi = __shfl_xor(besti, 32, 64);
+        if (ob < best || (ob == best && oi < besti)) {
+            best = ob;
+            besti = oi;
+        }
+    }
+    if (rv && half == 0) {
+        idx[row] = besti;
+        used[besti] = 1;
+    }
+    // gather q = E[idx] and accumulate sum (q - x)^2
+    double sse = 0.0;
+    for (int r = 0; r < 32; ++r) {
+        const int rr = rowbase + r;
+        if (rr >= rows) break;
+        const int bi = __shfl(besti, r, 64);
+        for (int d = lane; d < D; d += 64) {
+            const float qv = e[(long)bi * D + d];
+            const float dv = qv - x[(long)rr * D + d];
+            q[(long)rr * D + d] = qv;
+            sse += (double)(dv * dv);
+        }
+    }
+    sse = block_sum_256(sse, shd);
+    if (t == 0) sse_part[blockIdx.x] = sse;
+}
+
+// generic fallback (any D): one thread per latent row
+__global__ __launch_bounds__(256) void vq_nearest_generic(const float* __restrict__ x, const float* __restrict__ e,
+                                                          float* __restrict__ q, int64_t* __restrict__ idx,
+                                                          double* __restrict__ sse_part, int* __restrict__ used, int rows,
+                                                          int K, int D) {
+    __shared__ double shd[4];
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    double sse = 0.0;
+    if (row < rows) {
+        float xx = 0.f;
+        for (int d = 0; d < D; ++d) xx += x[(long)row * D + d] * x[(long)row * D + d];
+        float best = INFINITY;
+        int besti = 0;
+        for (int c = 0; c < K; ++c) {
+            float ee = 0.f, dot = 0.f;
+            for (int d = 0; d < D; ++d) {
+                const float ev = e[(long)c * D + d];
+                ee += ev * ev;
+                dot += ev * x[(long)row * D + d];
+            }
+            const float dist = (xx + ee) - 2.f * dot;
+            if (dist < best) {
+                best = dist;
+                besti = c;
+            }
+        }
+        idx[row] = besti;
+        used[besti] = 1;
+        for (int d = 0; d < D; ++d) {
+            const float qv = e[(long)besti * D + d];
+            const float dv = qv - x[(long)row * D + d];
+            q[(long)row * D + d] = qv;
+            sse += (double)(dv * dv);
+        }
+    }
+    sse = block_sum_256(sse, shd);
+    if (threadIdx.x == 0) sse_part[blockIdx.x] = sse;
+}
+
+__global__ __launch_bounds__(256) void vq_finalize(const double* __restrict__ part, int nblk, const int* __restrict__ used,
+                                                   int K, float* __restrict__ sse, int* __restrict__ used_count) {
+    __shared__ double shd[4];
+    double s = 0.0, u = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) s += part[i];
+    for (int i = threadIdx.x; i < K; i += 256) u += used[i] ? 1.0 : 0.0;
+    s = block_sum_256(s, shd);
+    u = block_sum_256(u, shd);
+    if (threadIdx.x == 0) {
+        sse[0] = (float)s;
+        if (used_count) used_count[0] = (int)(u + 0.5);
+    }
+}
+
+__global__ void vq_bwd_k(const float* __restrict__ x, const float* __restrict__ q, const int64_t* __restrict__ idx,
+                         const float* __restrict__ dq, const float* __restrict__ gc, const float* __restrict__ ge,
+                         float* __restrict__ dx, float* __restrict__ de, long rows, int D, float inv_numel) {
+    const float fc = gc ? gc[0] * 2.f * inv_numel : 0.f;
+    const float fe = ge ? ge[0] * 2.f * inv_numel : 0.f;
+    const long total = rows * D;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const float df = x[i] - q[i];
+        if (dx) dx[i] = (dq ? dq[i] : 0.f) + fc * df;
+        if (de && fe != 0.f) {
+            const long r = i / D;
+            const int d = (int)(i - r * D);
+            atomicAdd(&de[idx[r] * D + d], -fe * df);
+        }
+    }
+}
+
+template <int D>
+void launch_mfma(const float* x, const float* e, float* q, int64_t* idx, double* part, int* used, int rows, int K, int nblk,
+                 hipStream_t st) {
+    hipLaunchKernelGGL(vq_nearest_mfma<D>, dim3(nblk), dim3(256), 0, st, x, e, q, idx, part, used, rows, K);
+}
+
+}  // namespace
+
+extern "C" {
+
+int movae_vq_nearest_fwd(const float* x, const float* e, float* q, int64_t* idx, float* sse, int32_t* used_count, int rows,
+                         int k, int d, void* ws, size_t ws_bytes, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(x && e && q && idx && sse, "movae_vq_nearest_fwd: null pointer");
+    MOVAE_CHECK_ARG(rows > 0 && k > 0 && d > 0, "movae_vq_nearest_fwd: bad shape rows=%d k=%d d=%d", rows, k, d);
+    hipStream_t st = (hipStream_t)stream;
+    const bool mfma = d == 8 || d == 16 || d == 32 || d == 64 || d == 128;
+    const int nblk = mfma ? ceil_div(rows, ROWS_PER_BLOCK) : ceil_div(rows, 256);
+    const size_t need = (size_t)nblk * sizeof(double) + (size_t)k * sizeof(int);
+    MOVAE_CHECK_ARG(ws && ws_bytes >= need, "movae_vq_nearest_fwd: workspace too small (%zu < %zu)", ws_bytes, need);
+    double* part = static_cast<double*>(ws);
+    int* used = reinterpret_cast<int*>(part + nblk);
+    if (hipMemsetAsync(used, 0, (size_t)k * sizeof(int), st) != hipSuccess) {
+        movae_set_error("movae_vq_nearest_fwd: memset failed");
+        return MOVAE_ELAUNCH;
+    }
+    switch (mfma ? d : 0) {
+        case 8: launch_mfma<8>(x, e, q, idx, part, used, rows, k, nblk, st); break;
+        case 16: launch_mfma<16>(x, e, q, idx, part, used, rows, k, nblk, st); break;
+        case 32: launch_mfma<32>(x, e, q, idx, part, used, rows, k, nblk, st); break;
+        case 64: launch_mfma<64>(x, e, q, idx, part, used, rows, k, nblk, st); break;
+        case 128: launch_mfma<128>(x, e, q, idx, part, used, rows, k, nblk, st); break;
+        default:
+            hipLaunchKernelGGL(vq_nearest_generic, dim3(nblk), dim3(256), 0, st, x, e, q, idx, part, used, rows, k, d);
+    }
+    MOVAE_CHECK_LAUNCH("vq_nearest");
+    hipLaunchKernelGGL(vq_finalize, dim3(1), dim3(256), 0, st, part, nblk, used, k, sse, used_count);
+    MOVAE_CHECK_LAUNCH("vq_finalize");
+    return MOVAE_OK;
+}
+
+int movae_vq_bwd(const float* x, const float* q, const int64_t* idx, const float* dq, const float* gc, const float* ge,
+                 float* dx, float* de, int rows, int k, int d, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(x && q && idx, "movae_vq_bwd: null pointer");
+    MOVAE_CHECK_ARG(rows > 0 && k > 0 && d > 0, "movae_vq_bwd: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    if (de && hipMemsetAsync(de, 0, (size_t)k * d * sizeof(float), st) != hipSuccess) {
+        movae_set_error("movae_vq_bwd: memset failed");
+        return MOVAE_ELAUNCH;
+    }
+    const long total = (long)rows * d;
+    long gq = (total + 255) / 256;
+    if (gq > 4096) gq = 4096;
+    hipLaunchKernelGGL(vq_bwd_k, dim3((int)gq), dim3(256), 0, st, x, q, idx, dq, gc, ge, dx, de, (long)rows, d,
+                       1.f / (float)total);
+    MOVAE_CHECK_LAUNCH("vq_bwd");
+    return MOVAE_OK;
+}
+
+}  // extern "C"

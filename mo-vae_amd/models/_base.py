@@ -1,0 +1,79 @@
+"""Shared plumbing of the four hot-path models: loss-weight validation, summaries, noise source."""
+import torch
+import torch.nn as tnn
+
+from .. import nn as mnn
+from .. import ops
+
+
+def resolve_lambda_weights(owner, objectives, lambda_weights, defaults, list_order=None):
+    """dict | list | None -> dict keyed like `objectives` (models/vae.py:53-81 and siblings):
+    list length / dict keys are validated with the reference's exception types."""
+    keys = list(objectives.keys())
+    order = list_order or keys
+    if lambda_weights is None:
+        return dict(defaults)
+    if isinstance(lambda_weights, list):
+        if len(lambda_weights) != len(keys):
+            raise ValueError(f"{owner} requires {len(keys)} lambda_weights ({', '.join(order)}), got {len(lambda_weights)}")
+        return {k: lambda_weights[i] for i, k in enumerate(order)}
+    if isinstance(lambda_weights, dict):
+        expected, provided = set(keys), set(lambda_weights.keys())
+        if expected != provided:
+            missing, extra = expected - provided, provided - expected
+            msg = "lambda_weights keys must match objectives keys. "
+            if missing:
+                msg += f"Missing: {missing}. "
+            if extra:
+                msg += f"Extra: {extra}."
+            raise ValueError(msg)
+        return lambda_weights
+    raise TypeError(f"lambda_weights must be dict or list, got {type(lambda_weights)}")
+
+
+def activation_module(name):
+    if name not in mnn.ACTIVATIONS:
+        raise ValueError(f"recons_activation {name} not supported")
+    return mnn.ACTIVATIONS[name]()
+
+
+class HotPathModel(tnn.Module):
+    """Protocol consumed by the training loop (main.py:148,159-160,168,180-181): `.objectives`,
+    `.features`, `.lambda_weights`, forward -> dict, loss_function -> dict ending in total_loss."""
+
+    #: set to a tensor to replace torch.randn_like in reparameterize (seed-parity tests: the CPU and
+    #: HIP generators draw different streams, SURVEY section 7 "hard parts")
+    eps_override = None
+
+    def _noise_like(self, t):
+        if self.eps_override is not None:
+            return self.eps_override.to(device=t.device, dtype=t.dtype)
+        return torch.randn_like(t)
+
+    def total_trainable_params(self):
+        return sum(p.numel() for p in self.parameters() if p.requires_grad)
+
+    def print_model_summary(self):
+        """Layer table in place of torchsummary (absent offline); like the reference it runs one
+        eval-mode forward on a 2-image batch and returns None."""
+        was_training = self.training
+        try:
+            self.train(False)
+            dev = next(self.parameters()).device
+            x = torch.zeros(2, self.in_channels, self.input_size, self.input_size, device=dev)
+            with torch.no_grad():
+                self(x)
+            print(f"{'parameter':<44}{'shape':<24}{'count':>10}")
+            for n, p in self.named_parameters():
+                print(f"{n:<44}{str(tuple(p.shape)):<24}{p.numel():>10}")
+            print(f"Total trainable params: {self.total_trainable_params():,}")
+        except Exception as e:  # noqa: BLE001 -- the reference swallows summary errors too (models/vae.py:279-281)
+            print(f"Error printing model summary: {e}")
+        finally:
+            self.train(was_training)
+        return None
+
+
+def nchw_view(x_nhwc):
+    """NHWC buffer -> logical NCHW tensor (what callers of the reference models expect), zero copy."""
+    return x_nhwc.permute(0, 3, 1, 2)

@@ -1,0 +1,162 @@
+"""nn.Module shells whose parameters carry the reference's names / shapes / init sequence and whose
+forward passes run on the HIP ops (ops.py).  All modules consume and produce NHWC tensors
+([N, H, W, C]); the models convert at their NCHW boundary.
+
+Initialisation replays torch.nn's reset_parameters on a temporary contiguous tensor in the order
+the reference constructors create their layers, so a given seed yields bit-identical parameters
+(models/vae.py:117-173 etc.), then stores conv weights channels_last.
+"""
+import torch
+import torch.nn as tnn
+
+from . import ops
+
+LRELU_SLOPE = 0.01  # nn.LeakyReLU() default used everywhere in the reference
+
+
+def _channels_last_param(t):
+    return tnn.Parameter(t.detach().clone().contiguous(memory_format=torch.channels_last))
+
+
+class Conv2d(tnn.Module):
+    def __init__(self, cin, cout, k, stride=1, padding=0, bias=True):
+        super().__init__()
+        ref = tnn.Conv2d(cin, cout, k, stride=stride, padding=padding, bias=bias)  # draws the init RNG sequence
+        self.weight = _channels_last_param(ref.weight)
+        self.bias = tnn.Parameter(ref.bias.detach().clone()) if bias else None
+        self.stride, self.padding, self.kernel_size = stride, padding, k
+        self.in_channels, self.out_channels = cin, cout
+
+    def forward(self, x, act=None):
+        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, act, LRELU_SLOPE)
+
+    def extra_repr(self):
+        return f"{self.in_channels}, {self.out_channels}, k={self.kernel_size}, s={self.stride}, p={self.padding}"
+
+
+class ConvTranspose2d(tnn.Module):
+    def __init__(self, cin, cout, k, stride=1, padding=0, output_padding=0):
+        super().__init__()
+        ref = tnn.ConvTranspose2d(cin, cout, k, stride=stride, padding=padding, output_padding=output_padding)
+        self.weight = _channels_last_param(ref.weight)
+        self.bias = tnn.Parameter(ref.bias.detach().clone())
+        self.stride, self.padding, self.output_padding, self.kernel_size = stride, padding, output_padding, k
+        self.in_channels, self.out_channels = cin, cout
+
+    def forward(self, x, act=None):
+        return ops.conv_transpose2d(x, self.weight, self.bias, self.stride, self.padding, self.output_padding, act, LRELU_SLOPE)
+
+    def extra_repr(self):
+        return (f"{self.in_channels}, {self.out_channels}, k={self.kernel_size}, s={self.stride}, p={self.padding}, "
+                f"op={self.output_padding}")
+
+
+class Linear(tnn.Module):
+    def __init__(self, fin, fout):
+        super().__init__()
+        ref = tnn.Linear(fin, fout)
+        self.weight = tnn.Parameter(ref.weight.detach().clone())
+        self.bias = tnn.Parameter(ref.bias.detach().clone())
+        self.in_features, self.out_features = fin, fout
+
+    def forward(self, x):
+        return ops.linear(x, self.weight, self.bias)
+
+    def extra_repr(self):
+        return f"{self.in_features}, {self.out_features}"
+
+
+class BatchNorm2d(tnn.Module):
+    """nn.BatchNorm2d(affine, track_running_stats) semantics: eps 1e-5, momentum 0.1."""
+
+    def __init__(self, c, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.weight = tnn.Parameter(torch.ones(c))
+        self.bias = tnn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.eps, self.momentum, self.num_features = eps, momentum, c
+
+    def forward(self, y, act=None):
+        if self.training:
+            self.num_batches_tracked.add_(1)
+        return ops.batch_norm_act(y, self.weight, self.bias, self.running_mean, self.running_var, self.training, self.eps,
+                                  self.momentum, act, LRELU_SLOPE)
+
+    def extra_repr(self):
+        return f"{self.num_features}"
+
+
+class _Act(tnn.Module):
+    kind = None
+
+    def forward(self, x):
+        return ops.activation(x, self.kind, LRELU_SLOPE)
+
+
+class LeakyReLU(_Act):
+    kind = "lrelu"
+
+
+class ReLU(_Act):
+    kind = "relu"
+
+
+class Tanh(_Act):
+    kind = "tanh"
+
+
+class Sigmoid(_Act):
+    kind = "sigmoid"
+
+
+class Identity(_Act):
+    kind = None
+
+
+ACTIVATIONS = {"tanh": Tanh, "sigmoid": Sigmoid, "none": Identity}
+
+
+class Stack(tnn.Sequential):
+    """nn.Sequential (same child names, hence same state_dict keys) whose forward fuses
+    conv -> [batchnorm] -> activation runs into the conv / batch-norm kernels' epilogues."""
+
+    def forward(self, x):
+        mods = list(self)
+        i, n = 0, len(mods)
+        while i < n:
+            m = mods[i]
+            if isinstance(m, Stack):
+                x = m(x)
+                i += 1
+            elif isinstance(m, (Conv2d, ConvTranspose2d)):
+                nxt = mods[i + 1] if i + 1 < n else None
+                if isinstance(nxt, BatchNorm2d):
+                    act = mods[i + 2] if i + 2 < n and isinstance(mods[i + 2], _Act) else None
+                    x = nxt(m(x), act.kind if act is not None else None)
+                    i += 3 if act is not None else 2
+                elif isinstance(nxt, _Act):
+                    x = m(x, nxt.kind)
+                    i += 2
+                else:
+                    x = m(x)
+                    i += 1
+            else:
+                x = m(x)
+                i += 1
+        return x
+
+
+class Codebook(tnn.Module):
+    """nn.Embedding(K, D) drawn like models/vq_vae.py:24-25 (normal_ first, then uniform(-1/K, 1/K))."""
+
+    def __init__(self, K, D):
+        super().__init__()
+        ref = tnn.Embedding(K, D)
+        ref.weight.data.uniform_(-1.0 / K, 1.0 / K)
+        self.weight = tnn.Parameter(ref.weight.detach().clone())
+        self.num_embeddings, self.embedding_dim = K, D
+
+    def forward(self, code):
+        return self.weight[code]  # index gather for decode_code / sampling (outside the training path)

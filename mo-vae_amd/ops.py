@@ -1,0 +1,465 @@
+"""torch.autograd.Function wrappers over the C ABI (include/movae.h).
+
+PyTorch supplies device memory, the stream and the autograd tape; every FLOP below runs in
+libmovae_hip.so.  Activations are NHWC tensors of shape [N, H, W, C] (contiguous); conv weights
+are the reference's parameter shapes ([Co,Ci,kh,kw] / [Ci,Co,kh,kw]) held in channels_last memory
+so that `w.permute(0,2,3,1)` is the contiguous [.,kh,kw,.] image the kernels read.
+"""
+import torch
+from torch.autograd import Function
+
+from . import _lib as L
+
+
+def _call(name, *args):
+    L.check(getattr(L.load(), name)(*args), name)
+
+
+def _ws(t):
+    w = L.workspace(t.device)
+    return w.data_ptr(), w.numel()
+
+
+def _st(t):
+    return L.stream_ptr(t.device)
+
+
+def _c(t):
+    """contiguous fp32 view/copy of an incoming gradient"""
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def weight_mem(w):
+    """[a, b, kh, kw] parameter -> contiguous [a, kh, kw, b] memory image (no copy when the
+    parameter is channels_last, which is how nn.py creates it)."""
+    v = w.permute(0, 2, 3, 1)
+    if not v.is_contiguous():
+        v = v.contiguous()
+    return v
+
+
+def conv_out_size(h, k, s, p):
+    return (h + 2 * p - k) // s + 1
+
+
+def convT_out_size(h, k, s, p, op):
+    return (h - 1) * s - 2 * p + k + op
+
+
+# ---------------------------------------------------------------------------------------------
+class NchwToNhwc(Function):
+    @staticmethod
+    def forward(ctx, x):
+        L.require_gpu(x)
+        x = _c(x)
+        n, c, h, w = x.shape
+        y = torch.empty((n, h, w, c), dtype=x.dtype, device=x.device)
+        _call("movae_nchw_to_nhwc", x.data_ptr(), y.data_ptr(), n, c, h, w, _st(x))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        n, h, w, c = dy.shape
+        dx = torch.empty((n, c, h, w), dtype=dy.dtype, device=dy.device)
+        _call("movae_nhwc_to_nchw", dy.data_ptr(), dx.data_ptr(), n, c, h, w, _st(dy))
+        return dx
+
+
+class NhwcToNchw(Function):
+    @staticmethod
+    def forward(ctx, x):
+        L.require_gpu(x)
+        x = _c(x)
+        n, h, w, c = x.shape
+        y = torch.empty((n, c, h, w), dtype=x.dtype, device=x.device)
+        _call("movae_nhwc_to_nchw", x.data_ptr(), y.data_ptr(), n, c, h, w, _st(x))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        n, c, h, w = dy.shape
+        dx = torch.empty((n, h, w, c), dtype=dy.dtype, device=dy.device)
+        _call("movae_nchw_to_nhwc", dy.data_ptr(), dx.data_ptr(), n, c, h, w, _st(dy))
+        return dx
+
+
+def to_nhwc(x):
+    """logical NCHW tensor -> NHWC tensor (zero copy when it already is a permuted NHWC buffer)."""
+    v = x.permute(0, 2, 3, 1)
+    if v.is_contiguous():
+        return v
+    return NchwToNhwc.apply(x)
+
+
+def flatten_nchw(x_nhwc):
+    """nn.Flatten over the reference's NCHW ordering (models/vae.py:128)."""
+    n, h, w, c = x_nhwc.shape
+    if h == 1 and w == 1:
+        return x_nhwc.reshape(n, c)
+    return NhwcToNchw.apply(x_nhwc).reshape(n, c * h * w)
+
+
+def unflatten_nchw(x, c, h, w):
+    """nn.Unflatten(1, (C, H, W)) (models/vae.py:143) producing NHWC."""
+    n = x.shape[0]
+    if h == 1 and w == 1:
+        return x.reshape(n, 1, 1, c)
+    return NchwToNhwc.apply(x.reshape(n, c, h, w))
+
+
+# ---------------------------------------------------------------------------------------------
+class Conv(Function):
+    """conv2d / conv_transpose2d / linear (+bias, + fused activation)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, out_pad, transposed, act, slope):
+        L.require_gpu(x)
+        x = _c(x)
+        wm = weight_mem(w)
+        n, hi, wi, ci = x.shape
+        if transposed:
+            assert wm.shape[0] == ci, "ConvTranspose2d weight/in_channels mismatch"
+            kh, kw, co = wm.shape[1], wm.shape[2], wm.shape[3]
+            ho, wo = convT_out_size(hi, kh, stride, pad, out_pad), convT_out_size(wi, kw, stride, pad, out_pad)
+            fn = "movae_convT2d_fwd"
+        else:
+            assert wm.shape[3] == ci, "Conv2d weight/in_channels mismatch"
+            co, kh, kw = wm.shape[0], wm.shape[1], wm.shape[2]
+            ho, wo = conv_out_size(hi, kh, stride, pad), conv_out_size(wi, kw, stride, pad)
+            fn = "movae_conv2d_fwd"
+        y = torch.empty((n, ho, wo, co), dtype=x.dtype, device=x.device)
+        wsp, wsb = _ws(x)
+        _call(fn, x.data_ptr(), wm.data_ptr(), L.ptr(b), y.data_ptr(), n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad,
+              L.ACT[act], float(slope), wsp, wsb, _st(x))
+        ctx.geom = (n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad)
+        ctx.transposed, ctx.act, ctx.slope, ctx.has_bias = transposed, act, slope, b is not None
+        ctx.save_for_backward(x, w, y if L.ACT[act] else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        dy = _c(dy)
+        n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad = ctx.geom
+        st = _st(dy)
+        wsp, wsb = _ws(dy)
+        if L.ACT[ctx.act]:
+            dpre = torch.empty_like(dy)
+            _call("movae_act_bwd", dy.data_ptr(), y.data_ptr(), dpre.data_ptr(), dy.numel(), L.ACT[ctx.act], float(ctx.slope), st)
+            dy = dpre
+        pre = "movae_convT2d_" if ctx.transposed else "movae_conv2d_"
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            wm = weight_mem(w)
+            _call(pre + "dgrad", dy.data_ptr(), wm.data_ptr(), dx.data_ptr(), n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad,
+                  wsp, wsb, st)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            wm_shape = (ci, kh, kw, co) if ctx.transposed else (co, kh, kw, ci)
+            dwm = torch.empty(wm_shape, dtype=dy.dtype, device=dy.device)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = torch.empty(co, dtype=dy.dtype, device=dy.device)
+            _call(pre + "wgrad", dy.data_ptr(), x.data_ptr(), dwm.data_ptr(), L.ptr(db), n, hi, wi, ci, ho, wo, co, kh, kw,
+                  stride, pad, 0, wsp, wsb, st)
+            dw = dwm.permute(0, 3, 1, 2)
+        return dx, dw, db, None, None, None, None, None, None
+
+
+def conv2d(x, w, b=None, stride=1, pad=0, act=None, slope=0.01):
+    return Conv.apply(x, w, b, stride, pad, 0, False, act, slope)
+
+
+def conv_transpose2d(x, w, b=None, stride=1, pad=0, out_pad=0, act=None, slope=0.01):
+    return Conv.apply(x, w, b, stride, pad, out_pad, True, act, slope)
+
+
+def linear(x, w, b=None, act=None, slope=0.01):
+    """x [B, in], w [out, in] -> [B, out]  (a 1x1 convolution on a 1x1 image)."""
+    n, fin = x.shape
+    y = Conv.apply(x.reshape(n, 1, 1, fin), w.view(w.shape[0], fin, 1, 1), b, 1, 0, 0, False, act, slope)
+    return y.reshape(n, w.shape[0])
+
+
+# ---------------------------------------------------------------------------------------------
+class BatchNormAct(Function):
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, training, eps, momentum, act, slope):
+        L.require_gpu(y)
+        y = _c(y)
+        c = y.shape[-1]
+        rows = y.numel() // c
+        out = torch.empty_like(y)
+        mean = torch.empty(c, dtype=y.dtype, device=y.device)
+        rstd = torch.empty(c, dtype=y.dtype, device=y.device)
+        wsp, wsb = _ws(y)
+        _call("movae_bn_act_fwd", y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), mean.data_ptr(),
+              rstd.data_ptr(), L.ptr(running_mean), L.ptr(running_var), rows, c, float(eps), float(momentum),
+              1 if training else 0, L.ACT[act], float(slope), wsp, wsb, _st(y))
+        ctx.act, ctx.slope, ctx.training = act, slope, training
+        ctx.save_for_backward(y, gamma, beta, mean, rstd)
+        ctx.mark_non_differentiable(mean, rstd)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, gamma, beta, mean, rstd = ctx.saved_tensors
+        if not ctx.training:
+            raise RuntimeError("BatchNormAct backward is implemented for training-mode statistics only")
+        dout = _c(dout)
+        c = y.shape[-1]
+        rows = y.numel() // c
+        dy = torch.empty_like(y)
+        dg = torch.empty_like(gamma)
+        db = torch.empty_like(beta)
+        wsp, wsb = _ws(y)
+        _call("movae_bn_act_bwd", dout.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
+              rstd.data_ptr(), dy.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, c, L.ACT[ctx.act], float(ctx.slope), 0,
+              wsp, wsb, _st(y))
+        return dy, dg, db, None, None, None, None, None, None, None
+
+
+def batch_norm_act(y, gamma, beta, running_mean, running_var, training, eps=1e-5, momentum=0.1, act=None, slope=0.01):
+    return BatchNormAct.apply(y, gamma, beta, running_mean, running_var, training, eps, momentum, act, slope)
+
+
+# ---------------------------------------------------------------------------------------------
+class Activation(Function):
+    @staticmethod
+    def forward(ctx, x, act, slope):
+        L.require_gpu(x)
+        x = _c(x)
+        y = torch.empty_like(x)
+        _call("movae_act_fwd", x.data_ptr(), y.data_ptr(), x.numel(), L.ACT[act], float(slope), _st(x))
+        ctx.act, ctx.slope = act, slope
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        _call("movae_act_bwd", dy.data_ptr(), y.data_ptr(), dx.data_ptr(), dy.numel(), L.ACT[ctx.act], float(ctx.slope), _st(dy))
+        return dx, None, None
+
+
+def activation(x, act, slope=0.01):
+    if not L.ACT[act]:
+        return x
+    return Activation.apply(x, act, slope)
+
+
+class Add(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        L.require_gpu(a)
+        a, b = _c(a), _c(b)
+        y = torch.empty_like(a)
+        _call("movae_add", a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _st(a))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def add(a, b):
+    assert a.shape == b.shape
+    return Add.apply(a, b)
+
+
+class ConcatChannels(Function):
+    """torch.cat([a, b], dim=channel) for NHWC tensors (models/vq_vae2.py:228,241)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        L.require_gpu(a)
+        a, b = _c(a), _c(b)
+        ca, cb = a.shape[-1], b.shape[-1]
+        rows = a.numel() // ca
+        y = torch.empty(a.shape[:-1] + (ca + cb,), dtype=a.dtype, device=a.device)
+        st = _st(a)
+        _call("movae_copy_channels", a.data_ptr(), y.data_ptr(), rows, ca, ca + cb, 0, 0, ca, st)
+        _call("movae_copy_channels", b.data_ptr(), y.data_ptr(), rows, cb, ca + cb, 0, ca, cb, st)
+        ctx.ca, ctx.cb = ca, cb
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        ca, cb = ctx.ca, ctx.cb
+        rows = dy.numel() // (ca + cb)
+        da = torch.empty(dy.shape[:-1] + (ca,), dtype=dy.dtype, device=dy.device)
+        db = torch.empty(dy.shape[:-1] + (cb,), dtype=dy.dtype, device=dy.device)
+        st = _st(dy)
+        _call("movae_copy_channels", dy.data_ptr(), da.data_ptr(), rows, ca + cb, ca, 0, 0, ca, st)
+        _call("movae_copy_channels", dy.data_ptr(), db.data_ptr(), rows, ca + cb, cb, ca, 0, cb, st)
+        return da, db
+
+
+def concat_channels(a, b):
+    return ConcatChannels.apply(a, b)
+
+
+# ---------------------------------------------------------------------------------------------
+class Reparameterize(Function):
+    @staticmethod
+    def forward(ctx, mu, log_var, eps):
+        L.require_gpu(mu)
+        mu, log_var, eps = _c(mu), _c(log_var), _c(eps)
+        z = torch.empty_like(mu)
+        _call("movae_reparam_fwd", mu.data_ptr(), log_var.data_ptr(), eps.data_ptr(), z.data_ptr(), mu.numel(), _st(mu))
+        ctx.save_for_backward(log_var, eps)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        log_var, eps = ctx.saved_tensors
+        dz = _c(dz)
+        dmu, dlv = torch.empty_like(dz), torch.empty_like(dz)
+        _call("movae_reparam_bwd", dz.data_ptr(), log_var.data_ptr(), eps.data_ptr(), dmu.data_ptr(), dlv.data_ptr(), dz.numel(), _st(dz))
+        return dmu, dlv, None
+
+
+def reparameterize(mu, log_var, eps):
+    return Reparameterize.apply(mu, log_var, eps)
+
+
+# ---------------------------------------------------------------------------------------------
+class ReconLoss(Function):
+    """scale * mean(objective(recons, inputs)); both tensors must share one memory order."""
+
+    @staticmethod
+    def forward(ctx, recons, inputs, kind, scale):
+        L.require_gpu(recons)
+        recons, inputs = _c(recons), _c(inputs)
+        assert recons.shape == inputs.shape, (recons.shape, inputs.shape)
+        out = torch.empty((), dtype=recons.dtype, device=recons.device)
+        wsp, wsb = _ws(recons)
+        _call("movae_recon_loss_fwd", recons.data_ptr(), inputs.data_ptr(), out.data_ptr(), recons.numel(), L.RECON[kind],
+              float(scale), wsp, wsb, _st(recons))
+        ctx.kind, ctx.scale = kind, scale
+        ctx.save_for_backward(recons, inputs)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        recons, inputs = ctx.saved_tensors
+        g = _c(g)
+        dr = torch.empty_like(recons)
+        _call("movae_recon_loss_bwd", recons.data_ptr(), inputs.data_ptr(), g.data_ptr(), dr.data_ptr(), recons.numel(),
+              L.RECON[ctx.kind], float(ctx.scale), _st(recons))
+        return dr, None, None, None
+
+
+def recon_loss(recons, inputs, kind, scale=1.0):
+    return ReconLoss.apply(recons, inputs, kind, scale)
+
+
+class KLDivergence(Function):
+    @staticmethod
+    def forward(ctx, mu, log_var, scale):
+        L.require_gpu(mu)
+        mu, log_var = _c(mu), _c(log_var)
+        b, d = mu.shape
+        out = torch.empty((), dtype=mu.dtype, device=mu.device)
+        wsp, wsb = _ws(mu)
+        _call("movae_kl_fwd", mu.data_ptr(), log_var.data_ptr(), out.data_ptr(), b, d, float(scale), wsp, wsb, _st(mu))
+        ctx.scale = scale
+        ctx.save_for_backward(mu, log_var)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        mu, log_var = ctx.saved_tensors
+        g = _c(g)
+        b, d = mu.shape
+        dmu, dlv = torch.empty_like(mu), torch.empty_like(mu)
+        _call("movae_kl_bwd", mu.data_ptr(), log_var.data_ptr(), g.data_ptr(), dmu.data_ptr(), dlv.data_ptr(), b, d,
+              float(ctx.scale), _st(mu))
+        return dmu, dlv, None
+
+
+def kl_divergence(mu, log_var, scale=1.0):
+    return KLDivergence.apply(mu, log_var, scale)
+
+
+class TCDecomposition(Function):
+    """-> tensor [3] = (mi, tc, kld) of models/betatc_vae.py:294-296 (unweighted)."""
+
+    @staticmethod
+    def forward(ctx, z, mu, log_var, log_iw):
+        L.require_gpu(z)
+        z, mu, log_var, log_iw = _c(z), _c(mu), _c(log_var), _c(log_iw)
+        b, d = z.shape
+        out = torch.empty(3, dtype=z.dtype, device=z.device)
+        lj = torch.empty(b + b * b, dtype=z.dtype, device=z.device)
+        lm = torch.empty(b, d, dtype=z.dtype, device=z.device)
+        wsp, wsb = _ws(z)
+        _call("movae_tc_decomp_fwd", z.data_ptr(), mu.data_ptr(), log_var.data_ptr(), log_iw.data_ptr(), out.data_ptr(),
+              lj.data_ptr(), lm.data_ptr(), b, d, wsp, wsb, _st(z))
+        ctx.save_for_backward(z, mu, log_var, log_iw, lj, lm)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        z, mu, log_var, log_iw, lj, lm = ctx.saved_tensors
+        g = _c(g)
+        b, d = z.shape
+        dz, dmu, dlv = torch.empty_like(z), torch.empty_like(z), torch.empty_like(z)
+        _call("movae_tc_decomp_bwd", z.data_ptr(), mu.data_ptr(), log_var.data_ptr(), log_iw.data_ptr(), lj.data_ptr(),
+              lm.data_ptr(), g.data_ptr(), dz.data_ptr(), dmu.data_ptr(), dlv.data_ptr(), b, d, _st(z))
+        return dz, dmu, dlv, None
+
+
+def tc_decomposition(z, mu, log_var, log_iw):
+    return TCDecomposition.apply(z, mu, log_var, log_iw)
+
+
+# ---------------------------------------------------------------------------------------------
+class VectorQuantize(Function):
+    """x [.., D] latents (NHWC), codebook [K, D] -> (q_st, commitment, embedding, idx, used_count).
+
+    q_st carries the straight-through gradient to x; commitment = mse(q.detach(), x),
+    embedding = mse(q, x.detach()) (models/vq_vae.py:51-55)."""
+
+    @staticmethod
+    def forward(ctx, x, codebook):
+        L.require_gpu(x)
+        x, e = _c(x), _c(codebook)
+        k, d = e.shape
+        rows = x.numel() // d
+        q = torch.empty_like(x)
+        idx = torch.empty(rows, dtype=torch.int64, device=x.device)
+        sse = torch.empty((), dtype=x.dtype, device=x.device)
+        used = torch.empty((), dtype=torch.int32, device=x.device)
+        wsp, wsb = _ws(x)
+        _call("movae_vq_nearest_fwd", x.data_ptr(), e.data_ptr(), q.data_ptr(), idx.data_ptr(), sse.data_ptr(), used.data_ptr(),
+              rows, k, d, wsp, wsb, _st(x))
+        mse = sse / float(x.numel())
+        commitment, embedding = mse, mse.clone()
+        ctx.save_for_backward(x, q, idx)
+        ctx.kd = (k, d)
+        ctx.mark_non_differentiable(idx, used)
+        return q, commitment, embedding, idx, used
+
+    @staticmethod
+    def backward(ctx, dq, gc, ge, _gi, _gu):
+        x, q, idx = ctx.saved_tensors
+        k, d = ctx.kd
+        rows = x.numel() // d
+        dq = _c(dq) if dq is not None else None
+        need_x, need_e = ctx.needs_input_grad
+        dx = torch.empty_like(x) if need_x else None
+        de = torch.empty((k, d), dtype=x.dtype, device=x.device) if (need_e and ge is not None) else None
+        _call("movae_vq_bwd", x.data_ptr(), q.data_ptr(), idx.data_ptr(), L.ptr(dq), L.ptr(_c(gc) if gc is not None else None),
+              L.ptr(_c(ge) if ge is not None else None), L.ptr(dx), L.ptr(de), rows, k, d, _st(x))
+        if need_e and de is None:
+            de = torch.zeros((k, d), dtype=x.dtype, device=x.device)
+        return dx, de
+
+
+def vector_quantize(x, codebook):
+    return VectorQuantize.apply(x, codebook)

@@ -1,0 +1,134 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/movae.h declares,
+host logic (factories, validation, init replay) behaves like the reference, and the product path
+refuses to run without a GPU instead of falling back."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, cfg_from_meta, load_golden, meta_of
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import movae_amd
+
+    return movae_amd
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    hdr = open(os.path.join(ROOT, "include", "movae.h")).read()
+    names = set(re.findall(r"\b(movae_[a-z0-9_]+)\s*\(", hdr, flags=re.I))
+    names -= {"movae_stream_t"}
+    assert len(names) >= 40
+    lib = pkg.load_library()
+    raw = ctypes.CDLL(os.path.join(ROOT, "mo-vae_amd", "libmovae_hip.so"))
+    for n in sorted(names):
+        assert hasattr(raw, n), f"{n} declared in movae.h but not exported"
+    from movae_amd import _lib
+
+    assert set(_lib.SIGNATURES) == names, set(_lib.SIGNATURES) ^ names
+    assert lib.movae_version() >= 100
+    assert lib.movae_bn_ws_bytes(1024, 64) > 0 and lib.movae_gram_ws_bytes(4, 1 << 20) > 0
+
+
+def test_no_cpu_fallback(pkg):
+    from movae_amd import aggregation, ops
+
+    with pytest.raises(RuntimeError, match="no CPU"):
+        ops.conv2d(torch.zeros(1, 4, 4, 3), torch.zeros(8, 3, 3, 3))
+    with pytest.raises(RuntimeError, match="no CPU"):
+        aggregation.UPGrad()(torch.zeros(2, 8))
+    # nothing under the package imports the oracle
+    for dp, _, fs in os.walk(os.path.join(ROOT, "mo-vae_amd")):
+        for f in fs:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+
+
+class Args:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+@pytest.mark.parametrize("tag", ["vae_tiny", "vae_tiny_bce", "vae_1x1", "vq_vae_tiny", "vq_vae2_tiny", "betatc_vae_tiny"])
+def test_constructors_replay_reference_init_and_state_dict_layout(pkg, tag):
+    from movae_amd.models import get_network
+
+    fx = load_golden(tag)
+    m = meta_of(fx)
+    c = cfg_from_meta(m)
+    args = Args(arch=c["arch"], batch_size=c["batch_size"], dataset_size=c["dataset_size"], recons_objective=c["recons_objective"],
+                recons_activation=None, loss_weights=None,
+                **{k: v for k, v in c.items() if k in ("latent_dim", "hidden_dims", "embedding_dim", "num_embeddings",
+                                                        "num_residual_layers", "anneal_steps")})
+    torch.manual_seed(int(m["seed"]))
+    net = get_network(c["input_size"], 3, args, None)
+    sd = net.state_dict()
+    keys = [k[4:] for k in fx.files if k.startswith("sd0.")]
+    assert list(sd.keys()) == keys
+    for k in keys:
+        assert tuple(sd[k].shape) == fx["sd0." + k].shape, k
+        assert np.array_equal(sd[k].numpy(), fx["sd0." + k]), k
+    assert list(net.features) == [str(s) for s in fx["features"]]
+    assert list(net.objectives.keys()) == [str(s) for s in fx["objectives"]]
+    want_lw = dict(str(s).split("=") for s in fx["lambda_weights"])
+    assert {k: float(v) for k, v in want_lw.items()} == {k: float(v) for k, v in net.lambda_weights.items()}
+    # reference checkpoints (contiguous tensors) load into the channels_last parameters
+    net.load_state_dict({k: torch.from_numpy(fx["sd0." + k]) for k in keys})
+
+
+def test_factory_errors_and_quirks(pkg):
+    from movae_amd.models import VAE, VQVAE2, BetaTCVAE, get_network
+
+    with pytest.raises(ValueError):
+        get_network(32, 3, Args(arch="nope", batch_size=1, dataset_size=1), None)
+    with pytest.raises(NotImplementedError):
+        get_network(32, 3, Args(arch="gg_vae", batch_size=1, dataset_size=1), None)
+    with pytest.raises(ValueError):
+        VAE(latent_dim=4, hidden_dims=[4], input_size=8, lambda_weights=[1.0])
+    with pytest.raises(ValueError):
+        VAE(latent_dim=4, hidden_dims=[4], input_size=8, lambda_weights={"reconstruction_loss": 1.0})
+    with pytest.raises(TypeError):
+        VAE(latent_dim=4, hidden_dims=[4], input_size=8, lambda_weights=3.0)
+    with pytest.raises(ValueError):
+        VAE(latent_dim=4, hidden_dims=[4], input_size=8, recons_objective="foo")
+    with pytest.raises(ValueError):
+        VQVAE2(3, 8, 16, hidden_dims=[16, 32], lambda_weights=[1.0, 2.0])
+    with pytest.raises(ValueError):
+        BetaTCVAE(3, 4, hidden_dims=[4], input_size=8, lambda_weights=[1.0])
+    # bce forces sigmoid whatever activation was asked (utils/objectives.py:26-27)
+    v = VAE(latent_dim=4, hidden_dims=[4], input_size=8, recons_objective="bce", recons_activation="tanh")
+    assert type(v.final_layer[4]).__name__ == "Sigmoid"
+    # kld weight is forced to batch_size / dataset_size by the factory (models/__init__.py:49-55)
+    n = get_network(8, 3, Args(arch="vae", batch_size=10, dataset_size=100, latent_dim=4, hidden_dims=[4],
+                               loss_weights={"reconstruction_loss": 2.0, "kld_loss": 9.0}), None)
+    assert n.lambda_weights == {"reconstruction_loss": 2.0, "kld_loss": 0.1}
+
+
+def test_aggregator_factory_names(pkg):
+    from movae_amd import aggregation as A
+
+    def mk(name):
+        return A.make_aggregator(Args(aggregator=name, agg_norm_eps=1e-4, agg_reg_eps=1e-4, mgda_epsilon=1e-5,
+                                      mgda_max_iters=250, pref_weights=None))
+
+    assert mk(None) is None and mk("sum") == "sum"
+    assert isinstance(mk("upgrad"), A.UPGrad) and isinstance(mk("jd_sum"), A.Sum) and isinstance(mk("mean"), A.Mean)
+    for n, nt in [("mgda", "none"), ("mgda_ln", "l2"), ("mgda_gn", "loss"), ("mgda_lgn", "loss+")]:
+        assert mk(n).mgda_weighting.norm_type == nt
+    for n, sm in [("aligned_mtl", "min"), ("amtl", "min"), ("aligned_mtl_median", "median"), ("aligned_mtl_rmse", "rmse")]:
+        assert mk(n)._scale_mode == sm
+    with pytest.raises(NotImplementedError):
+        mk("pcgrad")
+    with pytest.raises(ValueError):
+        mk("bogus")
+    with pytest.raises(ValueError):
+        A.MGDA(norm_type="l3")
+    a = Args(aggregator=None)
+    A.make_aggregator(a)
+    assert a.aggregator == "sum"  # main.py:1245-1246

@@ -1,0 +1,414 @@
+"""Parity of every HIP kernel family (through the C ABI via mo-vae_amd/ops.py) against plain
+PyTorch fp32 on the CPU and against the oracle / golden vectors.  GPU only."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+FP32_TOL = dict(rtol=2e-4, atol=2e-5)  # fp32 tolerance for O(1) activations with K <= ~5k reductions
+
+
+@pytest.fixture(scope="module")
+def M(gpu_device):
+    import movae_amd  # noqa: F401
+    from movae_amd import aggregation, ops
+
+    movae_amd.load_library()
+    return ops, aggregation
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def nhwc(x):  # NCHW cpu -> NHWC cuda leaf
+    return x.permute(0, 2, 3, 1).contiguous().cuda().requires_grad_(True)
+
+
+def cl(w):  # weight cpu -> channels_last cuda leaf
+    return w.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+
+
+def back(t):  # NHWC cuda -> NCHW cpu
+    return t.detach().cpu().permute(0, 3, 1, 2)
+
+
+def close(a, b, what="", rtol=None, atol=None):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    scale = max(1.0, float(b.abs().max()))
+    np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=rtol or FP32_TOL["rtol"], atol=(atol or FP32_TOL["atol"]) * scale,
+                               err_msg=what)
+
+
+CONV_CASES = [
+    # n, ci, h, w, co, k, s, p
+    (2, 3, 16, 16, 8, 3, 2, 1),      # generic gather path (ci = 3)
+    (3, 16, 9, 7, 24, 3, 2, 1),      # vector path, odd sizes, N not multiple of tile
+    (2, 32, 8, 8, 64, 3, 1, 1),      # stride 1
+    (2, 3, 16, 16, 16, 4, 2, 1),     # k4 s2 (VQ / BetaTC encoders)
+    (4, 16, 4, 4, 3, 3, 1, 1),       # narrow output (final conv, co = 3)
+    (2, 48, 6, 6, 32, 1, 1, 0),      # 1x1
+    (5, 64, 2, 2, 128, 3, 2, 1),     # 2x2 -> 1x1 (CIFAR VAE tail), split-K path
+    (2, 20, 5, 5, 12, 3, 2, 1),      # ci not multiple of 16 nor 4
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("act", [None, "lrelu"])
+def test_conv2d_fwd_bwd(M, case, act):
+    ops, _ = M
+    n, ci, h, w, co, k, s, p = case
+    x, wt, b = rnd(n, ci, h, w, seed=1), rnd(co, ci, k, k, seed=2, scale=0.2), rnd(co, seed=3)
+    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, stride=s, padding=p)
+    if act:
+        yr = F.leaky_relu(yr, 0.01)
+    gy = rnd(*yr.shape, seed=4)
+    yr.backward(gy)
+    xg, wg, bg = nhwc(x), cl(wt), b.cuda().requires_grad_(True)
+    y = ops.conv2d(xg, wg, bg, s, p, act, 0.01)
+    y.backward(gy.permute(0, 2, 3, 1).contiguous().cuda())
+    close(back(y), yr, "y")
+    close(back(xg.grad), xr.grad, "dx")
+    close(wg.grad, wr.grad, "dw")
+    close(bg.grad, br.grad, "db")
+
+
+CONVT_CASES = [
+    # n, ci, h, w, co, k, s, p, op
+    (2, 16, 4, 4, 8, 3, 2, 1, 1),
+    (3, 32, 1, 1, 16, 3, 2, 1, 1),    # 1x1 -> 2x2 (CIFAR VAE decoder head)
+    (2, 8, 5, 6, 12, 3, 2, 1, 1),     # generic path
+    (2, 16, 8, 8, 3, 4, 2, 1, 0),     # k4 s2 p1 (VQ decoders), co = 3
+    (2, 32, 4, 4, 32, 4, 2, 1, 0),
+]
+
+
+@pytest.mark.parametrize("case", CONVT_CASES)
+@pytest.mark.parametrize("act", [None, "tanh"])
+def test_conv_transpose2d_fwd_bwd(M, case, act):
+    ops, _ = M
+    n, ci, h, w, co, k, s, p, op = case
+    x, wt, b = rnd(n, ci, h, w, seed=5), rnd(ci, co, k, k, seed=6, scale=0.2), rnd(co, seed=7)
+    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv_transpose2d(xr, wr, br, stride=s, padding=p, output_padding=op)
+    if act:
+        yr = torch.tanh(yr)
+    gy = rnd(*yr.shape, seed=8)
+    yr.backward(gy)
+    xg, wg, bg = nhwc(x), cl(wt), b.cuda().requires_grad_(True)
+    y = ops.conv_transpose2d(xg, wg, bg, s, p, op, act, 0.01)
+    y.backward(gy.permute(0, 2, 3, 1).contiguous().cuda())
+    close(back(y), yr, "y")
+    close(back(xg.grad), xr.grad, "dx")
+    close(wg.grad, wr.grad, "dw")
+    close(bg.grad, br.grad, "db")
+
+
+@pytest.mark.parametrize("shape", [(7, 33, 19), (256, 512, 128), (4, 2048, 8), (32, 4096, 256)])
+def test_linear_fwd_bwd(M, shape):
+    ops, _ = M
+    n, fin, fout = shape
+    x, wt, b = rnd(n, fin, seed=1), rnd(fout, fin, seed=2, scale=0.05), rnd(fout, seed=3)
+    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.linear(xr, wr, br)
+    gy = rnd(n, fout, seed=4)
+    yr.backward(gy)
+    xg, wg, bg = x.cuda().requires_grad_(True), wt.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    y = ops.linear(xg, wg, bg)
+    y.backward(gy.cuda())
+    close(y, yr, "y")
+    close(xg.grad, xr.grad, "dx")
+    close(wg.grad, wr.grad, "dw")
+    close(bg.grad, br.grad, "db")
+
+
+@pytest.mark.parametrize("shape", [(4, 8, 5, 5), (6, 32, 8, 8), (3, 20, 3, 3), (64, 512, 1, 1), (2, 3, 4, 4)])
+def test_batchnorm_act_train(M, shape):
+    ops, _ = M
+    n, c, h, w = shape
+    x = rnd(n, c, h, w, seed=11) * 2 + 0.5
+    g, b = rnd(c, seed=12).abs() + 0.5, rnd(c, seed=13)
+    bn = torch.nn.BatchNorm2d(c)
+    with torch.no_grad():
+        bn.weight.copy_(g)
+        bn.bias.copy_(b)
+    xr = x.clone().requires_grad_(True)
+    yr = F.leaky_relu(bn(xr), 0.01)
+    gy = rnd(*yr.shape, seed=14)
+    yr.backward(gy)
+    xg = nhwc(x)
+    gg, bg = g.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    rm, rv = torch.zeros(c).cuda(), torch.ones(c).cuda()
+    y = ops.batch_norm_act(xg, gg, bg, rm, rv, True, 1e-5, 0.1, "lrelu", 0.01)
+    y.backward(gy.permute(0, 2, 3, 1).contiguous().cuda())
+    close(back(y), yr, "y")
+    close(back(xg.grad), xr.grad, "dx", rtol=1e-3)
+    close(gg.grad, bn.weight.grad, "dgamma", rtol=1e-3)
+    close(bg.grad, bn.bias.grad, "dbeta", rtol=1e-3)
+    close(rm, bn.running_mean, "running_mean")
+    close(rv, bn.running_var, "running_var")
+    # eval mode uses the running statistics
+    bn.eval()
+    ye = ops.batch_norm_act(xg.detach(), gg.detach(), bg.detach(), rm, rv, False, 1e-5, 0.1, None, 0.01)
+    close(back(ye), bn(x), "eval")
+
+
+def test_layout_roundtrip_and_flatten(M):
+    ops, _ = M
+    x = rnd(3, 5, 4, 6, seed=21)
+    xg = x.cuda()
+    y = ops.NchwToNhwc.apply(xg)
+    assert torch.equal(y.cpu(), x.permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(ops.NhwcToNchw.apply(y).cpu(), x)
+    assert torch.equal(ops.flatten_nchw(y).cpu(), x.flatten(1))
+    assert torch.equal(ops.unflatten_nchw(x.flatten(1).cuda(), 5, 4, 6).cpu(), x.permute(0, 2, 3, 1).contiguous())
+
+
+def test_elementwise(M):
+    ops, _ = M
+    a, b = rnd(2, 4, 4, 7, seed=1), rnd(2, 4, 4, 7, seed=2)
+    assert torch.equal(ops.add(a.cuda(), b.cuda()).cpu(), a + b)
+    c = ops.concat_channels(a.cuda().requires_grad_(True), rnd(2, 4, 4, 3, seed=3).cuda())
+    assert torch.equal(c.cpu()[..., :7], a) and c.shape[-1] == 10
+    for kind, ref in [("relu", torch.relu), ("tanh", torch.tanh), ("sigmoid", torch.sigmoid),
+                      ("lrelu", lambda t: F.leaky_relu(t, 0.01))]:
+        xr = a.clone().requires_grad_(True)
+        ref(xr).backward(b)
+        xg = a.cuda().requires_grad_(True)
+        y = ops.activation(xg, kind, 0.01)
+        y.backward(b.cuda())
+        close(y, ref(a), kind)
+        close(xg.grad, xr.grad, kind + " grad")
+    mu, lv, eps = rnd(5, 9, seed=4), rnd(5, 9, seed=5) * 0.5, rnd(5, 9, seed=6)
+    mr, lr = mu.clone().requires_grad_(True), lv.clone().requires_grad_(True)
+    zr = mr + eps * torch.exp(0.5 * lr)
+    zr.backward(a.reshape(-1)[:45].reshape(5, 9))
+    mg, lg = mu.cuda().requires_grad_(True), lv.cuda().requires_grad_(True)
+    z = ops.reparameterize(mg, lg, eps.cuda())
+    z.backward(a.reshape(-1)[:45].reshape(5, 9).cuda())
+    close(z, zr, "z")
+    close(mg.grad, mr.grad, "dmu")
+    close(lg.grad, lr.grad, "dlv")
+
+
+@pytest.mark.parametrize("name,rkey", [("mse", "r_tanh"), ("l1", "r_tanh"), ("smooth_l1", "r_sl1"), ("bce", "r_sig")])
+def test_recon_losses_match_reference_fixture(M, name, rkey):
+    """golden values come from the reference's utils/objectives.py (incl. the saturated BCE points)."""
+    ops, _ = M
+    fx = load_golden("objectives")
+    x = torch.from_numpy(fx["x"]).cuda()
+    r = torch.from_numpy(fx[rkey]).cuda().requires_grad_(True)
+    v = ops.recon_loss(r, x, name, 1.0)
+    v.backward()
+    np.testing.assert_allclose(v.item(), fx[f"{name}.value"], rtol=2e-6)
+    np.testing.assert_allclose(r.grad.cpu().numpy(), fx[f"{name}.grad"], rtol=1e-5, atol=1e-9)
+    # lambda scaling and upstream gradient scaling
+    r2 = torch.from_numpy(fx[rkey]).cuda().requires_grad_(True)
+    (3.0 * ops.recon_loss(r2, x, name, 0.5)).backward()
+    np.testing.assert_allclose(r2.grad.cpu().numpy(), 1.5 * fx[f"{name}.grad"], rtol=1e-5, atol=1e-9)
+
+
+def test_kl_matches_reference_fixture(M):
+    ops, _ = M
+    fx = load_golden("objectives")
+    mu = torch.from_numpy(fx["kl.mu"]).cuda().requires_grad_(True)
+    lv = torch.from_numpy(fx["kl.log_var"]).cuda().requires_grad_(True)
+    v = ops.kl_divergence(mu, lv, 1.0)
+    v.backward()
+    np.testing.assert_allclose(v.item(), fx["kl.value"], rtol=1e-6)
+    np.testing.assert_allclose(mu.grad.cpu().numpy(), fx["kl.gmu"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(lv.grad.cpu().numpy(), fx["kl.glv"], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("B,D,ds", [(5, 6, 1000), (32, 128, 1281167), (17, 70, 50000), (64, 16, 30000)])
+def test_tc_decomposition_vs_oracle(M, B, D, ds):
+    ops, _ = M
+    from oracle import nets
+
+    z, mu, lv = rnd(B, D, seed=1), rnd(B, D, seed=2) * 0.5, rnd(B, D, seed=3) * 0.3
+    liw = nets.log_importance_weights(B, ds)
+    zr, mr, lr = [t.clone().requires_grad_(True) for t in (z, mu, lv)]
+    mat = nets._log_density_gaussian(zr.view(B, 1, D), mr.view(1, B, D), lr.view(1, B, D)) + liw.view(B, B, 1)
+    lqz = torch.logsumexp(mat.sum(2), dim=1)
+    lpq = torch.logsumexp(mat, dim=1).sum(1)
+    lqzx = nets._log_density_gaussian(zr, mr, lr).sum(1)
+    lpz = nets._log_density_gaussian(zr, torch.zeros_like(zr), torch.zeros_like(zr)).sum(1)
+    ref = torch.stack([(lqzx - lqz).mean(), (lqz - lpq).mean(), (lpq - lpz).mean()])
+    gw = torch.tensor([0.7, -1.3, 0.4])
+    (ref * gw).sum().backward()
+    zg, mg, lg = [t.cuda().requires_grad_(True) for t in (z, mu, lv)]
+    out = ops.tc_decomposition(zg, mg, lg, liw.cuda())
+    (out * gw.cuda()).sum().backward()
+    close(out, ref, "terms", rtol=2e-5, atol=2e-5)
+    close(zg.grad, zr.grad, "dz", rtol=2e-3, atol=2e-5)
+    close(mg.grad, mr.grad, "dmu", rtol=2e-3, atol=2e-5)
+    close(lg.grad, lr.grad, "dlv", rtol=2e-3, atol=2e-5)
+
+
+@pytest.mark.parametrize("rows,K,D", [(48, 16, 8), (300, 512, 64), (1000, 100, 32), (77, 40, 10), (4096, 512, 64)])
+def test_vector_quantize_vs_oracle(M, rows, K, D):
+    ops, _ = M
+    from oracle import nets
+
+    x = rnd(rows, D, seed=1).reshape(1, rows, 1, D)  # NHWC with H = rows
+    E = (torch.rand(K, D, generator=torch.Generator().manual_seed(2)) * 2 - 1) * 1.5
+    xr, Er = x.permute(0, 3, 1, 2).contiguous().requires_grad_(True), E.clone().requires_grad_(True)
+    qr, cr, er, ir = nets.vector_quantize(xr, Er)
+    gq = rnd(*qr.shape, seed=3)
+    (qr * gq).sum().backward(retain_graph=True)
+    (0.25 * cr + 2.0 * er).backward()
+    xg, Eg = x.cuda().requires_grad_(True), E.cuda().requires_grad_(True)
+    q, c, e, idx, used = ops.vector_quantize(xg, Eg)
+    ((q * gq.permute(0, 2, 3, 1).cuda()).sum() + 0.25 * c + 2.0 * e).backward()
+    agree = (idx.cpu() == ir).float().mean().item()
+    assert agree >= 0.999, f"index agreement {agree}"
+    assert int(used.item()) == torch.unique(ir).numel() or agree < 1.0
+    close(c, cr, "commitment", rtol=1e-4)
+    close(e, er, "embedding", rtol=1e-4)
+    if agree == 1.0:
+        close(q.permute(0, 3, 1, 2), qr, "q")
+        close(xg.grad.permute(0, 3, 1, 2), xr.grad, "dx", rtol=1e-3)
+        close(Eg.grad, Er.grad, "dE", rtol=1e-3, atol=1e-5)
+
+
+def test_vq_first_index_on_ties(M):
+    ops, _ = M
+    E = torch.zeros(40, 8)
+    E[3] = 1.0
+    E[17] = 1.0  # duplicate code: argmin must return the first
+    x = torch.ones(1, 5, 1, 8)
+    _, _, _, idx, used = ops.vector_quantize(x.cuda(), E.cuda())
+    assert idx.cpu().tolist() == [3] * 5 and int(used.item()) == 1
+
+
+# ---------------------------------------------------------------- aggregation
+CASES = ["kat", "k2", "k3", "k3_zero_row", "k4", "k4_conflict", "k5_rankdef", "k2_parallel"]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_gramian_and_combine(M, case):
+    _, agg = M
+    fx = load_golden("weightings")
+    J = torch.from_numpy(fx[f"{case}.J"])
+    G = agg.compute_gramian(J.cuda())
+    close(G, torch.from_numpy(fx[f"{case}.G"]), "G", rtol=1e-5)
+    w = torch.linspace(0.3, 1.7, J.shape[0])
+    close(agg.combine(J.cuda(), w.cuda()), w @ J, "combine", rtol=1e-5)
+
+
+def test_gramian_large_unaligned(M):
+    _, agg = M
+    J = rnd(3, 1_000_003, seed=9)
+    buf = torch.zeros(3, 1_000_004).cuda()
+    buf[:, :1_000_003] = J.cuda()
+    G = agg.compute_gramian(buf[:, :1_000_003])
+    close(G, (J.double() @ J.double().T).float(), "G", rtol=2e-6)
+    w = torch.tensor([0.5, -1.0, 2.0])
+    close(agg.combine(buf[:, :1_000_003], w.cuda()), w @ J, "g", rtol=1e-5)
+    sim = agg.gd_similarity(buf[:, :1_000_003], w.cuda())
+    ref = F.cosine_similarity(J.T @ w, J.mean(0), dim=0)
+    np.testing.assert_allclose(sim.item(), ref.item(), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("nt", ["none", "l2", "loss", "loss+"])
+def test_mgda_weights_match_reference_code(M, case, nt):
+    _, agg = M
+    fx = load_golden("weightings")
+    W = agg.MGDAWeighting(norm_type=nt)
+    W.set_losses(torch.from_numpy(fx[f"{case}.losses"]).cuda())
+    w = W(torch.from_numpy(fx[f"{case}.G"]).cuda())
+    np.testing.assert_allclose(w.cpu().numpy(), fx[f"{case}.mgda.{nt}"], rtol=2e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("sm", ["min", "median", "rmse"])
+def test_aligned_mtl_weights_match_reference_code(M, case, sm):
+    _, agg = M
+    fx = load_golden("weightings")
+    w = agg.AlignedMTLWeighting(None, scale_mode=sm)(torch.from_numpy(fx[f"{case}.G"]).cuda())
+    want = fx[f"{case}.amtl.{sm}"]
+    np.testing.assert_allclose(w.cpu().numpy(), want, rtol=5e-3, atol=1e-5 * np.abs(want).max())
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_upgrad_weights_vs_oracle(M, case):
+    _, agg = M
+    from oracle import aggregation as OA
+
+    fx = load_golden("weightings")
+    G = fx[f"{case}.G"]
+    w = agg.UPGradWeighting()(torch.from_numpy(G).cuda())
+    np.testing.assert_allclose(w.cpu().numpy(), OA.upgrad_weights(G), rtol=1e-5, atol=1e-7)
+
+
+def test_aggregator_docstring_kats(M):
+    """utils/torchmoo/mgda.py:54-86 and nupgrad.py:58-62."""
+    _, agg = M
+    J = torch.tensor([[-4.0, 1.0, 1.0], [6.0, 1.0, 1.0]]).cuda()
+    np.testing.assert_allclose(agg.UPGrad()(J).cpu().numpy(), [0.2929, 1.9004, 1.9004], atol=5e-5)
+    np.testing.assert_allclose(agg.MGDA()(J).cpu().numpy(), [0.0, 1.0, 1.0], atol=1e-5)
+    np.testing.assert_allclose(agg.MGDA(norm_type="l2")(J).cpu().numpy(), [1.0, 1.0, 1.0], atol=1e-5)
+    A = agg.MGDA(norm_type="loss")
+    A.set_losses(torch.tensor([0.5, 2.0]).cuda())
+    np.testing.assert_allclose(A(J).cpu().numpy(), [3.49, 1.0, 1.0], atol=5e-4)
+    A = agg.MGDA(norm_type="loss+")
+    A.set_losses(torch.tensor([0.5, 2.0]).cuda())
+    np.testing.assert_allclose(A(J).cpu().numpy(), [4.1606, 1.0, 1.0], atol=5e-4)
+    np.testing.assert_allclose(agg.Sum()(J).cpu().numpy(), [2.0, 2.0, 2.0], atol=1e-6)
+    np.testing.assert_allclose(agg.Mean()(J).cpu().numpy(), [1.0, 1.0, 1.0], atol=1e-6)
+    with pytest.raises(RuntimeError):
+        agg.MGDA(norm_type="loss")(J)  # losses not set
+
+
+def test_weighting_forward_hook_sees_jacobian_and_weights(M):
+    """main.py:1248-1250 registers hooks on aggregator.weighting: inputs[0] is J, output is w."""
+    _, agg = M
+    J = torch.tensor([[-4.0, 1.0, 1.0], [6.0, 1.0, 1.0]]).cuda()
+    seen = {}
+    A = agg.UPGrad()
+    A.weighting.register_forward_hook(lambda m, inp, out: seen.update(J=inp[0], w=out))
+    A(J)
+    assert seen["J"].shape == (2, 3) and seen["w"].shape == (2,)
+
+
+def test_adam_and_clip(M):
+    import movae_amd._lib as L
+
+    n = 10007
+    p, g = rnd(n, seed=1), rnd(n, seed=2)
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-3)
+    pg, m, v = p.cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    lib = L.load()
+    for step in range(1, 4):
+        gi = g * step
+        pr.grad = gi.clone()
+        opt.step()
+        L.check(lib.movae_adam_step(pg.data_ptr(), gi.cuda().data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-3, 0.9, 0.999,
+                                    1e-8, 0.0, 0, step, L.stream_ptr(pg.device)))
+    close(pg, pr, "adam", rtol=1e-5, atol=1e-6)
+    gg = g.cuda().clone()
+    ss = torch.empty((), device="cuda")
+    ws = L.workspace(gg.device)
+    L.check(lib.movae_sumsq(gg.data_ptr(), n, ss.data_ptr(), ws.data_ptr(), ws.numel(), L.stream_ptr(gg.device)))
+    np.testing.assert_allclose(ss.item(), (g.double() ** 2).sum().item(), rtol=1e-6)
+    L.check(lib.movae_scale_by_clip(gg.data_ptr(), n, ss.data_ptr(), 1.0, L.stream_ptr(gg.device)))
+    gr = g.clone().requires_grad_(True)
+    gr.grad = g.clone()
+    torch.nn.utils.clip_grad_norm_([gr], 1.0)
+    close(gg, gr.grad, "clip", rtol=1e-5)
+
+
+def test_invalid_arguments_raise(M):
+    ops, agg = M
+    with pytest.raises(RuntimeError):
+        ops.conv2d(torch.zeros(1, 4, 4, 3), torch.zeros(8, 3, 3, 3))  # CPU tensors: no CPU path
+    with pytest.raises(ValueError):
+        agg.compute_gramian(torch.zeros(9, 10).cuda())  # K > MOVAE_MAX_K
