@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""Benchmark of the MO-VAE training hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--config C2]
+
+One "step" = one pass of the hot path over one synthetic batch resident in HBM: forward, loss
+terms, K per-loss backward passes + Jacobian, device-side Gram / weight solve / combine (or plain
+backward for `sum`), [all-reduce of the aggregated gradient when N > 1], optimizer step.
+Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for how `roofline` is obtained.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+CONFIGS = {
+    # BASELINE.json:configs -- shapes per SURVEY.md section 8 (C1..C5); batch is per GPU (weak scaling)
+    "C1": dict(arch="vae", agg="sum", batch=128, size=32, dataset_size=50000, latent_dim=128, hidden_dims=[32, 64, 128, 256, 512],
+               flops_per_img=78.6e6, label="CIFAR-10 32x32 --arch vae --agg sum bs=128"),
+    "C2": dict(arch="vae", agg="upgrad", batch=256, size=32, dataset_size=50000, latent_dim=128, hidden_dims=[32, 64, 128, 256, 512],
+               flops_per_img=98.9e6, label="CIFAR-10 32x32 --arch vae --agg upgrad bs=256"),
+    "C3": dict(arch="vq_vae", agg="aligned_mtl", batch=128, size=64, dataset_size=162770, embedding_dim=64, num_embeddings=512,
+               hidden_dims=[128, 256], num_residual_layers=2, flops_per_img=11.9e9,
+               label="CelebA 64x64 --arch vq_vae K=512 D=64 --agg aligned_mtl bs=128"),
+    "C4": dict(arch="vq_vae2", agg="mgda_ln", batch=8, size=256, dataset_size=30000, embedding_dim=64, num_embeddings=512,
+               hidden_dims=[128, 256], num_residual_layers=2, flops_per_img=37.2e9,
+               label="CelebA-HQ 256x256 --arch vq_vae2 --agg mgda_ln bs=8/GPU"),
+    "C5": dict(arch="betatc_vae", agg="upgrad", batch=32, size=256, dataset_size=1281167, latent_dim=128,
+               hidden_dims=[32, 64, 128, 256, 512], anneal_steps=200, flops_per_img=13.35e9,
+               label="ImageNet 256x256 --arch betatc_vae --agg upgrad bs=32/GPU"),
+}
+
+CONV_CALLS = {"movae_conv2d_fwd", "movae_conv2d_dgrad", "movae_conv2d_wgrad", "movae_convT2d_fwd", "movae_convT2d_dgrad",
+              "movae_convT2d_wgrad"}
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0
+
+
+class Args:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def conv_call_flops(name, a):
+    """Nominal algorithmic FLOPs of one conv-family C-ABI call (2 * MACs, padding taps counted the way
+    SURVEY 8d counts them): conv = out_pixels*k*k*ci*co, transposed conv = in_pixels*k*k*ci*co."""
+    off = 4 if name.endswith("_fwd") or name.endswith("_wgrad") else 3
+    n, hi, wi, ci, ho, wo, co, kh, kw = a[off: off + 9]
+    pix = hi * wi if "convT" in name else ho * wo
+    return 2.0 * n * pix * kh * kw * ci * co
+
+
+def conv_call_key(name, a):
+    off = 4 if name.endswith("_fwd") or name.endswith("_wgrad") else 3
+    return (name,) + tuple(a[off: off + 11])
+
+
+def build_workload(cfg, device, seed=0, capturable=False):
+    import movae_amd  # noqa: F401
+    from movae_amd import aggregation
+    from movae_amd.models import get_network
+    from movae_amd.train import make_optimizer
+
+    a = Args(arch=cfg["arch"], batch_size=cfg["batch"], dataset_size=cfg["dataset_size"], recons_objective="mse",
+             recons_activation=None, loss_weights=None, aggregator=cfg["agg"], agg_norm_eps=1e-4, agg_reg_eps=1e-4,
+             mgda_epsilon=1e-5, mgda_max_iters=250, pref_weights=None, optimizer="adam", lr=1e-3, wd=0, momentum=0.9,
+             max_grad_norm=None, **{k: cfg[k] for k in ("latent_dim", "hidden_dims", "embedding_dim", "num_embeddings",
+                                                        "num_residual_layers", "anneal_steps") if k in cfg})
+    torch.manual_seed(seed)
+    net = get_network(cfg["size"], 3, a, device).to(device).train()
+    opt = make_optimizer(net, a, capturable=capturable)
+    agg = aggregation.make_aggregator(a)
+    g = torch.Generator().manual_seed(seed + 1)
+    pool = [torch.rand(cfg["batch"], 3, cfg["size"], cfg["size"], generator=g).to(device) for _ in range(8)]
+    return net, opt, agg, a, pool
+
+
+def cpu_baseline(cfg, seconds):
+    """The CPU oracle ("port" of the reference step, oracle/step.py) timed on this box's host cores."""
+    from oracle import nets
+    from oracle.step import OracleTrainer
+
+    # a 1-GPU box's CPU share is 16 cores; PyTorch's default of one thread per visible core (128) oversubscribes
+    # these small convolutions and is ~10x slower than 16 threads
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    kw = {k: cfg[k] for k in ("latent_dim", "hidden_dims", "embedding_dim", "num_embeddings", "num_residual_layers", "anneal_steps")
+          if k in cfg}
+    ocfg = nets.make_cfg(cfg["arch"], cfg["size"], cfg["batch"], cfg["dataset_size"], **kw)
+    tr = OracleTrainer(ocfg, seed=0, agg=cfg["agg"])
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(cfg["batch"], 3, cfg["size"], cfg["size"], generator=g)
+    need_eps = nets.ARCHS[cfg["arch"]]["needs_eps"]
+    eps = torch.randn(cfg["batch"], cfg.get("latent_dim", 1), generator=g) if need_eps else None
+    tr.step(x, eps)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        tr.step(x, eps)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or n >= 2000:
+            break
+    return dict(value=cfg["batch"] * n / dt, unit="images/sec", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n} steps of {cfg['label']} (oracle/step.py, PyTorch-CPU fp32, {dt:.1f} s)")
+
+
+def measure_dominant_kernel(recorded, device, reps=20):
+    """HIP-event timing of the conv-family launches captured from one real step: every captured call is
+    re-issued `reps` times back to back on the launch stream (same arguments, same live buffers) between
+    two events.  Returns per-call rows and the family aggregate."""
+    import movae_amd._lib as L
+
+    lib = L.load()
+    rows = []
+    stream = torch.cuda.current_stream(device)
+    for name, a in recorded:
+        if name not in CONV_CALLS:
+            continue
+        fn = getattr(lib, name)
+        for _ in range(3):
+            fn(*a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            fn(*a)
+        e1.record(stream)
+        e1.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        rows.append(dict(call=name, shape=list(conv_call_key(name, a)[1:]), us=us, gflop=conv_call_flops(name, a) / 1e9))
+    return rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", type=str, default="C2", choices=sorted(CONFIGS))
+    ap.add_argument("--agg", type=str, default=None)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="replay the step as one captured hipGraph (auto: single-GPU VAE configs)")
+    ap.add_argument("--kernel-table", type=str, default=None, help="write the per-launch conv table (JSON) here")
+    args = ap.parse_args()
+
+    cfg = dict(CONFIGS[args.config])
+    if args.agg:
+        cfg["agg"] = args.agg
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        print(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}", file=sys.stderr)
+        sys.exit(2)
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    device = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(device)
+
+    import movae_amd  # noqa: F401
+    import movae_amd._lib as L
+    from movae_amd.parallel import DataParallelGrads
+    from movae_amd.train import train_step
+
+    from movae_amd.train import GRAPH_SAFE_ARCHS, GraphedTrainStep
+
+    dp = DataParallelGrads.from_env() if world > 1 else None
+    use_graph = args.graph == "on" or (args.graph == "auto" and world == 1 and cfg["arch"] == "vae")
+    net, opt, agg, a, pool = build_workload(cfg, device, capturable=use_graph)
+    if dp is not None:
+        dp.attach(net)
+    graphed = GraphedTrainStep(net, opt, agg, a, pool[0]) if use_graph else None
+
+    def step(i, eager=False):
+        if graphed is not None and not eager:
+            return graphed.step(pool[i % len(pool)])
+        return train_step(net, pool[i % len(pool)], opt, agg, a, dp)
+
+    for i in range(args.warmup):
+        step(i)
+    if dp is not None:
+        dp.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ld, _ = step(i)
+    torch.cuda.synchronize()
+    if dp is not None:
+        dp.barrier()
+    elapsed = time.perf_counter() - t0
+    if dp is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(ld["total_loss"].item())
+
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        recorded = []
+        L.TRACE = lambda name, cargs: recorded.append((name, cargs))
+        keep = step(0, eager=True)  # noqa: F841 -- keeps this step's buffers alive while its launches are replayed
+        L.TRACE = None
+        torch.cuda.synchronize()
+        rows = measure_dominant_kernel(recorded, device)
+        tot_us = sum(r["us"] for r in rows)
+        tot_gf = sum(r["gflop"] for r in rows)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.config}.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        achieved = (tot_gf * 1e9) / (tot_us * 1e-6) / 1e12 if tot_us > 0 else 0.0
+        roofline = dict(bound="mfma", kernel="igemm_{fwd,bwd,wgrad} (implicit-GEMM conv family, v_mfma_f32_32x32x2_f32)",
+                        achieved=round(achieved, 3), peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
+                        launches_per_step=len(rows), avg_launch_us=round(tot_us / max(1, len(rows)), 2),
+                        flop_per_launch=round(tot_gf * 1e9 / max(1, len(rows))), conv_us_per_step=round(tot_us, 1))
+        if args.kernel_table:
+            with open(args.kernel_table, "w") as f:
+                json.dump(rows, f, indent=1)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(cfg, args.cpu_seconds)
+
+    if rank == 0:
+        n_img = cfg["batch"] * world * args.steps
+        out = {
+            "metric": "training images/sec", "value": n_img / elapsed, "unit": "images/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": cfg["label"], "arch": cfg["arch"], "aggregator": cfg["agg"], "per_gpu_batch": cfg["batch"],
+                       "global_batch": cfg["batch"] * world, "image": f"3x{cfg['size']}x{cfg['size']}",
+                       "parallelism": f"dp{world}", "optimizer": "adam", "final_total_loss": final_loss,
+                       "launch": "hipGraph replay" if use_graph else "eager",
+                       "step_gflop": cfg["flops_per_img"] * cfg["batch"] / 1e9},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if dp is not None:
+        dp.shutdown()
+
+
+if __name__ == "__main__":
+    main()

@@ -101,6 +101,16 @@ def load():
     return _lib
 
 
+TRACE = None  # optional callable(name, args) invoked for every C-ABI launch (bench.py's recorder)
+
+
+def call(name, *args):
+    """Invoke one C-ABI entry point, raising RuntimeError with the library's message on failure."""
+    if TRACE is not None:
+        TRACE(name, args)
+    check(getattr(load(), name)(*args), name)
+
+
 def check(rc, what=""):
     if rc != 0:
         msg = load().movae_last_error().decode(errors="replace")

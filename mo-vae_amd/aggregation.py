@@ -34,8 +34,8 @@ def compute_gramian(J):
     k, m = J.shape
     G = torch.empty((k, k), dtype=torch.float32, device=J.device)
     ws = L.workspace(J.device)
-    L.check(L.load().movae_gram(J.data_ptr(), J.stride(0) if k > 1 else max(J.stride(0), m), k, m, G.data_ptr(),
-                                ws.data_ptr(), ws.numel(), _st(J)), "movae_gram")
+    L.call("movae_gram", J.data_ptr(), J.stride(0) if k > 1 else max(J.stride(0), m), k, m, G.data_ptr(),
+                                ws.data_ptr(), ws.numel(), _st(J))
     return G
 
 
@@ -44,8 +44,8 @@ def combine(J, w):
     _check_matrix(J)
     k, m = J.shape
     g = torch.empty(m, dtype=torch.float32, device=J.device)
-    L.check(L.load().movae_combine(J.data_ptr(), J.stride(0) if k > 1 else max(J.stride(0), m), k, m, w.data_ptr(),
-                                   g.data_ptr(), 0, _st(J)), "movae_combine")
+    L.call("movae_combine", J.data_ptr(), J.stride(0) if k > 1 else max(J.stride(0), m), k, m, w.data_ptr(),
+                                   g.data_ptr(), 0, _st(J))
     return g
 
 
@@ -55,8 +55,8 @@ def gd_similarity(J, w):
     k, m = J.shape
     out = torch.empty((), dtype=torch.float32, device=J.device)
     ws = L.workspace(J.device)
-    L.check(L.load().movae_gd_similarity(J.data_ptr(), J.stride(0) if k > 1 else max(J.stride(0), m), k, m, w.data_ptr(),
-                                         out.data_ptr(), ws.data_ptr(), ws.numel(), _st(J)), "movae_gd_similarity")
+    L.call("movae_gd_similarity", J.data_ptr(), J.stride(0) if k > 1 else max(J.stride(0), m), k, m, w.data_ptr(),
+                                         out.data_ptr(), ws.data_ptr(), ws.numel(), _st(J))
     return out
 
 
@@ -105,8 +105,8 @@ class UPGradWeighting(Weighting):
         k = G.shape[0]
         w = torch.empty(k, dtype=torch.float32, device=G.device)
         pref = _pref_tensor(self.pref_vector, G.device)
-        L.check(L.load().movae_weights_upgrad(G.data_ptr(), k, float(self.norm_eps), float(self.reg_eps), L.ptr(pref),
-                                              w.data_ptr(), _st(G)), "movae_weights_upgrad")
+        L.call("movae_weights_upgrad", G.data_ptr(), k, float(self.norm_eps), float(self.reg_eps), L.ptr(pref),
+                                              w.data_ptr(), _st(G))
         return w
 
 
@@ -157,8 +157,8 @@ class MGDAWeighting(Weighting):
             losses = self._losses.to(device=G.device, dtype=torch.float32).contiguous()
         w = torch.empty(k, dtype=torch.float32, device=G.device)
         self._info = torch.empty(1, dtype=torch.int32, device=G.device)
-        L.check(L.load().movae_weights_mgda(G.data_ptr(), k, L.MGDA_NORM[self.norm_type], L.ptr(losses), float(self.epsilon),
-                                            int(self.max_iters), w.data_ptr(), self._info.data_ptr(), _st(G)), "movae_weights_mgda")
+        L.call("movae_weights_mgda", G.data_ptr(), k, L.MGDA_NORM[self.norm_type], L.ptr(losses), float(self.epsilon),
+                                            int(self.max_iters), w.data_ptr(), self._info.data_ptr(), _st(G))
         return w
 
 
@@ -193,8 +193,7 @@ class AlignedMTLWeighting(Weighting):
         k = G.shape[0]
         w = torch.empty(k, dtype=torch.float32, device=G.device)
         pref = _pref_tensor(self._pref_vector, G.device)
-        L.check(L.load().movae_weights_amtl(G.data_ptr(), k, L.AMTL_SCALE[self._scale_mode], L.ptr(pref), w.data_ptr(), _st(G)),
-                "movae_weights_amtl")
+        L.call("movae_weights_amtl", G.data_ptr(), k, L.AMTL_SCALE[self._scale_mode], L.ptr(pref), w.data_ptr(), _st(G))
         return w
 
 
@@ -216,7 +215,7 @@ class _ConstWeighting(Weighting):
     def forward(self, G):
         k = G.shape[0]
         w = torch.empty(k, dtype=torch.float32, device=G.device)
-        L.check(L.load().movae_weights_const(k, 1.0 / k if self.mean else 1.0, w.data_ptr(), _st(G)), "movae_weights_const")
+        L.call("movae_weights_const", k, 1.0 / k if self.mean else 1.0, w.data_ptr(), _st(G))
         return w
 
 

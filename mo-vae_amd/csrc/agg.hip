@@ -65,12 +65,14 @@ __global__ __launch_bounds__(256) void gram_partial(const float* __restrict__ J,
     }
 }
 
-__global__ void gram_final(const double* __restrict__ part, int nblk, int K, float* __restrict__ G) {
+// one wave per Gramian entry (upper triangle), lanes stride over the block partials
+__global__ __launch_bounds__(64) void gram_final(const double* __restrict__ part, int nblk, int K, float* __restrict__ G) {
     const int NP = K * (K + 1) / 2;
-    const int q = threadIdx.x;
-    if (q >= NP) return;
+    const int q = blockIdx.x;
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += part[(long)b * NP + q];
+    for (int b = threadIdx.x; b < nblk; b += 64) s += part[(long)b * NP + q];
+    s = wave_sum(s);
+    if (threadIdx.x != 0) return;
     int i = 0, rem = q;
     while (rem >= K - i) {
         rem -= K - i;
@@ -436,7 +438,7 @@ int movae_gram(const float* J, size_t ldj, int k, size_t m, float* G, void* ws, 
     rc = [&]() -> int { DISPATCH_K(k, CALL_GRAM) return MOVAE_EINVAL; }();
 #undef CALL_GRAM
     if (rc) return rc;
-    hipLaunchKernelGGL(gram_final, dim3(1), dim3(64), 0, st, part, nb, k, G);
+    hipLaunchKernelGGL(gram_final, dim3(k * (k + 1) / 2), dim3(64), 0, st, part, nb, k, G);
     MOVAE_CHECK_LAUNCH("gram_final");
     return MOVAE_OK;
 }

@@ -5,7 +5,7 @@
 
 namespace {
 
-constexpr int MAX_PARTS = 512;
+constexpr int MAX_PARTS = 256;
 
 __host__ __device__ inline int pow2_ge(int v) {
     int p = 1;
@@ -65,16 +65,20 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
     }
 }
 
-__global__ void bn_stats_final(const double* __restrict__ part, int nblk, int rows, int C, float eps, float momentum,
-                               float* __restrict__ save_mean, float* __restrict__ save_rstd,
-                               float* __restrict__ running_mean, float* __restrict__ running_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// one wave per channel: lanes stride over the block partials, fp64 shuffle reduction
+__global__ __launch_bounds__(64) void bn_stats_final(const double* __restrict__ part, int nblk, int rows, int C, float eps,
+                                                     float momentum, float* __restrict__ save_mean,
+                                                     float* __restrict__ save_rstd, float* __restrict__ running_mean,
+                                                     float* __restrict__ running_var) {
+    const int c = blockIdx.x;
     double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) {
+    for (int b = threadIdx.x; b < nblk; b += 64) {
         s += part[((long)b * C + c) * 2 + 0];
         q += part[((long)b * C + c) * 2 + 1];
     }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if (threadIdx.x != 0) return;
     const double mean = s / rows;
     double var = q / rows - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -160,16 +164,19 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
     }
 }
 
-// sums[c] = (mean dz, mean dz*xhat) ; dgamma / dbeta written
-__global__ void bn_bwd_final(const double* __restrict__ part, int nblk, int rows, int C, float* __restrict__ sums,
-                             float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// sums[c] = (mean dz, mean dz*xhat) ; dgamma / dbeta written.  One wave per channel.
+__global__ __launch_bounds__(64) void bn_bwd_final(const double* __restrict__ part, int nblk, int rows, int C,
+                                                   float* __restrict__ sums, float* __restrict__ dgamma,
+                                                   float* __restrict__ dbeta, int accumulate) {
+    const int c = blockIdx.x;
     double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) {
+    for (int b = threadIdx.x; b < nblk; b += 64) {
         s += part[((long)b * C + c) * 2 + 0];
         q += part[((long)b * C + c) * 2 + 1];
     }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if (threadIdx.x != 0) return;
     sums[2 * c + 0] = (float)(s / rows);
     sums[2 * c + 1] = (float)(q / rows);
     if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)q : (float)q;
@@ -218,7 +225,7 @@ int movae_bn_act_fwd(const float* y, const float* gamma, const float* beta, floa
         double* part = static_cast<double*>(ws);
         hipLaunchKernelGGL(bn_stats_partial, dim3(s.nblk), dim3(256), 0, st, y, part, rows, c, s.CB, s.rows_per_block);
         MOVAE_CHECK_LAUNCH("bn_stats_partial");
-        hipLaunchKernelGGL(bn_stats_final, dim3(ceil_div(c, 128)), dim3(128), 0, st, part, s.nblk, rows, c, eps, momentum,
+        hipLaunchKernelGGL(bn_stats_final, dim3(c), dim3(64), 0, st, part, s.nblk, rows, c, eps, momentum,
                            save_mean, save_rstd, running_mean, running_var);
         MOVAE_CHECK_LAUNCH("bn_stats_final");
     } else {
@@ -252,7 +259,7 @@ int movae_bn_act_bwd(const float* dout, const float* y, const float* gamma, cons
     hipLaunchKernelGGL(bn_bwd_partial, dim3(s.nblk), dim3(256), 0, st, dout, y, gamma, beta, save_mean, save_rstd, part, rows,
                        c, s.CB, s.rows_per_block, act, slope);
     MOVAE_CHECK_LAUNCH("bn_bwd_partial");
-    hipLaunchKernelGGL(bn_bwd_final, dim3(ceil_div(c, 128)), dim3(128), 0, st, part, s.nblk, rows, c, sums, dgamma, dbeta,
+    hipLaunchKernelGGL(bn_bwd_final, dim3(c), dim3(64), 0, st, part, s.nblk, rows, c, sums, dgamma, dbeta,
                        accumulate);
     MOVAE_CHECK_LAUNCH("bn_bwd_final");
     const long total = (long)rows * c;

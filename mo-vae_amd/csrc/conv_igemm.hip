@@ -188,13 +188,15 @@ __global__ __launch_bounds__(256) void igemm_fwd(const float* __restrict__ X, co
 // ------------------------------------------------------------------------------------------------
 template <int BM, int BN, bool VEC>
 __global__ __launch_bounds__(256) void igemm_bwd(const float* __restrict__ X, const float* __restrict__ W,
-                                                 float* __restrict__ Y, Geom g, Epilogue ep) {
+                                                 float* __restrict__ Y, Geom g, Epilogue ep, int S, int ktiles_per_split,
+                                                 float* __restrict__ slab, long total) {
     using T = Tile<BM, BN>;
     __shared__ float As[BK * T::LDA];
     __shared__ float Bs[BK * T::LDB];
     const int t = threadIdx.x;
     const int s = g.stride;
-    const int ph = blockIdx.z / s, pw = blockIdx.z % s;
+    const int cls = blockIdx.z / S, split = blockIdx.z - cls * S;
+    const int ph = cls / s, pw = cls % s;
     const int Hoc = (g.Ho - ph + s - 1) / s, Woc = (g.Wo - pw + s - 1) / s;
     const int M = g.Nimg * Hoc * Woc;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
@@ -292,9 +294,11 @@ __global__ __launch_bounds__(256) void igemm_bwd(const float* __restrict__ X, co
 
     const int wave = t >> 6;
     const int wm = wave / T::WN, wn = wave % T::WN;
-    const int nk = (K + BK - 1) / BK;
-    if (nk > 0) load_tile(0);
-    for (int kt = 0; kt < nk; ++kt) {
+    const int nk_total = (K + BK - 1) / BK;
+    const int kt_begin = split * ktiles_per_split;
+    const int nk = min(nk_total, kt_begin + ktiles_per_split);
+    if (kt_begin < nk) load_tile(kt_begin);
+    for (int kt = kt_begin; kt < nk; ++kt) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < AR; ++i)
@@ -312,7 +316,9 @@ __global__ __launch_bounds__(256) void igemm_bwd(const float* __restrict__ X, co
     const int lane = t & 63, half = lane >> 5, l31 = lane & 31;
     const int n = n0 + wn * 32 + l31;
     if (n >= N) return;
-    const float bv = ep.bias ? ep.bias[n] : 0.f;
+    const bool to_slab = slab != nullptr;
+    const float bv = (!to_slab && ep.bias) ? ep.bias[n] : 0.f;
+    float* out = to_slab ? slab + (long)split * total : Y;
 #pragma unroll
     for (int tm = 0; tm < T::TM; ++tm)
 #pragma unroll
@@ -323,7 +329,7 @@ __global__ __launch_bounds__(256) void igemm_bwd(const float* __restrict__ X, co
                 const int img = m / hw, rem = m - img * hw;
                 const int hc = rem / Woc, wc = rem - hc * Woc;
                 const long p = ((long)img * g.Ho + (hc * s + ph)) * g.Wo + (wc * s + pw);
-                Y[p * N + n] = apply_act(acc[tm][r] + bv, ep.act, ep.slope);
+                out[p * N + n] = to_slab ? acc[tm][r] : apply_act(acc[tm][r] + bv, ep.act, ep.slope);
             }
         }
 }
@@ -338,7 +344,7 @@ struct WGeom {
     int KH, KW, stride, pad;
 };
 
-template <int BM, int BN, bool VEC>
+template <int BM, int BN, bool VECA, bool VECB>
 __global__ __launch_bounds__(256) void igemm_wgrad(const float* __restrict__ S, const float* __restrict__ Bg,
                                                    float* __restrict__ out, WGeom g, int K, int kchunk, int to_slab) {
     using T = Tile<BM, BN>;
@@ -376,7 +382,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad(const float* __restrict__ S, 
             const int ak = id / AQ, amq = id % AQ;
             const int k = k0 + ak, m = m0 + amq * 4;
             if (ak < BK) {
-                if (VEC) {
+                if (VECA) {
                     ra[pss] = (k < k_end && m < M) ? *reinterpret_cast<const f32x4*>(S + (long)k * M + m)
                                                  : f32x4{0.f, 0.f, 0.f, 0.f};
                 } else {
@@ -392,7 +398,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad(const float* __restrict__ S, 
             const int img = kk / hw, rem = kk - img * hw;
             const int hs = rem / g.Ws, ws = rem - hs * g.Ws;
             const float* base = Bg + (long)img * g.Hb * g.Wb * g.Cb;
-            if (VEC) {
+            if (VECB) {
                 const int h = hs * g.stride - g.pad + tap0_kh, w = ws * g.stride - g.pad + tap0_kw;
                 const bool v = kv && b_nv[0] && h >= 0 && h < g.Hb && w >= 0 && w < g.Wb;
                 rb = v ? *reinterpret_cast<const f32x4*>(base + ((long)h * g.Wb + w) * g.Cb + b_c[0])
@@ -452,15 +458,70 @@ __global__ __launch_bounds__(256) void igemm_wgrad(const float* __restrict__ S, 
 }
 
 // out[i] = (accumulate ? out[i] : 0) + sum_z slab[z][i], then optional bias (per column n = i % N) + activation
-__global__ void splitk_reduce(const float* __restrict__ slab, float* __restrict__ out, long total, int S, int N,
-                              const float* __restrict__ bias, int act, float slope, int accumulate) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
+// Block = 16 split-lanes x 16 consecutive outputs: lane (sl, il) sums slabs sl, sl+16, ... of output i0+il
+// (64-byte coalesced rows), then the 16 split-lanes are folded with 4 shuffles.  Deterministic.
+__global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ slab, float* __restrict__ out, long total,
+                                                     int S, int N, const float* __restrict__ bias, int act, float slope,
+                                                     int accumulate) {
+    const int il = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const long i = (long)blockIdx.x * 16 + il;
     float v = 0.f;
-    for (int z = 0; z < S; ++z) v += slab[(long)z * total + i];
-    if (bias) v += bias[i % N];
-    v = apply_act(v, act, slope);
-    out[i] = accumulate ? out[i] + v : v;
+    if (i < total)
+        for (int z = sl; z < S; z += 16) v += slab[(long)z * total + i];
+    // lanes of one wave hold sl in {4w..4w+3}; fold those with shuffles, then the 4 waves through LDS
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    __shared__ float sh[4][16];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) < 16) sh[w][il] = v;
+    __syncthreads();
+    if (threadIdx.x < 16 && i < total) {
+        v = (sh[0][il] + sh[1][il]) + (sh[2][il] + sh[3][il]);
+        if (bias) v += bias[i % N];
+        v = apply_act(v, act, slope);
+        out[i] = accumulate ? out[i] + v : v;
+    }
+}
+
+// few slabs over many outputs: one thread per output, grid-stride
+__global__ __launch_bounds__(256) void splitk_reduce_flat(const float* __restrict__ slab, float* __restrict__ out, long total,
+                                                          int S, int N, const float* __restrict__ bias, int act, float slope,
+                                                          int accumulate) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        float v = 0.f;
+        for (int z = 0; z < S; ++z) v += slab[(long)z * total + i];
+        if (bias) v += bias[i % N];
+        v = apply_act(v, act, slope);
+        out[i] = accumulate ? out[i] + v : v;
+    }
+}
+
+inline int launch_reduce(const float* slab, float* out, long total, int S, int N, const float* bias, int act, float slope,
+                         int accumulate, hipStream_t st) {
+    if (S >= 8 && total <= (1L << 20)) {
+        hipLaunchKernelGGL(splitk_reduce, dim3(ceil_div(total, 16)), dim3(256), 0, st, slab, out, total, S, N, bias, act, slope,
+                           accumulate);
+    } else {
+        long gq = (total + 255) / 256;
+        if (gq > 4096) gq = 4096;
+        hipLaunchKernelGGL(splitk_reduce_flat, dim3((int)gq), dim3(256), 0, st, slab, out, total, S, N, bias, act, slope,
+                           accumulate);
+    }
+    MOVAE_CHECK_LAUNCH("splitk_reduce");
+    return MOVAE_OK;
+}
+
+// split-K factor: enough blocks to occupy 256 CUs a few times over, at least MIN_KT k-tiles per split
+inline int choose_split(long tiles, int nk, size_t per_slab_bytes, size_t ws_bytes, bool have_ws) {
+    // splitting pays only when the unsplit grid cannot fill the chip once (256 CUs); every split costs one slab
+    // write + read of the whole output, so large outputs stay unsplit
+    if (!have_ws || tiles > 192 || nk < 4) return 1;
+    long S = (768 + tiles - 1) / tiles;
+    if (S > nk / 2) S = nk / 2;
+    if (S > 128) S = 128;
+    while (S > 1 && per_slab_bytes * (size_t)S > ws_bytes) --S;
+    return S < 2 ? 1 : (int)S;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -473,14 +534,8 @@ int launch_fwd_t(const float* X, const float* W, float* Y, const Geom& g, const 
                  void* ws, size_t ws_bytes, hipStream_t st) {
     const int gx = ceil_div(M, BM), gy = ceil_div(g.Nn, BN);
     const int nk = ceil_div(K, BK);
-    int S = 1;
     const long tiles = (long)gx * gy;
-    if (tiles < 128 && nk >= 8 && ws) {
-        S = (int)min((long)(512 / tiles), (long)(nk / 4));
-        const size_t per = (size_t)M * g.Nn * sizeof(float);
-        while (S > 1 && per * S > ws_bytes) --S;
-        if (S < 2) S = 1;
-    }
+    int S = choose_split(tiles, nk, (size_t)M * g.Nn * sizeof(float), ws_bytes, ws != nullptr);
     const int per_split = ceil_div(nk, S);
     S = ceil_div(nk, per_split);
     float* slab = S > 1 ? static_cast<float*>(ws) : nullptr;
@@ -492,9 +547,7 @@ int launch_fwd_t(const float* X, const float* W, float* Y, const Geom& g, const 
     MOVAE_CHECK_LAUNCH("igemm_fwd");
     if (S > 1) {
         const long total = (long)M * g.Nn;
-        hipLaunchKernelGGL(splitk_reduce, dim3(ceil_div(total, 256)), dim3(256), 0, st, slab, Y, total, S, g.Nn, ep.bias,
-                           ep.act, ep.slope, 0);
-        MOVAE_CHECK_LAUNCH("splitk_reduce");
+        if (int rc = launch_reduce(slab, Y, total, S, g.Nn, ep.bias, ep.act, ep.slope, 0, st)) return rc;
     }
     return MOVAE_OK;
 }
@@ -515,19 +568,31 @@ int launch_fwd(const float* X, const float* W, float* Y, const Geom& g, const Ep
 }
 
 template <int BM, int BN>
-int launch_bwd_t(const float* X, const float* W, float* Y, const Geom& g, const Epilogue& ep, bool vec, hipStream_t st) {
+int launch_bwd_t(const float* X, const float* W, float* Y, const Geom& g, const Epilogue& ep, bool vec, void* ws,
+                 size_t ws_bytes, hipStream_t st) {
     const int s = g.stride;
     const long Mmax = (long)g.Nimg * ceil_div(g.Ho, s) * ceil_div(g.Wo, s);
-    dim3 grid(ceil_div(Mmax, BM), ceil_div(g.Nn, BN), s * s);
+    const int gx = ceil_div(Mmax, BM), gy = ceil_div(g.Nn, BN);
+    const int nk_max = ceil_div((long)ceil_div(g.KH, s) * ceil_div(g.KW, s) * g.Cr, BK);
+    const long total = (long)g.Nimg * g.Ho * g.Wo * g.Nn;
+    int S = choose_split((long)gx * gy * s * s, nk_max, (size_t)total * sizeof(float), ws_bytes, ws != nullptr);
+    const int per_split = ceil_div(nk_max, S);
+    S = ceil_div(nk_max, per_split);
+    float* slab = S > 1 ? static_cast<float*>(ws) : nullptr;
+    dim3 grid(gx, gy, s * s * S);
     if (vec)
-        hipLaunchKernelGGL((igemm_bwd<BM, BN, true>), grid, dim3(256), 0, st, X, W, Y, g, ep);
+        hipLaunchKernelGGL((igemm_bwd<BM, BN, true>), grid, dim3(256), 0, st, X, W, Y, g, ep, S, per_split, slab, total);
     else
-        hipLaunchKernelGGL((igemm_bwd<BM, BN, false>), grid, dim3(256), 0, st, X, W, Y, g, ep);
+        hipLaunchKernelGGL((igemm_bwd<BM, BN, false>), grid, dim3(256), 0, st, X, W, Y, g, ep, S, per_split, slab, total);
     MOVAE_CHECK_LAUNCH("igemm_bwd");
+    if (S > 1) {
+        if (int rc = launch_reduce(slab, Y, total, S, g.Nn, ep.bias, ep.act, ep.slope, 0, st)) return rc;
+    }
     return MOVAE_OK;
 }
 
-int launch_bwd(const float* X, const float* W, float* Y, const Geom& g, const Epilogue& ep, hipStream_t st) {
+int launch_bwd(const float* X, const float* W, float* Y, const Geom& g, const Epilogue& ep, void* ws, size_t ws_bytes,
+               hipStream_t st) {
     const long Ml = (long)g.Nimg * g.Ho * g.Wo;
     if (Ml <= 0 || g.Nn <= 0 || g.Cr <= 0 || Ml > 0x7fffffffL) {
         movae_set_error("conv bwd-form: bad shape M=%ld N=%d Cr=%d", Ml, g.Nn, g.Cr);
@@ -535,23 +600,18 @@ int launch_bwd(const float* X, const float* W, float* Y, const Geom& g, const Ep
     }
     const bool vec = (g.Cr % BK == 0) && (g.Nn % 4 == 0) && aligned16(X) && aligned16(W);
     const long Mc = Ml / (g.stride * g.stride);
-    if (g.Nn <= 32) return launch_bwd_t<128, 32>(X, W, Y, g, ep, vec, st);
-    if (Mc >= 128 * 512) return launch_bwd_t<128, 64>(X, W, Y, g, ep, vec, st);
-    return launch_bwd_t<64, 64>(X, W, Y, g, ep, vec, st);
+    if (g.Nn <= 32) return launch_bwd_t<128, 32>(X, W, Y, g, ep, vec, ws, ws_bytes, st);
+    if (Mc >= 128 * 512) return launch_bwd_t<128, 64>(X, W, Y, g, ep, vec, ws, ws_bytes, st);
+    return launch_bwd_t<64, 64>(X, W, Y, g, ep, vec, ws, ws_bytes, st);
 }
 
 template <int BM, int BN>
-int launch_wgrad_t(const float* S, const float* Bg, float* dW, const WGeom& g, int K, bool vec, int accumulate, void* ws,
+int launch_wgrad_t(const float* S, const float* Bg, float* dW, const WGeom& g, int K, int vec, int accumulate, void* ws,
                    size_t ws_bytes, hipStream_t st) {
     const int M = g.Cs, N = g.KH * g.KW * g.Cb;
     const int gx = ceil_div(M, BM), gy = ceil_div(N, BN);
     const long tiles = (long)gx * gy;
-    int Sp = 1;
-    if (ws) {
-        Sp = (int)max(1L, min((long)(1024 / tiles), (long)(K / (4 * BK))));
-        const size_t per = (size_t)M * N * sizeof(float);
-        while (Sp > 1 && per * Sp > ws_bytes) --Sp;
-    }
+    int Sp = choose_split(tiles, ceil_div(K, BK), (size_t)M * N * sizeof(float), ws_bytes, ws != nullptr);
     int kchunk = ceil_div(ceil_div(K, Sp), BK) * BK;
     Sp = ceil_div(K, kchunk);
     const bool slab = Sp > 1 || accumulate;
@@ -561,16 +621,19 @@ int launch_wgrad_t(const float* S, const float* Bg, float* dW, const WGeom& g, i
     }
     float* out = slab ? static_cast<float*>(ws) : dW;
     dim3 grid(gx, gy, Sp);
-    if (vec)
-        hipLaunchKernelGGL((igemm_wgrad<BM, BN, true>), grid, dim3(256), 0, st, S, Bg, out, g, K, kchunk, slab ? 1 : 0);
+    const bool va = (vec & 1) != 0, vb = (vec & 2) != 0;
+    if (va && vb)
+        hipLaunchKernelGGL((igemm_wgrad<BM, BN, true, true>), grid, dim3(256), 0, st, S, Bg, out, g, K, kchunk, slab ? 1 : 0);
+    else if (va)
+        hipLaunchKernelGGL((igemm_wgrad<BM, BN, true, false>), grid, dim3(256), 0, st, S, Bg, out, g, K, kchunk, slab ? 1 : 0);
+    else if (vb)
+        hipLaunchKernelGGL((igemm_wgrad<BM, BN, false, true>), grid, dim3(256), 0, st, S, Bg, out, g, K, kchunk, slab ? 1 : 0);
     else
-        hipLaunchKernelGGL((igemm_wgrad<BM, BN, false>), grid, dim3(256), 0, st, S, Bg, out, g, K, kchunk, slab ? 1 : 0);
+        hipLaunchKernelGGL((igemm_wgrad<BM, BN, false, false>), grid, dim3(256), 0, st, S, Bg, out, g, K, kchunk, slab ? 1 : 0);
     MOVAE_CHECK_LAUNCH("igemm_wgrad");
     if (slab) {
         const long total = (long)M * N;
-        hipLaunchKernelGGL(splitk_reduce, dim3(ceil_div(total, 256)), dim3(256), 0, st, out, dW, total, Sp, N,
-                           (const float*)nullptr, 0, 0.f, accumulate);
-        MOVAE_CHECK_LAUNCH("splitk_reduce");
+        if (int rc = launch_reduce(out, dW, total, Sp, N, nullptr, 0, 0.f, accumulate, st)) return rc;
     }
     return MOVAE_OK;
 }
@@ -582,7 +645,7 @@ int launch_wgrad(const float* S, const float* Bg, float* dW, const WGeom& g, int
         movae_set_error("wgrad: bad shape K=%ld Cs=%d Cb=%d", Kl, g.Cs, g.Cb);
         return MOVAE_EINVAL;
     }
-    const bool vec = (g.Cs % 4 == 0) && (g.Cb % 4 == 0) && aligned16(S) && aligned16(Bg);
+    const int vec = ((g.Cs % 4 == 0 && aligned16(S)) ? 1 : 0) | ((g.Cb % 4 == 0 && aligned16(Bg)) ? 2 : 0);
     const int N = g.KH * g.KW * g.Cb;
     if (N <= 32) return launch_wgrad_t<128, 32>(S, Bg, dW, g, (int)Kl, vec, accumulate, ws, ws_bytes, st);
     return launch_wgrad_t<64, 64>(S, Bg, dW, g, (int)Kl, vec, accumulate, ws, ws_bytes, st);
@@ -631,8 +694,7 @@ int movae_conv2d_dgrad(const float* dy, const float* w, float* dx, int n, int hi
     if (int rc = check_conv_shape("movae_conv2d_dgrad", n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, false)) return rc;
     // gathered tensor = dy (ho x wo x co), output grid = dx (hi x wi x ci); W[co][tap][ci] is the [Cr][tap][Nn] image
     Geom g{n, ho, wo, co, hi, wi, ci, kh, kw, stride, pad};
-    (void)ws; (void)ws_bytes;
-    return launch_bwd(dy, w, dx, g, Epilogue{nullptr, MOVAE_ACT_NONE, 0.f}, (hipStream_t)stream);
+    return launch_bwd(dy, w, dx, g, Epilogue{nullptr, MOVAE_ACT_NONE, 0.f}, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int movae_conv2d_wgrad(const float* dy, const float* x, float* dw, float* dbias, int n, int hi, int wi, int ci, int ho,
@@ -652,8 +714,7 @@ int movae_convT2d_fwd(const float* x, const float* w, const float* bias, float* 
     MOVAE_CHECK_ARG(x && w && y, "movae_convT2d_fwd: null pointer");
     if (int rc = check_conv_shape("movae_convT2d_fwd", n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, true)) return rc;
     Geom g{n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad};
-    (void)ws; (void)ws_bytes;
-    return launch_bwd(x, w, y, g, Epilogue{bias, act, slope}, (hipStream_t)stream);
+    return launch_bwd(x, w, y, g, Epilogue{bias, act, slope}, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int movae_convT2d_dgrad(const float* dy, const float* w, float* dx, int n, int hi, int wi, int ci, int ho, int wo, int co,

@@ -117,12 +117,13 @@ __global__ __launch_bounds__(256) void colsum_partial(const float* __restrict__ 
     }
 }
 
-__global__ void colsum_final(const double* __restrict__ part, int nblk, int C, float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(64) void colsum_final(const double* __restrict__ part, int nblk, int C, float* __restrict__ out,
+                                                   int accumulate) {
+    const int c = blockIdx.x;
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += part[(long)b * C + c];
-    out[c] = accumulate ? out[c] + (float)s : (float)s;
+    for (int b = threadIdx.x; b < nblk; b += 64) s += part[(long)b * C + c];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 
 __global__ void reparam_fwd_k(const float* __restrict__ mu, const float* __restrict__ lv, const float* __restrict__ eps,
@@ -226,7 +227,7 @@ int movae_colsum(const float* x, float* out, int rows, int c, int accumulate, vo
     double* part = static_cast<double*>(ws);
     hipLaunchKernelGGL(colsum_partial, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, part, rows, c, CB, rpb);
     MOVAE_CHECK_LAUNCH("colsum_partial");
-    hipLaunchKernelGGL(colsum_final, dim3(ceil_div(c, 128)), dim3(128), 0, (hipStream_t)stream, part, nblk, c, out, accumulate);
+    hipLaunchKernelGGL(colsum_final, dim3(c), dim3(64), 0, (hipStream_t)stream, part, nblk, c, out, accumulate);
     MOVAE_CHECK_LAUNCH("colsum_final");
     return MOVAE_OK;
 }

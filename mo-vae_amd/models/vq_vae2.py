@@ -98,14 +98,17 @@ class VQVAE2(HotPathModel):
         self.latent_spatial_dim_top = input_size // 8
 
     def encode(self, x):
-        enc_b = self.enc_b(ops.to_nhwc(x))
-        enc_t = self.enc_t(enc_b)
-        quant_t, c_t, e_t, i_t = self.quantize_t(nchw_view(self.quantize_conv_t(enc_t)))
+        # the returned NCHW views ARE the graph nodes later stages consume (mtl_backward differentiates
+        # the losses w.r.t. these feature tensors), so downstream ops re-enter through the views
+        enc_b = nchw_view(self.enc_b(ops.to_nhwc(x)))
+        enc_t = nchw_view(self.enc_t(ops.to_nhwc(enc_b)))
+        quant_t, c_t, e_t, i_t = self.quantize_t(nchw_view(self.quantize_conv_t(ops.to_nhwc(enc_t))))
         used_t = self.quantize_t.last_used_count
         dec_t = self.dec_t(ops.to_nhwc(quant_t))
-        quant_b, c_b, e_b, i_b = self.quantize_b(nchw_view(self.quantize_conv_b(ops.concat_channels(dec_t, enc_b))))
+        quant_b, c_b, e_b, i_b = self.quantize_b(
+            nchw_view(self.quantize_conv_b(ops.concat_channels(dec_t, ops.to_nhwc(enc_b)))))
         self._used = (used_t, self.quantize_b.last_used_count)
-        return nchw_view(enc_b), nchw_view(enc_t), quant_t, quant_b, c_t, c_b, e_t, e_b, i_t, i_b
+        return enc_b, enc_t, quant_t, quant_b, c_t, c_b, e_t, e_b, i_t, i_b
 
     def decode(self, quant_t, quant_b):
         up = self.upsample_t(ops.to_nhwc(quant_t))

@@ -11,8 +11,7 @@ from torch.autograd import Function
 from . import _lib as L
 
 
-def _call(name, *args):
-    L.check(getattr(L.load(), name)(*args), name)
+_call = L.call
 
 
 def _ws(t):

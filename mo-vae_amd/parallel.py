@@ -1,0 +1,78 @@
+"""Data-parallel step exchange: one process per GPU, the minibatch is sharded,
+every rank runs its K per-loss backward passes and its own aggregation locally, and only the
+AGGREGATED gradient crosses xGMI -- a single all-reduce of one flat fp32 bucket per step (RCCL,
+`backend="nccl"`; gloo for the CPU rehearsal in tests/).  The reference has no multi-device code.
+
+Semantics (documented limitation): aggregation is non-linear in J and BatchNorm statistics are
+per-rank, so N ranks reproduce "the mean over shards of the single-device result on each shard",
+not the single-device large-batch step.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def flatten_grads(params):
+    """All gradients in one contiguous buffer (memory order); params without grad contribute zeros."""
+    chunks = []
+    for p in params:
+        if p.grad is None:
+            chunks.append(torch.zeros(p.numel(), dtype=p.dtype, device=p.device))
+        else:
+            g = p.grad
+            if g.dim() == 4 and not g.is_contiguous() and g.permute(0, 2, 3, 1).is_contiguous():
+                chunks.append(g.permute(0, 2, 3, 1).reshape(-1))
+            else:
+                chunks.append(g.contiguous().reshape(-1))
+    return torch.cat(chunks)
+
+
+def unflatten_into_grads(flat, params):
+    off = 0
+    for p in params:
+        n = p.numel()
+        p.grad = flat[off: off + n].as_strided(p.shape, p.stride())  # params are dense (contiguous or channels_last)
+        off += n
+
+
+class DataParallelGrads:
+    def __init__(self, rank, world_size, local_rank, backend):
+        self.rank, self.world_size, self.local_rank, self.backend = rank, world_size, local_rank, backend
+        self.params = []
+
+    @classmethod
+    def from_env(cls, backend=None):
+        """torchrun / torch.distributed.run environment -> initialised process group, or None."""
+        ws = int(os.environ.get("WORLD_SIZE", "1"))
+        if ws <= 1:
+            return None
+        rank, local_rank = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", os.environ["RANK"]))
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend=backend, rank=rank, world_size=ws)
+        return cls(rank, ws, local_rank, backend)
+
+    def attach(self, net):
+        """Broadcast rank 0's parameters / buffers so every replica starts identical."""
+        self.params = [p for p in net.parameters() if p.requires_grad]
+        for t in list(net.parameters()) + list(net.buffers()):
+            dist.broadcast(t.data, src=0)
+
+    def all_reduce_grads(self):
+        """mean over ranks of the full flat gradient: ONE collective per step."""
+        flat = flatten_grads(self.params)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(self.world_size)
+        unflatten_into_grads(flat, self.params)
+        return flat
+
+    def barrier(self):
+        dist.barrier()
+
+    def shutdown(self):
+        if dist.is_initialized():
+            dist.destroy_process_group()

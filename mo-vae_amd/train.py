@@ -1,0 +1,432 @@
+"""Training loop and CLI of the hot path -- drop-in for the reference's main.py:125-235 (train_epoch),
+:1088-1497 (main) and :1500-1670 (argparse), restricted to what the per-step path needs.
+
+Differences that are by design: the step's device->host reads (losses, hook values) are
+batched into ONE copy per step instead of ~K+5 `.item()` syncs; evaluation metrics that need
+pretrained networks (FID/IS/LPIPS) and dataset downloads are out of scope -- `--dataset synthetic_*`
+provides seeded in-memory data of the right shape; with torchrun (WORLD_SIZE>1) the batch is sharded
+and the aggregated gradient is all-reduced once per step over RCCL.
+"""
+import json
+import math
+import os
+import time
+from argparse import ArgumentParser
+
+import torch
+import torch.optim as optim
+
+from . import aggregation
+from . import autojac
+from .aggregation import MGDA
+from .models import get_network
+from .parallel import DataParallelGrads
+
+_current_step = 0
+_hook_values = {}
+
+
+class AverageMeter:
+    """utils/utils.py:62-109."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val = self.avg = self.sum = 0.0
+        self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+
+def set_seed(seed):
+    """utils/utils.py:58-60."""
+    import numpy as np
+
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(seed)
+        torch.cuda.manual_seed_all(seed)
+
+
+# ---- aggregator hooks (main.py:71-122): computed on device, read with the step's single host copy ----
+def print_weights(_, __, weights):
+    _hook_values["weights"] = weights
+
+
+def print_gd_similarity(_, inputs, weights):
+    _hook_values["similarity"] = aggregation.gd_similarity(inputs[0], weights)
+
+
+def train_step(net, images, optimizer, aggregator, args, dp=None):
+    """One optimisation step (main.py:155-214).  Returns the loss dict (device tensors) and outputs."""
+    optimizer.zero_grad()
+    outputs = net(images)
+    loss_dict = net.loss_function(images, args=outputs)
+    if aggregator is None or aggregator == "sum":
+        loss_dict["total_loss"].backward()
+    else:
+        features = [outputs[f] for f in net.features] if net.features is not None else None
+        component_losses = [v for k, v in loss_dict.items() if k != "total_loss"]  # main.py:184
+        if isinstance(aggregator, MGDA):
+            aggregator.set_losses(torch.stack([c.detach() for c in component_losses]))
+        if features is not None:
+            autojac.mtl_backward(losses=component_losses, features=features, aggregator=aggregator, retain_graph=True)
+        else:
+            autojac.backward(component_losses, aggregator=aggregator)
+    if dp is not None:
+        dp.all_reduce_grads()
+    if getattr(args, "max_grad_norm", None) is not None:
+        torch.nn.utils.clip_grad_norm_(net.parameters(), max_norm=args.max_grad_norm)
+    optimizer.step()
+    return loss_dict, outputs
+
+
+GRAPH_SAFE_ARCHS = {"VAE"}  # forward/loss free of host syncs and of Python-side per-step scalars
+
+
+class GraphedTrainStep:
+    """The whole optimisation step (forward, losses, K per-loss backward passes, Gram / solve / combine,
+    optimizer) captured ONCE into a hipGraph and replayed per batch: the step is ~250 short kernels, so
+    eager launches are host-bound; a replay is one submission.  No tracing compiler is involved -- the
+    graph holds exactly the launches the eager step made.  The optimizer must be constructed with
+    capturable=True (its step counter then lives on the device)."""
+
+    def __init__(self, net, optimizer, aggregator, args, example, warmup=3):
+        if type(net).__name__ not in GRAPH_SAFE_ARCHS:
+            raise NotImplementedError(f"{type(net).__name__}: forward syncs with the host (codebook usage / anneal counter); "
+                                      "use the eager train_step")
+        if getattr(args, "max_grad_norm", None) is not None:
+            raise NotImplementedError("clip_grad_norm_ reads the norm on the host; use the eager train_step")
+        self.net, self.opt, self.agg, self.args = net, optimizer, aggregator, args
+        self.static_x = example.clone()
+        from . import _lib as L
+
+        L.workspace(example.device)  # allocate the scratch arena outside the capture
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                train_step(net, self.static_x, optimizer, aggregator, args)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self.loss_dict, self.outputs = train_step(net, self.static_x, optimizer, aggregator, args)
+
+    def step(self, images):
+        self.static_x.copy_(images, non_blocking=True)
+        self.graph.replay()
+        return self.loss_dict, self.outputs
+
+
+def _host_values(loss_dict):
+    """ONE device->host transfer for every scalar the step logs."""
+    keys = list(loss_dict.keys())
+    vals = [loss_dict[k].detach().reshape(1) for k in keys]
+    extra = []
+    if "weights" in _hook_values:
+        extra.append(_hook_values["weights"].detach().reshape(-1))
+    if "similarity" in _hook_values:
+        extra.append(_hook_values["similarity"].detach().reshape(1))
+    flat = torch.cat(vals + extra).cpu().tolist()
+    out = dict(zip(keys, flat[: len(keys)]))
+    rest = flat[len(keys):]
+    if "weights" in _hook_values:
+        k = _hook_values["weights"].numel()
+        out["_weights"] = rest[:k]
+        rest = rest[k:]
+    if "similarity" in _hook_values:
+        out["_similarity"] = rest[0]
+    return out
+
+
+def train_epoch(net, train_loader, optimizer, aggregator, step, device, args, dp=None, log=None):
+    """main.py:125-235."""
+    global _current_step
+    net.train()
+    meters = {k: AverageMeter() for k in net.objectives.keys()}
+    meters["total_loss"] = AverageMeter()
+    usage = AverageMeter()
+    for images, _ in train_loader:
+        images = images.to(device, non_blocking=True)
+        _current_step = step + 1
+        _hook_values.clear()
+        try:
+            loss_dict, outputs = train_step(net, images, optimizer, aggregator, args, dp)
+        except RuntimeError as e:  # main.py:197-208: skip the batch on device-side assertion errors
+            if "cuda" in str(e).lower() or "hip" in str(e).lower() or "assert" in str(e).lower():
+                print(f"Step {step}: device error during backward: {e}\n  Skipping this batch...")
+                continue
+            raise
+        host = _host_values(loss_dict)
+        if host["total_loss"] > 1e15:
+            print(f"Step {step}: EXPLODING: Total loss: {host['total_loss']:.6e}")
+        if "codebook_usage_percentage" in outputs:
+            usage.update(outputs["codebook_usage_percentage"], n=images.size(0))
+        for k in meters:
+            meters[k].update(host[k])
+        step += 1
+        if log is not None:
+            rec = {f"train/{k}": m.avg for k, m in meters.items()}
+            rec.update({f"train/{k}_curr": m.val for k, m in meters.items()})
+            if usage.count > 0:
+                rec["train/codebook_usage_percentage"] = usage.avg
+            for i, w in enumerate(host.get("_weights", [])):
+                rec[f"train/task_{i}_weight"] = w
+            if "_similarity" in host:
+                rec["train/gradient_similarity"] = host["_similarity"]
+            log(rec, step)
+    if usage.count > 0:
+        meters["codebook_usage_percentage"] = usage
+    return meters, step
+
+
+@torch.no_grad()
+def evaluate(net, loader, device, args):
+    """main.py:238-332, losses and codebook usage only."""
+    net.eval()
+    meters = {k: AverageMeter() for k in net.objectives.keys()}
+    meters["total_loss"] = AverageMeter()
+    for images, _ in loader:
+        images = images.to(device)
+        out = net(images)
+        ld = net.loss_function(images, args=out)
+        vals = torch.stack([ld[k].detach() for k in meters]).cpu().tolist()
+        for k, v in zip(meters, vals):
+            meters[k].update(v, n=images.size(0))
+    return meters
+
+
+# ---- data ----------------------------------------------------------------------------------------
+SYNTHETIC = {"synthetic_cifar10": (32, 50000), "synthetic_celeba": (64, 162770), "synthetic_celeba_hq": (256, 30000),
+             "synthetic_imagenet": (256, 1281167)}
+
+
+class SyntheticImages(torch.utils.data.Dataset):
+    """Seeded uniform [0,1) images (the un-normalised ToTensor range, utils/utils.py:187-192)."""
+
+    def __init__(self, n, size, seed, normalize=False):
+        self.n, self.size, self.seed, self.normalize = n, size, seed, normalize
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(self.seed * 1_000_003 + i)
+        x = torch.rand(3, self.size, self.size, generator=g)
+        return (2 * x - 1 if self.normalize else x), 0
+
+
+def get_dataset(name, data_dir="./data", normalize=False, max_items=None):
+    """utils/utils.py:144-426 for real datasets needs torchvision / HF `datasets` downloads, which are
+    unavailable offline; synthetic_* names give shape-compatible data."""
+    key = name.lower()
+    if key in SYNTHETIC:
+        size, n = SYNTHETIC[key]
+        n = min(n, max_items) if max_items else n
+        return SyntheticImages(n, size, 0, normalize), SyntheticImages(max(1, n // 10), size, 1, normalize), size
+    raise NotImplementedError(
+        f"dataset {name!r}: real datasets are fetched over the network by the reference (torchvision / HF hub) and are "
+        f"outside the hot path; use one of {sorted(SYNTHETIC)}")
+
+
+# ---- CLI -----------------------------------------------------------------------------------------
+def build_parser():
+    """Flag names, aliases and defaults of main.py:1500-1651 (hot-path subset keeps every name)."""
+    p = ArgumentParser()
+    p.add_argument("--seed", type=int, default=None)
+    p.add_argument("--device", type=str, default="cuda:0" if torch.cuda.is_available() else "cpu")
+    p.add_argument("--data_dir", type=str, default="./data")
+    p.add_argument("--save_path", type=str, default="logs/")
+    p.add_argument("--epochs", type=int, default=50)
+    p.add_argument("--dataset", type=str, default="CIFAR10")
+    p.add_argument("--normalize_inputs", action="store_true", dest="normalize_inputs")
+    p.add_argument("--batch_size", type=int, default=128)
+    p.add_argument("--num_workers", type=int, default=0)
+    p.add_argument("--aggregator", "--agg", type=str, default=None)
+    p.add_argument("--agg_norm_eps", "--agg-norm-eps", "--norm_eps", "--norm-eps", type=float, default=1e-4)
+    p.add_argument("--agg_reg_eps", "--agg-reg-eps", "--reg_eps", "--reg-eps", type=float, default=1e-4)
+    p.add_argument("--mgda_epsilon", "--mgda-epsilon", type=float, default=1e-5)
+    p.add_argument("--mgda_max_iters", "--mgda-max-iters", type=int, default=250)
+    p.add_argument("--mgda_min_eigenvalue_eps", "--mgda-min-eigenvalue-eps", type=float, default=1e-10)
+    p.add_argument("--comfort_mgda_norm_type", "--comfort-mgda-norm-type", type=str, default="none", choices=["none", "l2", "loss", "loss+"])
+    p.add_argument("--comfort_mgda_stable", "--comfort-mgda-stable", action="store_true")
+    p.add_argument("--comfort_beta_k", type=float, default=1.0)
+    p.add_argument("--comfort_beta_a", type=float, default=1.0)
+    p.add_argument("--comfort_beta_l", type=float, default=0.01)
+    p.add_argument("--comfort_beta_u", type=float, default=1.0)
+    p.add_argument("--arch", type=str, default="vae")
+    p.add_argument("--layer_norm", type=str, default="batch")
+    p.add_argument("--latent_dim", type=int, default=128)
+    p.add_argument("--hidden_dims", type=int, nargs="+", default=[32, 64, 128, 256, 512])
+    p.add_argument("--num_residual_layers", type=int, default=2)
+    p.add_argument("--recons_objective", type=str, default="mse", choices=["mse", "bce", "l1", "smooth_l1", "perceptual"])
+    p.add_argument("--recons_activation", type=str, default=None, choices=["tanh", "sigmoid", "none"])
+    p.add_argument("--loss_weights", type=str, nargs="*", default=None)
+    p.add_argument("--pref_weights", type=str, nargs="*", default=None)
+    p.add_argument("--optimizer", type=str, default="adam")
+    p.add_argument("--momentum", type=float, default=0.9)
+    p.add_argument("--max_grad_norm", type=float, default=None)
+    p.add_argument("--lr", type=float, default=0.001)
+    p.add_argument("--wd", "--weight_decay", type=float, default=0)
+    p.add_argument("--scheduler", type=str, default=None)
+    p.add_argument("--scheduler_lr_min", type=float, default=0.0)
+    p.add_argument("--scheduler_gamma", type=float, default=0.1)
+    p.add_argument("--scheduler_milestones", type=int, nargs="+", default=None)
+    p.add_argument("--embedding_dim", type=int, default=None)
+    p.add_argument("--num_embeddings", type=int, default=None)
+    p.add_argument("--anneal_steps", type=int, default=None)
+    p.add_argument("--hv_ref", type=str, nargs="*", default=None)
+    p.add_argument("--num_vis_samples", type=int, default=4, dest="num_vis_samples")
+    p.add_argument("--save_freq", type=int, default=10)
+    p.add_argument("--eval_freq", type=int, default=1)
+    p.add_argument("--use_wandb", action="store_true")
+    p.add_argument("--wandb_project", type=str, default="mo-vae")
+    p.add_argument("--wandb_entity", type=str, default=None)
+    p.add_argument("--wandb_name", type=str, default=None)
+    p.add_argument("--wandb_group", type=str, default=None)
+    p.add_argument("--wandb_tags", type=str, nargs="+", default=None)
+    p.add_argument("--max_fid_samples", type=int, default=10000)
+    p.add_argument("--max_gen_metrics_samples", type=int, default=10000)
+    p.add_argument("--skip_pixelcnn", action="store_true")
+    # additions of this build (not in the reference)
+    p.add_argument("--max_items", type=int, default=None, help="cap the synthetic dataset length")
+    p.add_argument("--max_steps", type=int, default=None, help="stop after this many optimisation steps")
+    return p
+
+
+def parse_args(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.loss_weights is not None and len(args.loss_weights) > 0:  # main.py:1655-1659
+        if len(args.loss_weights) == 1 and args.loss_weights[0].strip().startswith("{"):
+            args.loss_weights = json.loads(args.loss_weights[0])
+        else:
+            args.loss_weights = [float(x) for x in args.loss_weights]
+    if args.hv_ref is not None and len(args.hv_ref) > 0:
+        if len(args.hv_ref) == 1 and args.hv_ref[0].strip().startswith("{"):
+            args.hv_ref = {k: float(v) for k, v in json.loads(args.hv_ref[0]).items()}
+        else:
+            args.hv_ref = [float(x) for x in args.hv_ref]
+    return args
+
+
+def make_optimizer(net, args, capturable=False):
+    """main.py:1169-1178.  capturable=True keeps Adam's step counter on the device (hipGraph replay)."""
+    if args.optimizer == "sgd":
+        return optim.SGD(net.parameters(), lr=args.lr, momentum=args.momentum, weight_decay=args.wd)
+    if args.optimizer == "adam":
+        return optim.Adam(net.parameters(), lr=args.lr, weight_decay=args.wd, capturable=capturable)
+    if args.optimizer == "adamw":
+        return optim.AdamW(net.parameters(), lr=args.lr, weight_decay=args.wd, capturable=capturable)
+    if args.optimizer == "rmsprop":
+        return optim.RMSprop(net.parameters(), lr=args.lr, weight_decay=args.wd)
+    raise ValueError(f"Optimizer {args.optimizer} not supported")
+
+
+def make_scheduler(optimizer, args):
+    """main.py:1180-1189."""
+    if args.scheduler is None:
+        return None
+    if args.scheduler == "cosine":
+        return optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=args.epochs, eta_min=args.scheduler_lr_min)
+    if args.scheduler == "multi_step":
+        return optim.lr_scheduler.MultiStepLR(optimizer, milestones=args.scheduler_milestones, gamma=args.scheduler_gamma)
+    if args.scheduler == "exponential":
+        return optim.lr_scheduler.ExponentialLR(optimizer, gamma=args.scheduler_gamma)
+    raise ValueError(f"Scheduler {args.scheduler} not supported")
+
+
+def main(args):
+    dp = DataParallelGrads.from_env()
+    if dp is not None:
+        args.device = f"cuda:{dp.local_rank}"
+    device = torch.device(args.device)
+    if device.type != "cuda":
+        raise RuntimeError("the MI355X hot path needs a HIP device (--device cuda:N); there is no CPU path")
+    torch.cuda.set_device(device)
+    train_ds, test_ds, input_size = get_dataset(args.dataset, data_dir=args.data_dir, normalize=args.normalize_inputs,
+                                                max_items=args.max_items)
+    per_rank_bs = args.batch_size if dp is None else max(1, args.batch_size // dp.world_size)
+    sampler = None
+    if dp is not None:
+        sampler = torch.utils.data.distributed.DistributedSampler(train_ds, num_replicas=dp.world_size, rank=dp.rank,
+                                                                  shuffle=True, seed=args.seed or 0)
+    loader_kw = dict(num_workers=args.num_workers, pin_memory=True, drop_last=False,
+                     persistent_workers=args.num_workers > 0)
+    train_loader = torch.utils.data.DataLoader(train_ds, batch_size=per_rank_bs, shuffle=sampler is None, sampler=sampler, **loader_kw)
+    test_loader = torch.utils.data.DataLoader(test_ds, batch_size=per_rank_bs, shuffle=False, **loader_kw)
+    args.dataset_size = len(train_ds)
+    net = get_network(input_size, num_channels=3, args=args, device=device).to(device)
+    args.total_params = net.total_trainable_params()
+    for name, w in net.lambda_weights.items():
+        setattr(args, f"{name}_weight", w)
+    if dp is not None:
+        dp.attach(net)
+    optimizer = make_optimizer(net, args)
+    scheduler = make_scheduler(optimizer, args)
+    aggregator = aggregation.make_aggregator(args)
+    if aggregator is not None and aggregator != "sum":
+        aggregator.weighting.register_forward_hook(print_weights)
+        aggregator.weighting.register_forward_hook(print_gd_similarity)
+    rank0 = dp is None or dp.rank == 0
+    stamp = time.strftime("%Y%m%d_%H%M%S")
+    save_root = os.path.join(args.save_path, args.dataset, args.arch, args.optimizer, args.aggregator, stamp)
+    if rank0:
+        os.makedirs(os.path.join(save_root, "checkpoints"), exist_ok=True)
+    log = None
+    if args.use_wandb:
+        try:
+            import wandb
+
+            wandb.init(project=args.wandb_project, entity=args.wandb_entity, name=args.wandb_name, config=vars(args),
+                       dir=save_root, group=args.wandb_group, tags=args.wandb_tags)
+            log = lambda rec, step: wandb.log(rec, step=step)  # noqa: E731
+        except ImportError:
+            print("wandb is not installed; continuing without it")
+    if hasattr(net, "print_model_summary") and args.device.endswith("0") and rank0:
+        net.print_model_summary()
+    step, history, best = 0, [], float("inf")
+    for epoch in range(1, args.epochs + 1):
+        if sampler is not None:
+            sampler.set_epoch(epoch)
+        t0 = time.time()
+        meters, step = train_epoch(net, train_loader, optimizer, aggregator, step, device, args, dp, log)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        rec = {k: m.avg for k, m in meters.items()}
+        history.append(rec)
+        if rank0:
+            n_img = len(train_ds)
+            print(f"epoch {epoch}: " + ", ".join(f"{k}: {v:.6e}" for k, v in rec.items()) + f"  [{n_img / dt:.0f} img/s]")
+        if args.eval_freq and epoch % args.eval_freq == 0:
+            ev = evaluate(net, test_loader, device, args)
+            best = min(best, ev["total_loss"].avg)
+            if rank0:
+                print(f"  eval: " + ", ".join(f"{k}: {m.avg:.6e}" for k, m in ev.items()))
+        if scheduler is not None:
+            scheduler.step()
+        if args.max_steps is not None and step >= args.max_steps:
+            break
+    if rank0:  # main.py:1422-1436: save-only checkpoint with the reference's keys
+        ckpt = {"epoch": epoch, "model_state_dict": {k: v.contiguous() for k, v in net.state_dict().items()},
+                "args": vars(args), "train_losses": history, "best_eval_loss": best}
+        if scheduler is not None:
+            ckpt["scheduler_state_dict"] = scheduler.state_dict()
+        torch.save(ckpt, os.path.join(save_root, "checkpoints", "final_checkpoint.pth"))
+    if dp is not None:
+        dp.shutdown()
+    return history
+
+
+def cli(argv=None):
+    args = parse_args(argv)
+    if args.seed is not None:
+        set_seed(args.seed)
+    return main(args)

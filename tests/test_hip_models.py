@@ -92,7 +92,9 @@ def test_forward_losses_sum_backward_and_adam(tag, gpu_device):
     net.eval()
     with torch.no_grad():
         oe = net(x)
-    assert_close(oe["recons"], fx["eval.recons"], "eval recons", rtol=2e-3, atol=1e-4)
+    # eval mode exposes the conv biases in front of BatchNorm, whose Adam update is +-lr rounding noise in the
+    # reference itself (see test_oracle_golden): 5e-3 absolute for the BN models, tight otherwise
+    assert_close(oe["recons"], fx["eval.recons"], "eval recons", rtol=2e-3, atol=5e-3 if tag.startswith("vae") else 1e-4)
 
 
 @pytest.mark.parametrize("tag", ["vae_tiny", "vq_vae_tiny", "betatc_vae_tiny", "vq_vae2_tiny"])
@@ -213,3 +215,45 @@ def test_full_size_configs_step0(tag, gpu_device):
         if not np.isclose(got, l2, rtol=2e-2, atol=1e-6):
             bad.append((n, got, l2))
     assert not bad, bad
+
+
+def test_hipgraph_replay_matches_eager_steps(gpu_device):
+    """GraphedTrainStep (one captured hipGraph per step) must reproduce the eager loop: same losses and the
+    same parameters after several Adam steps on changing batches."""
+    import movae_amd  # noqa: F401
+    from movae_amd import aggregation
+    from movae_amd.models import get_network
+    from movae_amd.train import GraphedTrainStep, make_optimizer, train_step
+
+    def make():
+        a = Args(arch="vae", batch_size=16, dataset_size=1000, latent_dim=16, hidden_dims=[16, 32, 64], recons_objective="mse",
+                 recons_activation=None, loss_weights=None, aggregator="upgrad", agg_norm_eps=1e-4, agg_reg_eps=1e-4,
+                 mgda_epsilon=1e-5, mgda_max_iters=250, pref_weights=None, optimizer="adam", lr=1e-3, wd=0, momentum=0.9,
+                 max_grad_norm=None)
+        torch.manual_seed(3)
+        net = get_network(32, 3, a, gpu_device).to(gpu_device).train()
+        net.eps_override = torch.randn(16, 16, generator=torch.Generator().manual_seed(5)).to(gpu_device)
+        return net, a
+
+    g = torch.Generator().manual_seed(11)
+    batches = [torch.rand(16, 3, 32, 32, generator=g).to(gpu_device) for _ in range(4)]
+    net_e, a = make()
+    opt_e = make_optimizer(net_e, a, capturable=True)
+    agg_e = aggregation.make_aggregator(a)
+    # the graphed twin performs 3 warm-up steps + 1 capture step on batches[0] before the first replay
+    for _ in range(4):
+        train_step(net_e, batches[0], opt_e, agg_e, a)
+    eager_losses = []
+    for b in batches:
+        ld, _ = train_step(net_e, b, opt_e, agg_e, a)
+        eager_losses.append(ld["total_loss"].item())
+    net_g, a2 = make()
+    opt_g = make_optimizer(net_g, a2, capturable=True)
+    gs = GraphedTrainStep(net_g, opt_g, aggregation.make_aggregator(a2), a2, batches[0])
+    graph_losses = []
+    for b in batches:
+        ld, _ = gs.step(b)
+        graph_losses.append(ld["total_loss"].item())
+    np.testing.assert_allclose(graph_losses, eager_losses, rtol=1e-5)
+    for (n, p), (_, q) in zip(net_e.named_parameters(), net_g.named_parameters()):
+        np.testing.assert_allclose(q.detach().cpu().numpy(), p.detach().cpu().numpy(), rtol=1e-4, atol=1e-6, err_msg=n)
