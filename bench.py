@@ -117,17 +117,53 @@ def measure_dominant_kernel(recorded, device, reps=20):
 
     lib = L.load()
     rows = []
-    stream = torch.cuda.current_stream(device)
-    for name, a in recorded:
+    ws = L.workspace(device)
+
+    def synth(name, a):
+        """Fresh, owned operand buffers of the recorded call's geometry (the step's own activations are
+        recycled by the caching allocator, so their recorded addresses must not be reused)."""
+        off = 4 if name.endswith("_fwd") or name.endswith("_wgrad") else 3
+        n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad = a[off: off + 11]
+        x = torch.randn(n * hi * wi * ci, device=device)
+        y = torch.randn(n * ho * wo * co, device=device)
+        w = torch.randn(co * kh * kw * ci, device=device) * 0.05
+        b = torch.randn(co, device=device)
+        geom = (n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad)
+        tail = (ws.data_ptr(), ws.numel())
+        if name.endswith("_fwd"):
+            args = (x.data_ptr(), w.data_ptr(), b.data_ptr() if a[2] else 0, y.data_ptr()) + geom + (a[15], a[16]) + tail
+        elif name.endswith("_dgrad"):
+            args = (y.data_ptr(), w.data_ptr(), x.data_ptr()) + geom + tail
+        else:
+            args = (y.data_ptr(), x.data_ptr(), w.data_ptr(), b.data_ptr() if a[3] else 0) + geom + (0,) + tail
+        return args, (x, y, w, b)
+
+    for name, rec in recorded:
         if name not in CONV_CALLS:
             continue
         fn = getattr(lib, name)
-        for _ in range(3):
-            fn(*a)
+        a0, keep = synth(name, rec)
+        a = a0 + (0,)
+        # the launches are captured into a hipGraph first so that the timed interval contains device work
+        # only (a Python/ctypes launch costs more host time than these kernels run for)
+        side = torch.cuda.Stream(device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            a_side = a[:-1] + (side.cuda_stream,)
+            for _ in range(2):
+                fn(*a_side)
+        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            a_cap = a[:-1] + (torch.cuda.current_stream(device).cuda_stream,)
+            for _ in range(reps):
+                fn(*a_cap)
+        graph.replay()
+        stream = torch.cuda.current_stream(device)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
-        for _ in range(reps):
-            fn(*a)
+        graph.replay()
         e1.record(stream)
         e1.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / reps

@@ -35,7 +35,8 @@ def _digest(paths):
 def build(force=False, verbose=True):
     os.makedirs(BUILD, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "movae.h")]
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    headers.append(os.path.join(HERE, "..", "include", "movae.h"))
     objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)

@@ -527,6 +527,8 @@ inline int choose_split(long tiles, int nk, size_t per_slab_bytes, size_t ws_byt
 // ------------------------------------------------------------------------------------------------
 // host dispatch
 // ------------------------------------------------------------------------------------------------
+#include "igemm_v2.h"
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <int BM, int BN>
@@ -561,6 +563,11 @@ int launch_fwd(const float* X, const float* W, float* Y, const Geom& g, const Ep
         return MOVAE_EINVAL;
     }
     const int M = (int)Ml, K = (int)Kl;
+    if (g.Cr % 4 == 0 && aligned16(X) && aligned16(W)) {  // fast path (igemm_v2.h)
+        if (g.Nn <= 32) return v2::launch_fwd2<128, 32>(X, W, Y, g, ep, M, K, ws, ws_bytes, st);
+        if (Ml >= 128 * 512) return v2::launch_fwd2<128, 64>(X, W, Y, g, ep, M, K, ws, ws_bytes, st);
+        return v2::launch_fwd2<64, 64>(X, W, Y, g, ep, M, K, ws, ws_bytes, st);
+    }
     const bool vec = (g.Cr % BK == 0) && aligned16(X) && aligned16(W);
     if (g.Nn <= 32) return launch_fwd_t<128, 32>(X, W, Y, g, ep, M, K, vec, ws, ws_bytes, st);
     if (Ml >= 128 * 512) return launch_fwd_t<128, 64>(X, W, Y, g, ep, M, K, vec, ws, ws_bytes, st);
@@ -598,8 +605,13 @@ int launch_bwd(const float* X, const float* W, float* Y, const Geom& g, const Ep
         movae_set_error("conv bwd-form: bad shape M=%ld N=%d Cr=%d", Ml, g.Nn, g.Cr);
         return MOVAE_EINVAL;
     }
-    const bool vec = (g.Cr % BK == 0) && (g.Nn % 4 == 0) && aligned16(X) && aligned16(W);
     const long Mc = Ml / (g.stride * g.stride);
+    if (g.Cr % 4 == 0 && g.Nn % 4 == 0 && aligned16(X) && aligned16(W)) {  // fast path (igemm_v2.h)
+        if (g.Nn <= 32) return v2::launch_bwd2<128, 32>(X, W, Y, g, ep, ws, ws_bytes, st);
+        if (Mc >= 128 * 512) return v2::launch_bwd2<128, 64>(X, W, Y, g, ep, ws, ws_bytes, st);
+        return v2::launch_bwd2<64, 64>(X, W, Y, g, ep, ws, ws_bytes, st);
+    }
+    const bool vec = (g.Cr % BK == 0) && (g.Nn % 4 == 0) && aligned16(X) && aligned16(W);
     if (g.Nn <= 32) return launch_bwd_t<128, 32>(X, W, Y, g, ep, vec, ws, ws_bytes, st);
     if (Mc >= 128 * 512) return launch_bwd_t<128, 64>(X, W, Y, g, ep, vec, ws, ws_bytes, st);
     return launch_bwd_t<64, 64>(X, W, Y, g, ep, vec, ws, ws_bytes, st);
@@ -647,6 +659,10 @@ int launch_wgrad(const float* S, const float* Bg, float* dW, const WGeom& g, int
     }
     const int vec = ((g.Cs % 4 == 0 && aligned16(S)) ? 1 : 0) | ((g.Cb % 4 == 0 && aligned16(Bg)) ? 2 : 0);
     const int N = g.KH * g.KW * g.Cb;
+    if (vec == 3) {  // fast path (igemm_v2.h)
+        if (N <= 32) return v2::launch_wgrad2<128, 32>(S, Bg, dW, g, (int)Kl, accumulate, ws, ws_bytes, st);
+        return v2::launch_wgrad2<64, 64>(S, Bg, dW, g, (int)Kl, accumulate, ws, ws_bytes, st);
+    }
     if (N <= 32) return launch_wgrad_t<128, 32>(S, Bg, dW, g, (int)Kl, vec, accumulate, ws, ws_bytes, st);
     return launch_wgrad_t<64, 64>(S, Bg, dW, g, (int)Kl, vec, accumulate, ws, ws_bytes, st);
 }

@@ -1,0 +1,430 @@
+// igemm_v2.h -- the fast implicit-GEMM path (included inside conv_igemm.hip's anonymous namespace).
+//
+// Same three gather forms as the v1 kernels, restricted to 4-float-aligned reduction / output
+// channels (every layer of the hot path except the 3-channel image ends), and built for latency:
+//   * BK = 32 per stage: 16 v_mfma_f32_32x32x2_f32 per wave tile between barriers (1024 MFMA cycles to
+//     cover the next stage's global loads, which are issued before the MFMAs);
+//   * every global access is a 16-byte load along the operand's contiguous axis (k for gathered
+//     activations and [n][k] weights, n for [k][n] weights / wgrad operands) and goes to LDS with one
+//     ds_write_b128 -- no transposing stores;
+//   * k-contiguous operands live row-major [row][BK+4] in LDS and are read with ds_read_b128 (4 MFMA
+//     operands per read, stride 36 floats => conflict-free 16-lane groups); n-contiguous operands live
+//     k-major [BK][cols+4] and are read with conflict-free ds_read_b32.
+//   MFMA k assignment: lane half h consumes k = 16h + j at step j (both operands agree, so the
+//   contraction is unchanged).
+#pragma once
+
+namespace v2 {
+
+constexpr int BK2 = 32;
+constexpr int HK = BK2 / 2;
+constexpr int LDR = BK2 + 4;  // row-major leading dimension
+
+template <int BM, int BN>
+struct T2 {
+    static constexpr int WN = BN / 32;
+    static constexpr int WM = 4 / WN;
+    static constexpr int TM = BM / (WM * 32);
+    static constexpr int LDKA = BM + 4;  // k-major leading dims
+    static constexpr int LDKB = BN + 4;
+    static_assert(TM >= 1, "tile");
+};
+
+// A row-major, B row-major (FWD)
+template <int TM>
+__device__ __forceinline__ void mma_rr(const float* __restrict__ As, const float* __restrict__ Bs, int a_row, int b_row,
+                                       f32x16 (&acc)[TM]) {
+    const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int jj = 0; jj < HK / 4; ++jj) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(Bs + (b_row + l31) * LDR + half * HK + jj * 4);
+        f32x4 a4[TM];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+            a4[tm] = *reinterpret_cast<const f32x4*>(As + (a_row + tm * 32 + l31) * LDR + half * HK + jj * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[tm][e], b4[e], acc[tm], 0, 0, 0);
+    }
+}
+
+// A row-major, B k-major (BWD)
+template <int TM>
+__device__ __forceinline__ void mma_rk(const float* __restrict__ As, const float* __restrict__ Bs, int ldb, int a_row,
+                                       int b_col, f32x16 (&acc)[TM]) {
+    const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int jj = 0; jj < HK / 4; ++jj) {
+        f32x4 a4[TM];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+            a4[tm] = *reinterpret_cast<const f32x4*>(As + (a_row + tm * 32 + l31) * LDR + half * HK + jj * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float b = Bs[(half * HK + jj * 4 + e) * ldb + b_col + l31];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[tm][e], b, acc[tm], 0, 0, 0);
+        }
+    }
+}
+
+// A k-major, B k-major (WGRAD)
+template <int TM>
+__device__ __forceinline__ void mma_kk(const float* __restrict__ As, const float* __restrict__ Bs, int lda, int ldb,
+                                       int a_col, int b_col, f32x16 (&acc)[TM]) {
+    const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int j = 0; j < HK; ++j) {
+        const float b = Bs[(half * HK + j) * ldb + b_col + l31];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const float a = As[(half * HK + j) * lda + a_col + tm * 32 + l31];
+            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[tm], 0, 0, 0);
+        }
+    }
+}
+
+#define ZERO4 (f32x4{0.f, 0.f, 0.f, 0.f})
+
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void igemm2_fwd(const float* __restrict__ X, const float* __restrict__ W,
+                                                  float* __restrict__ Y, Geom g, Epilogue ep, int M, int K,
+                                                  int ktiles_per_split, float* __restrict__ slab) {
+    using T = T2<BM, BN>;
+    __shared__ __attribute__((aligned(16))) float As[BM * LDR];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * LDR];
+    const int t = threadIdx.x;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int N = g.Nn;
+    constexpr int AC = BM / 32, BC = BN / 32;  // 16-byte chunks per thread (8 chunks per row, 256 threads)
+    const int kq = t & 7, r8 = t >> 3;
+
+    const float* a_base[AC];
+    int a_h0[AC], a_w0[AC];
+    bool a_ok[AC];
+#pragma unroll
+    for (int i = 0; i < AC; ++i) {
+        const int m = m0 + r8 + 32 * i;
+        a_ok[i] = m < M;
+        const int mm = a_ok[i] ? m : 0;
+        const int hw = g.Ho * g.Wo;
+        const int img = mm / hw, rem = mm - img * hw;
+        const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
+        a_h0[i] = ho * g.stride - g.pad;
+        a_w0[i] = wo * g.stride - g.pad;
+        a_base[i] = X + (long)img * g.Hi * g.Wi * g.Cr;
+    }
+    const float* b_base[BC];
+    bool b_ok[BC];
+#pragma unroll
+    for (int i = 0; i < BC; ++i) {
+        const int n = n0 + r8 + 32 * i;
+        b_ok[i] = n < N;
+        b_base[i] = W + (long)(b_ok[i] ? n : 0) * K;
+    }
+    const int nk_total = (K + BK2 - 1) / BK2;
+    const int kt_begin = blockIdx.z * ktiles_per_split;
+    const int kt_end = min(nk_total, kt_begin + ktiles_per_split);
+
+    f32x4 ra[AC], rb[BC];
+    auto load_tile = [&](int kt) {
+        const int k = kt * BK2 + kq * 4;
+        const bool kv = k < K;
+        const int kk = kv ? k : 0;
+        const int tap = kk / g.Cr, c = kk - tap * g.Cr;
+        const int kh = tap / g.KW, kw = tap - kh * g.KW;
+#pragma unroll
+        for (int i = 0; i < AC; ++i) {
+            const int h = a_h0[i] + kh, w = a_w0[i] + kw;
+            const bool v = kv && a_ok[i] && h >= 0 && h < g.Hi && w >= 0 && w < g.Wi;
+            ra[i] = v ? *reinterpret_cast<const f32x4*>(a_base[i] + ((long)h * g.Wi + w) * g.Cr + c) : ZERO4;
+        }
+#pragma unroll
+        for (int i = 0; i < BC; ++i) rb[i] = (kv && b_ok[i]) ? *reinterpret_cast<const f32x4*>(b_base[i] + kk) : ZERO4;
+    };
+
+    f32x16 acc[T::TM];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const int wave = t >> 6, wm = wave / T::WN, wn = wave % T::WN;
+    if (kt_begin < kt_end) load_tile(kt_begin);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < AC; ++i) *reinterpret_cast<f32x4*>(As + (r8 + 32 * i) * LDR + kq * 4) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BC; ++i) *reinterpret_cast<f32x4*>(Bs + (r8 + 32 * i) * LDR + kq * 4) = rb[i];
+        __syncthreads();
+        if (kt + 1 < kt_end) load_tile(kt + 1);
+        mma_rr<T::TM>(As, Bs, wm * T::TM * 32, wn * 32, acc);
+    }
+
+    const int lane = t & 63, half = lane >> 5, l31 = lane & 31;
+    const int n = n0 + wn * 32 + l31;
+    if (n >= N) return;
+    const bool to_slab = slab != nullptr;
+    const float bv = (!to_slab && ep.bias) ? ep.bias[n] : 0.f;
+    float* out = to_slab ? slab + (long)blockIdx.z * M * N : Y;
+#pragma unroll
+    for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * T::TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m < M) out[(long)m * N + n] = to_slab ? acc[tm][r] : apply_act(acc[tm][r] + bv, ep.act, ep.slope);
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void igemm2_bwd(const float* __restrict__ X, const float* __restrict__ W,
+                                                  float* __restrict__ Y, Geom g, Epilogue ep, int S, int ktiles_per_split,
+                                                  float* __restrict__ slab, long total) {
+    using T = T2<BM, BN>;
+    __shared__ __attribute__((aligned(16))) float As[BM * LDR];
+    __shared__ __attribute__((aligned(16))) float Bs[BK2 * T::LDKB];
+    const int t = threadIdx.x;
+    const int s = g.stride;
+    const int cls = blockIdx.z / S, split = blockIdx.z - cls * S;
+    const int ph = cls / s, pw = cls % s;
+    const int Hoc = (g.Ho - ph + s - 1) / s, Woc = (g.Wo - pw + s - 1) / s;
+    const int M = g.Nimg * Hoc * Woc;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    if (m0 >= M) return;
+    const int N = g.Nn;
+    const int kh0 = (ph + g.pad) % s, kw0 = (pw + g.pad) % s;
+    const int nA = kh0 < g.KH ? (g.KH - kh0 + s - 1) / s : 0;
+    const int nB = kw0 < g.KW ? (g.KW - kw0 + s - 1) / s : 0;
+    const int qh = (ph + g.pad - kh0) / s, qw = (pw + g.pad - kw0) / s;
+    const int K = nA * nB * g.Cr;
+    const int taps = g.KH * g.KW;
+    const int nBd = nB > 0 ? nB : 1;
+
+    constexpr int AC = BM / 32;
+    const int kq = t & 7, r8 = t >> 3;
+    const float* a_base[AC];
+    int a_h0[AC], a_w0[AC];
+    bool a_ok[AC];
+#pragma unroll
+    for (int i = 0; i < AC; ++i) {
+        const int m = m0 + r8 + 32 * i;
+        a_ok[i] = m < M;
+        const int mm = a_ok[i] ? m : 0;
+        const int hw = Hoc * Woc;
+        const int img = mm / hw, rem = mm - img * hw;
+        const int hc = rem / Woc, wc = rem - hc * Woc;
+        a_h0[i] = hc + qh;
+        a_w0[i] = wc + qw;
+        a_base[i] = X + (long)img * g.Hi * g.Wi * g.Cr;
+    }
+    constexpr int BQ = BN / 4;              // 16-byte chunks per k-row
+    constexpr int BC = BK2 * BQ / 256;      // chunks per thread (2 for BN=64, 1 for BN=32)
+    constexpr int KSTEP = 256 / BQ;         // k-rows covered per pass
+    const int bq = t % BQ, bk = t / BQ;
+    const int bn = n0 + bq * 4;
+    const bool bn_ok = bn < N;              // N % 4 == 0 on this path
+
+    f32x4 ra[AC], rb[BC];
+    auto load_tile = [&](int kt) {
+        {
+            const int k = kt * BK2 + kq * 4;
+            const bool kv = k < K;
+            const int kk = kv ? k : 0;
+            const int tt = kk / g.Cr, c = kk - tt * g.Cr;
+            const int a = tt / nBd, b = tt - a * nBd;
+#pragma unroll
+            for (int i = 0; i < AC; ++i) {
+                const int h = a_h0[i] - a, w = a_w0[i] - b;
+                const bool v = kv && a_ok[i] && h >= 0 && h < g.Hi && w >= 0 && w < g.Wi;
+                ra[i] = v ? *reinterpret_cast<const f32x4*>(a_base[i] + ((long)h * g.Wi + w) * g.Cr + c) : ZERO4;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BC; ++i) {
+            const int k = kt * BK2 + bk + KSTEP * i;
+            const bool kv = k < K && bn_ok;
+            const int kk = k < K ? k : 0;
+            const int tt = kk / g.Cr, c = kk - tt * g.Cr;
+            const int a = tt / nBd, b = tt - a * nBd;
+            const int kh = kh0 + s * a, kw = kw0 + s * b;
+            rb[i] = kv ? *reinterpret_cast<const f32x4*>(W + ((long)c * taps + kh * g.KW + kw) * N + bn) : ZERO4;
+        }
+    };
+
+    f32x16 acc[T::TM];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const int wave = t >> 6, wm = wave / T::WN, wn = wave % T::WN;
+    const int nk_total = (K + BK2 - 1) / BK2;
+    const int kt_begin = split * ktiles_per_split;
+    const int kt_end = min(nk_total, kt_begin + ktiles_per_split);
+    if (kt_begin < kt_end) load_tile(kt_begin);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < AC; ++i) *reinterpret_cast<f32x4*>(As + (r8 + 32 * i) * LDR + kq * 4) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BC; ++i) *reinterpret_cast<f32x4*>(Bs + (bk + KSTEP * i) * T::LDKB + bq * 4) = rb[i];
+        __syncthreads();
+        if (kt + 1 < kt_end) load_tile(kt + 1);
+        mma_rk<T::TM>(As, Bs, T::LDKB, wm * T::TM * 32, wn * 32, acc);
+    }
+
+    const int lane = t & 63, half = lane >> 5, l31 = lane & 31;
+    const int n = n0 + wn * 32 + l31;
+    if (n >= N) return;
+    const bool to_slab = slab != nullptr;
+    const float bv = (!to_slab && ep.bias) ? ep.bias[n] : 0.f;
+    float* out = to_slab ? slab + (long)split * total : Y;
+#pragma unroll
+    for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * T::TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m < M) {
+                const int hw = Hoc * Woc;
+                const int img = m / hw, rem = m - img * hw;
+                const int hc = rem / Woc, wc = rem - hc * Woc;
+                const long p = ((long)img * g.Ho + (hc * s + ph)) * g.Wo + (wc * s + pw);
+                out[p * N + n] = to_slab ? acc[tm][r] : apply_act(acc[tm][r] + bv, ep.act, ep.slope);
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void igemm2_wgrad(const float* __restrict__ Sm, const float* __restrict__ Bg,
+                                                    float* __restrict__ out, WGeom g, int K, int kchunk, int to_slab) {
+    using T = T2<BM, BN>;
+    __shared__ __attribute__((aligned(16))) float As[BK2 * T::LDKA];
+    __shared__ __attribute__((aligned(16))) float Bs[BK2 * T::LDKB];
+    const int t = threadIdx.x;
+    const int M = g.Cs, N = g.KH * g.KW * g.Cb;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int k_begin = blockIdx.z * kchunk, k_end = min(K, k_begin + kchunk);
+    constexpr int AQ = BM / 4, BQ = BN / 4;
+    constexpr int ACH = BK2 * AQ / 256, BCH = BK2 * BQ / 256;
+    constexpr int AKS = 256 / AQ, BKS = 256 / BQ;
+    const int aq = t % AQ, ak = t / AQ;
+    const int bq = t % BQ, bk = t / BQ;
+    const int am = m0 + aq * 4;
+    const bool am_ok = am < M;  // M % 4 == 0 on this path
+    const int bn = n0 + bq * 4;
+    const bool bn_ok = bn < N;  // Cb % 4 == 0 => the 4 columns share one tap
+    const int b_tap = (bn_ok ? bn : 0) / g.Cb, b_c = (bn_ok ? bn : 0) - b_tap * g.Cb;
+    const int b_kh = b_tap / g.KW, b_kw = b_tap - b_kh * g.KW;
+    const int hw = g.Hs * g.Ws;
+
+    f32x4 ra[ACH], rb[BCH];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            const int k = k0 + ak + AKS * i;
+            ra[i] = (k < k_end && am_ok) ? *reinterpret_cast<const f32x4*>(Sm + (long)k * M + am) : ZERO4;
+        }
+#pragma unroll
+        for (int i = 0; i < BCH; ++i) {
+            const int k = k0 + bk + BKS * i;
+            const bool kv = k < k_end && bn_ok;
+            const int kk = k < k_end ? k : k_begin;
+            const int img = kk / hw, rem = kk - img * hw;
+            const int hs = rem / g.Ws, ws = rem - hs * g.Ws;
+            const int h = hs * g.stride - g.pad + b_kh, w = ws * g.stride - g.pad + b_kw;
+            const bool v = kv && h >= 0 && h < g.Hb && w >= 0 && w < g.Wb;
+            rb[i] = v ? *reinterpret_cast<const f32x4*>(Bg + (((long)img * g.Hb + h) * g.Wb + w) * g.Cb + b_c) : ZERO4;
+        }
+    };
+
+    f32x16 acc[T::TM];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const int wave = t >> 6, wm = wave / T::WN, wn = wave % T::WN;
+    if (k_begin < k_end) load_tile(k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += BK2) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) *reinterpret_cast<f32x4*>(As + (ak + AKS * i) * T::LDKA + aq * 4) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BCH; ++i) *reinterpret_cast<f32x4*>(Bs + (bk + BKS * i) * T::LDKB + bq * 4) = rb[i];
+        __syncthreads();
+        if (k0 + BK2 < k_end) load_tile(k0 + BK2);
+        mma_kk<T::TM>(As, Bs, T::LDKA, T::LDKB, wm * T::TM * 32, wn * 32, acc);
+    }
+
+    const int lane = t & 63, half = lane >> 5, l31 = lane & 31;
+    const int n = n0 + wn * 32 + l31;
+    if (n >= N) return;
+    float* dst = to_slab ? out + (long)blockIdx.z * M * N : out;
+#pragma unroll
+    for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * T::TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m < M) dst[(long)m * N + n] = acc[tm][r];
+        }
+}
+
+#undef ZERO4
+
+// ---- host side ------------------------------------------------------------------------------------
+template <int BM, int BN>
+int launch_fwd2(const float* X, const float* W, float* Y, const Geom& g, const Epilogue& ep, int M, int K, void* ws,
+                size_t ws_bytes, hipStream_t st) {
+    const int gx = ceil_div(M, BM), gy = ceil_div(g.Nn, BN);
+    const int nk = ceil_div(K, BK2);
+    int S = choose_split((long)gx * gy, nk, (size_t)M * g.Nn * sizeof(float), ws_bytes, ws != nullptr);
+    const int per_split = ceil_div(nk, S);
+    S = ceil_div(nk, per_split);
+    float* slab = S > 1 ? static_cast<float*>(ws) : nullptr;
+    hipLaunchKernelGGL((igemm2_fwd<BM, BN>), dim3(gx, gy, S), dim3(256), 0, st, X, W, Y, g, ep, M, K, per_split, slab);
+    MOVAE_CHECK_LAUNCH("igemm2_fwd");
+    if (S > 1) return launch_reduce(slab, Y, (long)M * g.Nn, S, g.Nn, ep.bias, ep.act, ep.slope, 0, st);
+    return MOVAE_OK;
+}
+
+template <int BM, int BN>
+int launch_bwd2(const float* X, const float* W, float* Y, const Geom& g, const Epilogue& ep, void* ws, size_t ws_bytes,
+                hipStream_t st) {
+    const int s = g.stride;
+    const long Mmax = (long)g.Nimg * ceil_div(g.Ho, s) * ceil_div(g.Wo, s);
+    const int gx = ceil_div(Mmax, BM), gy = ceil_div(g.Nn, BN);
+    const int nk_max = ceil_div((long)ceil_div(g.KH, s) * ceil_div(g.KW, s) * g.Cr, BK2);
+    const long total = (long)g.Nimg * g.Ho * g.Wo * g.Nn;
+    int S = choose_split((long)gx * gy * s * s, nk_max, (size_t)total * sizeof(float), ws_bytes, ws != nullptr);
+    const int per_split = ceil_div(nk_max, S);
+    S = ceil_div(nk_max, per_split);
+    float* slab = S > 1 ? static_cast<float*>(ws) : nullptr;
+    hipLaunchKernelGGL((igemm2_bwd<BM, BN>), dim3(gx, gy, s * s * S), dim3(256), 0, st, X, W, Y, g, ep, S, per_split, slab, total);
+    MOVAE_CHECK_LAUNCH("igemm2_bwd");
+    if (S > 1) return launch_reduce(slab, Y, total, S, g.Nn, ep.bias, ep.act, ep.slope, 0, st);
+    return MOVAE_OK;
+}
+
+template <int BM, int BN>
+int launch_wgrad2(const float* Sm, const float* Bg, float* dW, const WGeom& g, int K, int accumulate, void* ws, size_t ws_bytes,
+                  hipStream_t st) {
+    const int M = g.Cs, N = g.KH * g.KW * g.Cb;
+    const int gx = ceil_div(M, BM), gy = ceil_div(N, BN);
+    int Sp = choose_split((long)gx * gy, ceil_div(K, BK2), (size_t)M * N * sizeof(float), ws_bytes, ws != nullptr);
+    const int kchunk = ceil_div(ceil_div(K, Sp), BK2) * BK2;
+    Sp = ceil_div(K, kchunk);
+    const bool slab = Sp > 1 || accumulate;
+    if (slab && (!ws || (size_t)M * N * sizeof(float) * Sp > ws_bytes)) {
+        movae_set_error("wgrad: workspace too small (%zu bytes) for %d splits of %dx%d", ws_bytes, Sp, M, N);
+        return MOVAE_EINVAL;
+    }
+    float* out = slab ? static_cast<float*>(ws) : dW;
+    hipLaunchKernelGGL((igemm2_wgrad<BM, BN>), dim3(gx, gy, Sp), dim3(256), 0, st, Sm, Bg, out, g, K, kchunk, slab ? 1 : 0);
+    MOVAE_CHECK_LAUNCH("igemm2_wgrad");
+    if (slab) return launch_reduce(out, dW, (long)M * N, Sp, N, nullptr, 0, 0.f, accumulate, st);
+    return MOVAE_OK;
+}
+
+}  // namespace v2

@@ -240,8 +240,9 @@ def test_hipgraph_replay_matches_eager_steps(gpu_device):
     net_e, a = make()
     opt_e = make_optimizer(net_e, a, capturable=True)
     agg_e = aggregation.make_aggregator(a)
-    # the graphed twin performs 3 warm-up steps + 1 capture step on batches[0] before the first replay
-    for _ in range(4):
+    # the graphed twin performs 3 real warm-up steps on batches[0] before the first replay (the capture
+    # pass itself only records launches, it does not execute them)
+    for _ in range(3):
         train_step(net_e, batches[0], opt_e, agg_e, a)
     eager_losses = []
     for b in batches:
