@@ -196,7 +196,7 @@ def main():
         print(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}", file=sys.stderr)
         sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    device = torch.device(f"cuda:{local_rank}")
+    device = torch.device(f"cuda:{local_rank % torch.cuda.device_count()}")
     torch.cuda.set_device(device)
 
     import movae_amd  # noqa: F401
@@ -206,12 +206,25 @@ def main():
 
     from movae_amd.train import GRAPH_SAFE_ARCHS, GraphedTrainStep
 
-    dp = DataParallelGrads.from_env() if world > 1 else None
-    use_graph = args.graph == "on" or (args.graph == "auto" and world == 1 and cfg["arch"] == "vae")
+    dp = DataParallelGrads.from_env() if (world > 1 or os.environ.get("MOVAE_FORCE_DP")) else None
+    use_graph = args.graph == "on" or (args.graph == "auto" and cfg["arch"] == "vae")
     net, opt, agg, a, pool = build_workload(cfg, device, capturable=use_graph)
     if dp is not None:
         dp.attach(net)
-    graphed = GraphedTrainStep(net, opt, agg, a, pool[0]) if use_graph else None
+    graphed = GraphedTrainStep(net, opt, agg, a, pool[0], dp=dp) if use_graph else None
+    if graphed is not None and dp is not None:
+        # watchdog: if graph replay + collective misbehaves on this node (observed when several ranks share one
+        # GPU under gloo), every rank falls back to the eager step together
+        torch.cuda.synchronize()
+        dp.barrier()
+        t_probe = time.perf_counter()
+        for i in range(4):
+            graphed.step(pool[i % len(pool)])
+        torch.cuda.synchronize()
+        probe = torch.tensor([(time.perf_counter() - t_probe) / 4], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(probe, op=torch.distributed.ReduceOp.MAX)
+        if float(probe.item()) > 0.05:  # a healthy replay step is ~3 ms
+            graphed, use_graph = None, False
 
     def step(i, eager=False):
         if graphed is not None and not eager:

@@ -13,6 +13,8 @@ features (e.g. VQ embedding_loss) costs no backward pass -- its row is simply le
 """
 import torch
 
+from . import ops
+
 
 def _leaf_tensors(roots, excluded=()):
     stop = {t.grad_fn for t in excluded if t.grad_fn is not None}
@@ -75,11 +77,18 @@ class JacobianBuffer:
     def J(self):
         return self.buf[:, : self.m]
 
+    def sinks(self, i):
+        """{param data_ptr: row slice}: lets the backward kernels write row i of J in place (ops.GRAD_SINK)."""
+        row = self.buf[i]
+        return {p.data_ptr(): row[off: off + p.numel()] for p, off in zip(self.params, self.offsets)}
+
     def write_row(self, i, grads):
         row = self.buf[i]
         for p, off, g in zip(self.params, self.offsets, grads):
             if g is not None:
-                row[off: off + p.numel()].copy_(_mem_flat(g))
+                dst = row[off: off + p.numel()]
+                if g.data_ptr() != dst.data_ptr():  # already written in place through the sink
+                    dst.copy_(_mem_flat(g))
 
 
 def _aggregate_into_grads(jb, aggregator):
@@ -115,8 +124,13 @@ def mtl_backward(losses, features, aggregator, tasks_params=None, shared_params=
         live = [(f, g) for f, g in zip(feat_diff, gf) if g is not None]
         if not live or not shared_params:
             continue  # no path from this loss to the shared parameters: zero Jacobian row
-        js = torch.autograd.grad([f for f, _ in live], shared_params, grad_outputs=[g for _, g in live],
-                                 retain_graph=True, allow_unused=True)
+        ops.GRAD_SINK.clear()
+        ops.GRAD_SINK.update(jb.sinks(i))
+        try:
+            js = torch.autograd.grad([f for f, _ in live], shared_params, grad_outputs=[g for _, g in live],
+                                     retain_graph=True, allow_unused=True)
+        finally:
+            ops.GRAD_SINK.clear()
         jb.write_row(i, js)
     if shared_params:
         _aggregate_into_grads(jb, aggregator)

@@ -198,9 +198,133 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ do
     }
 }
 
+// ---- 16-byte variants (C % 4 == 0): a thread owns one 4-channel quad, a wave reads 1 KiB contiguous ----
+struct Split4 {
+    int CQB, RG, rows_per_block, nblk;
+};
+
+inline Split4 make_split4(int rows, int c) {
+    Split4 s;
+    const int cq = c / 4;
+    s.CQB = pow2_ge(cq) < 256 ? pow2_ge(cq) : 256;
+    s.RG = 256 / s.CQB;
+    int rpb = ceil_div(rows, 1024);
+    rpb = ceil_div(rpb, s.RG) * s.RG;
+    if (rpb < s.RG * 8) rpb = s.RG * 8;
+    s.rows_per_block = rpb;
+    s.nblk = ceil_div(rows, rpb);
+    return s;
+}
+
+template <int NV>  // NV doubles per thread
+__device__ __forceinline__ void block_fold(double (&v)[NV], double* sh, int CQB, int RG, int cl, int rg) {
+    // sh: [NV][256]
+#pragma unroll
+    for (int q = 0; q < NV; ++q) sh[q * 256 + threadIdx.x] = v[q];
+    __syncthreads();
+    if (rg == 0) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            double s = v[q];
+            for (int i = 1; i < RG; ++i) s += sh[q * 256 + i * CQB + cl];
+            v[q] = s;
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void bn_stats_partial4(const float* __restrict__ y, double* __restrict__ part, int rows,
+                                                         int C, int CQB, int rows_per_block) {
+    __shared__ double sh[8 * 256];
+    const int t = threadIdx.x, RG = 256 / CQB, cl = t % CQB, rg = t / CQB, CQ = C / 4;
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min((long)rows, r0 + rows_per_block);
+    for (int cb = 0; cb < CQ; cb += CQB) {
+        const int cq = cb + cl;
+        double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (cq < CQ)
+            for (long r = r0 + rg; r < r1; r += RG) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(y + r * C + cq * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] += (double)x[j];
+                    v[4 + j] += (double)x[j] * (double)x[j];
+                }
+            }
+        block_fold<8>(v, sh, CQB, RG, cl, rg);
+        if (rg == 0 && cq < CQ)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                part[((long)blockIdx.x * C + cq * 4 + j) * 2 + 0] = v[j];
+                part[((long)blockIdx.x * C + cq * 4 + j) * 2 + 1] = v[4 + j];
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_partial4(const float* __restrict__ dout, const float* __restrict__ y,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       double* __restrict__ part, int rows, int C, int CQB,
+                                                       int rows_per_block, int act, float slope) {
+    __shared__ double sh[8 * 256];
+    const int t = threadIdx.x, RG = 256 / CQB, cl = t % CQB, rg = t / CQB, CQ = C / 4;
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min((long)rows, r0 + rows_per_block);
+    for (int cb = 0; cb < CQ; cb += CQB) {
+        const int cq = cb + cl;
+        double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (cq < CQ) {
+            const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + cq * 4), rs = *reinterpret_cast<const f32x4*>(rstd + cq * 4);
+            const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + cq * 4), be = *reinterpret_cast<const f32x4*>(beta + cq * 4);
+            for (long r = r0 + rg; r < r1; r += RG) {
+                const f32x4 yy = *reinterpret_cast<const f32x4*>(y + r * C + cq * 4);
+                const f32x4 go = *reinterpret_cast<const f32x4*>(dout + r * C + cq * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xh = (yy[j] - mu[j]) * rs[j];
+                    const float o = apply_act(xh * ga[j] + be[j], act, slope);
+                    const float dz = go[j] * act_grad_from_out(o, act, slope);
+                    v[j] += (double)dz;
+                    v[4 + j] += (double)dz * (double)xh;
+                }
+            }
+        }
+        block_fold<8>(v, sh, CQB, RG, cl, rg);
+        if (rg == 0 && cq < CQ)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                part[((long)blockIdx.x * C + cq * 4 + j) * 2 + 0] = v[j];
+                part[((long)blockIdx.x * C + cq * 4 + j) * 2 + 1] = v[4 + j];
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply4(const float* __restrict__ dout, const float* __restrict__ y,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ sums, float* __restrict__ dy, long total, int C,
+                                                     int act, float slope) {
+    const long stride = (long)gridDim.x * blockDim.x, nv = total / 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+        const int c = (int)((i * 4) % C);
+        const f32x4 yy = reinterpret_cast<const f32x4*>(y)[i], go = reinterpret_cast<const f32x4*>(dout)[i];
+        f32x4 o4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xh = (yy[j] - mean[c + j]) * rstd[c + j];
+            const float o = apply_act(xh * gamma[c + j] + beta[c + j], act, slope);
+            const float dz = go[j] * act_grad_from_out(o, act, slope);
+            o4[j] = gamma[c + j] * rstd[c + j] * (dz - sums[2 * (c + j)] - xh * sums[2 * (c + j) + 1]);
+        }
+        reinterpret_cast<f32x4*>(dy)[i] = o4;
+    }
+}
+
 inline int grid_for(long total) {
     long g = (total + 255) / 256;
     return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+
+inline bool al16(const void* a, const void* b = nullptr, const void* c = nullptr) {
+    return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
 }
 
 }  // namespace
@@ -209,8 +333,8 @@ extern "C" {
 
 size_t movae_bn_ws_bytes(int rows, int c) {
     if (rows <= 0 || c <= 0) return 0;
-    const Split s = make_split(rows, c);
-    return (size_t)s.nblk * c * 2 * sizeof(double) + (size_t)c * 2 * sizeof(float) + 64;
+    const int nblk = (c % 4 == 0) ? make_split4(rows, c).nblk : make_split(rows, c).nblk;
+    return (size_t)nblk * c * 2 * sizeof(double) + (size_t)c * 2 * sizeof(float) + 64;
 }
 
 int movae_bn_act_fwd(const float* y, const float* gamma, const float* beta, float* out, float* save_mean, float* save_rstd,
@@ -221,11 +345,19 @@ int movae_bn_act_fwd(const float* y, const float* gamma, const float* beta, floa
     hipStream_t st = (hipStream_t)stream;
     if (training) {
         MOVAE_CHECK_ARG(ws && ws_bytes >= movae_bn_ws_bytes(rows, c), "movae_bn_act_fwd: workspace too small");
-        const Split s = make_split(rows, c);
         double* part = static_cast<double*>(ws);
-        hipLaunchKernelGGL(bn_stats_partial, dim3(s.nblk), dim3(256), 0, st, y, part, rows, c, s.CB, s.rows_per_block);
+        int nblk;
+        if (c % 4 == 0 && al16(y)) {
+            const Split4 s = make_split4(rows, c);
+            nblk = s.nblk;
+            hipLaunchKernelGGL(bn_stats_partial4, dim3(s.nblk), dim3(256), 0, st, y, part, rows, c, s.CQB, s.rows_per_block);
+        } else {
+            const Split s = make_split(rows, c);
+            nblk = s.nblk;
+            hipLaunchKernelGGL(bn_stats_partial, dim3(s.nblk), dim3(256), 0, st, y, part, rows, c, s.CB, s.rows_per_block);
+        }
         MOVAE_CHECK_LAUNCH("bn_stats_partial");
-        hipLaunchKernelGGL(bn_stats_final, dim3(c), dim3(64), 0, st, part, s.nblk, rows, c, eps, momentum,
+        hipLaunchKernelGGL(bn_stats_final, dim3(c), dim3(64), 0, st, part, nblk, rows, c, eps, momentum,
                            save_mean, save_rstd, running_mean, running_var);
         MOVAE_CHECK_LAUNCH("bn_stats_final");
     } else {
@@ -253,18 +385,31 @@ int movae_bn_act_bwd(const float* dout, const float* y, const float* gamma, cons
     MOVAE_CHECK_ARG(rows > 0 && c > 0, "movae_bn_act_bwd: bad shape rows=%d c=%d", rows, c);
     MOVAE_CHECK_ARG(ws && ws_bytes >= movae_bn_ws_bytes(rows, c), "movae_bn_act_bwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    const Split s = make_split(rows, c);
     double* part = static_cast<double*>(ws);
-    float* sums = reinterpret_cast<float*>(part + (size_t)s.nblk * c * 2);
-    hipLaunchKernelGGL(bn_bwd_partial, dim3(s.nblk), dim3(256), 0, st, dout, y, gamma, beta, save_mean, save_rstd, part, rows,
-                       c, s.CB, s.rows_per_block, act, slope);
+    const bool vec = c % 4 == 0 && al16(dout, y, dy) && al16(gamma, beta) && al16(save_mean, save_rstd);
+    int nblk;
+    if (vec) {
+        const Split4 s = make_split4(rows, c);
+        nblk = s.nblk;
+        hipLaunchKernelGGL(bn_bwd_partial4, dim3(s.nblk), dim3(256), 0, st, dout, y, gamma, beta, save_mean, save_rstd, part,
+                           rows, c, s.CQB, s.rows_per_block, act, slope);
+    } else {
+        const Split s = make_split(rows, c);
+        nblk = s.nblk;
+        hipLaunchKernelGGL(bn_bwd_partial, dim3(s.nblk), dim3(256), 0, st, dout, y, gamma, beta, save_mean, save_rstd, part,
+                           rows, c, s.CB, s.rows_per_block, act, slope);
+    }
     MOVAE_CHECK_LAUNCH("bn_bwd_partial");
-    hipLaunchKernelGGL(bn_bwd_final, dim3(c), dim3(64), 0, st, part, s.nblk, rows, c, sums, dgamma, dbeta,
-                       accumulate);
+    float* sums = reinterpret_cast<float*>(part + (size_t)nblk * c * 2);
+    hipLaunchKernelGGL(bn_bwd_final, dim3(c), dim3(64), 0, st, part, nblk, rows, c, sums, dgamma, dbeta, accumulate);
     MOVAE_CHECK_LAUNCH("bn_bwd_final");
     const long total = (long)rows * c;
-    hipLaunchKernelGGL(bn_bwd_apply, dim3(grid_for(total)), dim3(256), 0, st, dout, y, gamma, beta, save_mean, save_rstd, sums,
-                       dy, total, c, act, slope);
+    if (vec)
+        hipLaunchKernelGGL(bn_bwd_apply4, dim3(grid_for(total / 4)), dim3(256), 0, st, dout, y, gamma, beta, save_mean, save_rstd,
+                           sums, dy, total, c, act, slope);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply, dim3(grid_for(total)), dim3(256), 0, st, dout, y, gamma, beta, save_mean, save_rstd,
+                           sums, dy, total, c, act, slope);
     MOVAE_CHECK_LAUNCH("bn_bwd_apply");
     return MOVAE_OK;
 }

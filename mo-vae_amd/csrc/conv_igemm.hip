@@ -12,6 +12,7 @@
 // (conflict-free ds_read_b32 per MFMA operand), global loads for tile t+1 issued before the
 // MFMAs of tile t.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -516,8 +517,10 @@ inline int launch_reduce(const float* slab, float* out, long total, int S, int N
 inline int choose_split(long tiles, int nk, size_t per_slab_bytes, size_t ws_bytes, bool have_ws) {
     // splitting pays only when the unsplit grid cannot fill the chip once (256 CUs); every split costs one slab
     // write + read of the whole output, so large outputs stay unsplit
-    if (!have_ws || tiles > 192 || nk < 4) return 1;
-    long S = (768 + tiles - 1) / tiles;
+    static const int tune_tiles = getenv("MOVAE_SPLIT_TILES") ? atoi(getenv("MOVAE_SPLIT_TILES")) : 192;
+    static const int tune_target = getenv("MOVAE_SPLIT_TARGET") ? atoi(getenv("MOVAE_SPLIT_TARGET")) : 768;
+    if (!have_ws || tiles > tune_tiles || nk < 4) return 1;
+    long S = (tune_target + tiles - 1) / tiles;
     if (S > nk / 2) S = nk / 2;
     if (S > 128) S = 128;
     while (S > 1 && per_slab_bytes * (size_t)S > ws_bytes) --S;
@@ -528,6 +531,7 @@ inline int choose_split(long tiles, int nk, size_t per_slab_bytes, size_t ws_byt
 // host dispatch
 // ------------------------------------------------------------------------------------------------
 #include "igemm_v2.h"
+#include "conv_thin.h"
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -563,6 +567,8 @@ int launch_fwd(const float* X, const float* W, float* Y, const Geom& g, const Ep
         return MOVAE_EINVAL;
     }
     const int M = (int)Ml, K = (int)Kl;
+    if (thin::thin_in_ok(g)) return thin::launch_thin_in<false>(X, W, Y, g, ep, st);
+    if (thin::thin_out_ok(g, X)) return thin::launch_thin_out_fwd(X, W, Y, g, ep, st);
     if (g.Cr % 4 == 0 && aligned16(X) && aligned16(W)) {  // fast path (igemm_v2.h)
         if (g.Nn <= 32) return v2::launch_fwd2<128, 32>(X, W, Y, g, ep, M, K, ws, ws_bytes, st);
         if (Ml >= 128 * 512) return v2::launch_fwd2<128, 64>(X, W, Y, g, ep, M, K, ws, ws_bytes, st);
@@ -606,6 +612,7 @@ int launch_bwd(const float* X, const float* W, float* Y, const Geom& g, const Ep
         return MOVAE_EINVAL;
     }
     const long Mc = Ml / (g.stride * g.stride);
+    if (thin::thin_in_ok(g)) return thin::launch_thin_in<true>(X, W, Y, g, ep, st);
     if (g.Cr % 4 == 0 && g.Nn % 4 == 0 && aligned16(X) && aligned16(W)) {  // fast path (igemm_v2.h)
         if (g.Nn <= 32) return v2::launch_bwd2<128, 32>(X, W, Y, g, ep, ws, ws_bytes, st);
         if (Mc >= 128 * 512) return v2::launch_bwd2<128, 64>(X, W, Y, g, ep, ws, ws_bytes, st);
@@ -659,6 +666,7 @@ int launch_wgrad(const float* S, const float* Bg, float* dW, const WGeom& g, int
     }
     const int vec = ((g.Cs % 4 == 0 && aligned16(S)) ? 1 : 0) | ((g.Cb % 4 == 0 && aligned16(Bg)) ? 2 : 0);
     const int N = g.KH * g.KW * g.Cb;
+    if (thin::thin_wgrad_ok(g) && ws) return thin::launch_thin_wgrad(S, Bg, dW, g, (int)Kl, accumulate, ws, ws_bytes, st);
     if (vec == 3) {  // fast path (igemm_v2.h)
         if (N <= 32) return v2::launch_wgrad2<128, 32>(S, Bg, dW, g, (int)Kl, accumulate, ws, ws_bytes, st);
         return v2::launch_wgrad2<64, 64>(S, Bg, dW, g, (int)Kl, accumulate, ws, ws_bytes, st);

@@ -117,6 +117,36 @@ __global__ __launch_bounds__(256) void colsum_partial(const float* __restrict__ 
     }
 }
 
+// 16-byte variant: a thread owns one 4-channel quad (C % 4 == 0), a wave reads 1 KiB contiguous
+__global__ __launch_bounds__(256) void colsum_partial4(const float* __restrict__ x, double* __restrict__ part, int rows,
+                                                       int C, int CQB, int rows_per_block) {
+    __shared__ double sh[4 * 256];
+    const int t = threadIdx.x, RG = 256 / CQB, cl = t % CQB, rg = t / CQB, CQ = C / 4;
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min((long)rows, r0 + rows_per_block);
+    for (int cb = 0; cb < CQ; cb += CQB) {
+        const int cq = cb + cl;
+        double v[4] = {0, 0, 0, 0};
+        if (cq < CQ)
+            for (long r = r0 + rg; r < r1; r += RG) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(x + r * C + cq * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += (double)a[j];
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sh[j * 256 + t] = v[j];
+        __syncthreads();
+        if (rg == 0 && cq < CQ) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                double s = v[j];
+                for (int i = 1; i < RG; ++i) s += sh[j * 256 + i * CQB + cl];
+                part[(long)blockIdx.x * C + cq * 4 + j] = s;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(64) void colsum_final(const double* __restrict__ part, int nblk, int C, float* __restrict__ out,
                                                    int accumulate) {
     const int c = blockIdx.x;
@@ -217,6 +247,22 @@ int movae_copy_channels(const float* src, float* dst, int rows, int c_src, int c
 
 int movae_colsum(const float* x, float* out, int rows, int c, int accumulate, void* ws, size_t ws_bytes, movae_stream_t stream) {
     MOVAE_CHECK_ARG(x && out && rows > 0 && c > 0, "movae_colsum: bad argument");
+    if (c % 4 == 0 && al16(x)) {
+        const int cq = c / 4;
+        const int CQB = pow2_ge(cq) < 256 ? pow2_ge(cq) : 256;
+        const int RG4 = 256 / CQB;
+        int rpb4 = ceil_div(rows, 1024);
+        rpb4 = ceil_div(rpb4, RG4) * RG4;
+        if (rpb4 < RG4 * 8) rpb4 = RG4 * 8;
+        const int nblk4 = ceil_div(rows, rpb4);
+        MOVAE_CHECK_ARG(ws && ws_bytes >= (size_t)nblk4 * c * sizeof(double), "movae_colsum: workspace too small");
+        double* part4 = static_cast<double*>(ws);
+        hipLaunchKernelGGL(colsum_partial4, dim3(nblk4), dim3(256), 0, (hipStream_t)stream, x, part4, rows, c, CQB, rpb4);
+        MOVAE_CHECK_LAUNCH("colsum_partial4");
+        hipLaunchKernelGGL(colsum_final, dim3(c), dim3(64), 0, (hipStream_t)stream, part4, nblk4, c, out, accumulate);
+        MOVAE_CHECK_LAUNCH("colsum_final");
+        return MOVAE_OK;
+    }
     const int CB = pow2_ge(c) < 256 ? pow2_ge(c) : 256;
     const int RG = 256 / CB;
     int rpb = ceil_div(rows, 256);

@@ -27,8 +27,8 @@ class Conv2d(tnn.Module):
         self.stride, self.padding, self.kernel_size = stride, padding, k
         self.in_channels, self.out_channels = cin, cout
 
-    def forward(self, x, act=None):
-        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, act, LRELU_SLOPE)
+    def forward(self, x, act=None, feeds_batchnorm=False):
+        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, act, LRELU_SLOPE, feeds_batchnorm)
 
     def extra_repr(self):
         return f"{self.in_channels}, {self.out_channels}, k={self.kernel_size}, s={self.stride}, p={self.padding}"
@@ -43,8 +43,9 @@ class ConvTranspose2d(tnn.Module):
         self.stride, self.padding, self.output_padding, self.kernel_size = stride, padding, output_padding, k
         self.in_channels, self.out_channels = cin, cout
 
-    def forward(self, x, act=None):
-        return ops.conv_transpose2d(x, self.weight, self.bias, self.stride, self.padding, self.output_padding, act, LRELU_SLOPE)
+    def forward(self, x, act=None, feeds_batchnorm=False):
+        return ops.conv_transpose2d(x, self.weight, self.bias, self.stride, self.padding, self.output_padding, act, LRELU_SLOPE,
+                                    feeds_batchnorm)
 
     def extra_repr(self):
         return (f"{self.in_channels}, {self.out_channels}, k={self.kernel_size}, s={self.stride}, p={self.padding}, "
@@ -134,7 +135,7 @@ class Stack(tnn.Sequential):
                 nxt = mods[i + 1] if i + 1 < n else None
                 if isinstance(nxt, BatchNorm2d):
                     act = mods[i + 2] if i + 2 < n and isinstance(mods[i + 2], _Act) else None
-                    x = nxt(m(x), act.kind if act is not None else None)
+                    x = nxt(m(x, None, nxt.training), act.kind if act is not None else None)
                     i += 3 if act is not None else 2
                 elif isinstance(nxt, _Act):
                     x = m(x, nxt.kind)

@@ -13,6 +13,18 @@ from . import _lib as L
 
 _call = L.call
 
+#: data_ptr of a parameter -> 1-D destination tensor for its gradient.  autojac.mtl_backward points this at
+#: the current row of the Jacobian arena so wgrad / BN-backward kernels write their results in place
+#: (consumed on first use; a second use of the same parameter falls back to a fresh buffer).
+GRAD_SINK = {}
+
+
+def _sink(param, shape):
+    dst = GRAD_SINK.pop(param.data_ptr(), None) if GRAD_SINK else None
+    if dst is not None and dst.numel() == param.numel():
+        return dst.view(shape)
+    return torch.empty(shape, dtype=param.dtype, device=param.device)
+
 
 def _ws(t):
     w = L.workspace(t.device)
@@ -113,7 +125,7 @@ class Conv(Function):
     """conv2d / conv_transpose2d / linear (+bias, + fused activation)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, out_pad, transposed, act, slope):
+    def forward(ctx, x, w, b, stride, pad, out_pad, transposed, act, slope, bias_grad_is_zero=False):
         L.require_gpu(x)
         x = _c(x)
         wm = weight_mem(w)
@@ -134,12 +146,13 @@ class Conv(Function):
               L.ACT[act], float(slope), wsp, wsb, _st(x))
         ctx.geom = (n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad)
         ctx.transposed, ctx.act, ctx.slope, ctx.has_bias = transposed, act, slope, b is not None
-        ctx.save_for_backward(x, w, y if L.ACT[act] else None)
+        ctx.bias_grad_is_zero = bias_grad_is_zero
+        ctx.save_for_backward(x, w, y if L.ACT[act] else None, b)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, y = ctx.saved_tensors
+        x, w, y, b = ctx.saved_tensors
         dy = _c(dy)
         n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad = ctx.geom
         st = _st(dy)
@@ -157,21 +170,28 @@ class Conv(Function):
                   wsp, wsb, st)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             wm_shape = (ci, kh, kw, co) if ctx.transposed else (co, kh, kw, ci)
-            dwm = torch.empty(wm_shape, dtype=dy.dtype, device=dy.device)
+            dwm = _sink(w, wm_shape)
+            db_k = None
             if ctx.has_bias and ctx.needs_input_grad[2]:
-                db = torch.empty(co, dtype=dy.dtype, device=dy.device)
-            _call(pre + "wgrad", dy.data_ptr(), x.data_ptr(), dwm.data_ptr(), L.ptr(db), n, hi, wi, ci, ho, wo, co, kh, kw,
+                db = _sink(b, (co,))
+                if ctx.bias_grad_is_zero:
+                    # the bias feeds a training-mode BatchNorm, which subtracts the batch mean: d(loss)/d(bias) == 0
+                    # identically (the reference's value is rounding noise of order 1e-9); no column-sum pass
+                    db.zero_()
+                else:
+                    db_k = db
+            _call(pre + "wgrad", dy.data_ptr(), x.data_ptr(), dwm.data_ptr(), L.ptr(db_k), n, hi, wi, ci, ho, wo, co, kh, kw,
                   stride, pad, 0, wsp, wsb, st)
             dw = dwm.permute(0, 3, 1, 2)
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
-def conv2d(x, w, b=None, stride=1, pad=0, act=None, slope=0.01):
-    return Conv.apply(x, w, b, stride, pad, 0, False, act, slope)
+def conv2d(x, w, b=None, stride=1, pad=0, act=None, slope=0.01, bias_grad_is_zero=False):
+    return Conv.apply(x, w, b, stride, pad, 0, False, act, slope, bias_grad_is_zero)
 
 
-def conv_transpose2d(x, w, b=None, stride=1, pad=0, out_pad=0, act=None, slope=0.01):
-    return Conv.apply(x, w, b, stride, pad, out_pad, True, act, slope)
+def conv_transpose2d(x, w, b=None, stride=1, pad=0, out_pad=0, act=None, slope=0.01, bias_grad_is_zero=False):
+    return Conv.apply(x, w, b, stride, pad, out_pad, True, act, slope, bias_grad_is_zero)
 
 
 def linear(x, w, b=None, act=None, slope=0.01):
@@ -210,8 +230,8 @@ class BatchNormAct(Function):
         c = y.shape[-1]
         rows = y.numel() // c
         dy = torch.empty_like(y)
-        dg = torch.empty_like(gamma)
-        db = torch.empty_like(beta)
+        dg = _sink(gamma, gamma.shape)
+        db = _sink(beta, beta.shape)
         wsp, wsb = _ws(y)
         _call("movae_bn_act_bwd", dout.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
               rstd.data_ptr(), dy.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, c, L.ACT[ctx.act], float(ctx.slope), 0,

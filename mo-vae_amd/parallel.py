@@ -13,7 +13,7 @@ import torch
 import torch.distributed as dist
 
 
-def flatten_grads(params):
+def flatten_grads(params, out=None):
     """All gradients in one contiguous buffer (memory order); params without grad contribute zeros."""
     chunks = []
     for p in params:
@@ -25,6 +25,8 @@ def flatten_grads(params):
                 chunks.append(g.permute(0, 2, 3, 1).reshape(-1))
             else:
                 chunks.append(g.contiguous().reshape(-1))
+    if out is not None:
+        return torch.cat(chunks, out=out)
     return torch.cat(chunks)
 
 
@@ -45,11 +47,16 @@ class DataParallelGrads:
     def from_env(cls, backend=None):
         """torchrun / torch.distributed.run environment -> initialised process group, or None."""
         ws = int(os.environ.get("WORLD_SIZE", "1"))
-        if ws <= 1:
+        if ws <= 1 and not os.environ.get("MOVAE_FORCE_DP"):  # MOVAE_FORCE_DP: exercise the collective path with one rank
             return None
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("MASTER_PORT", "29533")
         rank, local_rank = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", os.environ["RANK"]))
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
-        if backend == "nccl":
+        # MOVAE_DIST_BACKEND=gloo rehearses the N>1 path on a box with fewer GPUs than ranks (RCCL refuses two
+        # ranks on one device); the device index then wraps around the visible devices.
+        backend = backend or os.environ.get("MOVAE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            local_rank = local_rank % torch.cuda.device_count()
             torch.cuda.set_device(local_rank)
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -63,8 +63,8 @@ def print_gd_similarity(_, inputs, weights):
     _hook_values["similarity"] = aggregation.gd_similarity(inputs[0], weights)
 
 
-def train_step(net, images, optimizer, aggregator, args, dp=None):
-    """One optimisation step (main.py:155-214).  Returns the loss dict (device tensors) and outputs."""
+def forward_backward(net, images, optimizer, aggregator):
+    """zero_grad, forward, losses and the (aggregated) backward of one step (main.py:157-196)."""
     optimizer.zero_grad()
     outputs = net(images)
     loss_dict = net.loss_function(images, args=outputs)
@@ -79,6 +79,12 @@ def train_step(net, images, optimizer, aggregator, args, dp=None):
             autojac.mtl_backward(losses=component_losses, features=features, aggregator=aggregator, retain_graph=True)
         else:
             autojac.backward(component_losses, aggregator=aggregator)
+    return loss_dict, outputs
+
+
+def train_step(net, images, optimizer, aggregator, args, dp=None):
+    """One optimisation step (main.py:155-214).  Returns the loss dict (device tensors) and outputs."""
+    loss_dict, outputs = forward_backward(net, images, optimizer, aggregator)
     if dp is not None:
         dp.all_reduce_grads()
     if getattr(args, "max_grad_norm", None) is not None:
@@ -95,34 +101,59 @@ class GraphedTrainStep:
     optimizer) captured ONCE into a hipGraph and replayed per batch: the step is ~250 short kernels, so
     eager launches are host-bound; a replay is one submission.  No tracing compiler is involved -- the
     graph holds exactly the launches the eager step made.  The optimizer must be constructed with
-    capturable=True (its step counter then lives on the device)."""
+    capturable=True (its step counter then lives on the device).
 
-    def __init__(self, net, optimizer, aggregator, args, example, warmup=3):
+    Data parallel (dp given): the step is two graphs around ONE eager collective --
+    graph 1 = forward/backward + flatten of every gradient into a static flat bucket, then
+    `all_reduce(bucket)` over RCCL, then graph 2 = 1/N scaling + optimizer step on views of the bucket."""
+
+    def __init__(self, net, optimizer, aggregator, args, example, warmup=3, dp=None):
         if type(net).__name__ not in GRAPH_SAFE_ARCHS:
             raise NotImplementedError(f"{type(net).__name__}: forward syncs with the host (codebook usage / anneal counter); "
                                       "use the eager train_step")
         if getattr(args, "max_grad_norm", None) is not None:
             raise NotImplementedError("clip_grad_norm_ reads the norm on the host; use the eager train_step")
-        self.net, self.opt, self.agg, self.args = net, optimizer, aggregator, args
+        self.net, self.opt, self.agg, self.args, self.dp = net, optimizer, aggregator, args, dp
         self.static_x = example.clone()
         from . import _lib as L
+        from .parallel import flatten_grads, unflatten_into_grads
 
         L.workspace(example.device)  # allocate the scratch arena outside the capture
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                train_step(net, self.static_x, optimizer, aggregator, args)
+                train_step(net, self.static_x, optimizer, aggregator, args, dp)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
+        self.graph2 = None
         optimizer.zero_grad(set_to_none=True)
+        if dp is None:
+            with torch.cuda.graph(self.graph):
+                self.loss_dict, self.outputs = train_step(net, self.static_x, optimizer, aggregator, args)
+            return
+        params = [p for p in net.parameters() if p.requires_grad]
+        # the bucket handed to the collective is an ordinary allocation (not graph-pool memory)
+        self.flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=example.device)
         with torch.cuda.graph(self.graph):
-            self.loss_dict, self.outputs = train_step(net, self.static_x, optimizer, aggregator, args)
+            self.loss_dict, self.outputs = forward_backward(net, self.static_x, optimizer, aggregator)
+            flatten_grads(params, out=self.flat)
+        self.graph.replay()  # the capture pass recorded but did not execute: materialise real gradients once
+        torch.distributed.all_reduce(self.flat)
+        unflatten_into_grads(self.flat, params)  # .grad := static views of the bucket, kept for every replay
+        self.graph2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph2, pool=self.graph.pool()):
+            self.flat.div_(dp.world_size)
+            optimizer.step()
+        self.graph2.replay()  # completes the step whose gradients were just reduced
 
     def step(self, images):
         self.static_x.copy_(images, non_blocking=True)
         self.graph.replay()
+        if self.graph2 is not None:
+            torch.distributed.all_reduce(self.flat)
+            self.graph2.replay()
         return self.loss_dict, self.outputs
 
 
