@@ -16,9 +16,14 @@
 
 namespace v2 {
 
-constexpr int BK2 = 32;
-constexpr int HK = BK2 / 2;
-constexpr int LDR = BK2 + 4;  // row-major leading dimension
+#ifndef MOVAE_IGEMM_KB
+#define MOVAE_IGEMM_KB 32
+#endif
+constexpr int BK2 = MOVAE_IGEMM_KB;   // k per stage
+constexpr int HK = BK2 / 2;           // k per lane half
+constexpr int LDR = BK2 + 4;          // row-major leading dimension (16-byte rows, conflict-free b128 reads)
+constexpr int CPR = BK2 / 4;          // 16-byte chunks per row-major row
+constexpr int RPP = 256 / CPR;        // rows staged per pass of the 256 threads
 
 template <int BM, int BN>
 struct T2 {
@@ -31,12 +36,12 @@ struct T2 {
 };
 
 // A row-major, B row-major (FWD)
-template <int TM>
+template <int TM, int PART>  // PART 0/1: first / second half of the stage's k range
 __device__ __forceinline__ void mma_rr(const float* __restrict__ As, const float* __restrict__ Bs, int a_row, int b_row,
                                        f32x16 (&acc)[TM]) {
     const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
 #pragma unroll
-    for (int jj = 0; jj < HK / 4; ++jj) {
+    for (int jj = PART * (HK / 8); jj < (PART + 1) * (HK / 8); ++jj) {
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(Bs + (b_row + l31) * LDR + half * HK + jj * 4);
         f32x4 a4[TM];
 #pragma unroll
@@ -50,12 +55,12 @@ __device__ __forceinline__ void mma_rr(const float* __restrict__ As, const float
 }
 
 // A row-major, B k-major (BWD)
-template <int TM>
+template <int TM, int PART>
 __device__ __forceinline__ void mma_rk(const float* __restrict__ As, const float* __restrict__ Bs, int ldb, int a_row,
                                        int b_col, f32x16 (&acc)[TM]) {
     const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
 #pragma unroll
-    for (int jj = 0; jj < HK / 4; ++jj) {
+    for (int jj = PART * (HK / 8); jj < (PART + 1) * (HK / 8); ++jj) {
         f32x4 a4[TM];
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
@@ -70,12 +75,12 @@ __device__ __forceinline__ void mma_rk(const float* __restrict__ As, const float
 }
 
 // A k-major, B k-major (WGRAD)
-template <int TM>
+template <int TM, int PART>
 __device__ __forceinline__ void mma_kk(const float* __restrict__ As, const float* __restrict__ Bs, int lda, int ldb,
                                        int a_col, int b_col, f32x16 (&acc)[TM]) {
     const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
 #pragma unroll
-    for (int j = 0; j < HK; ++j) {
+    for (int j = PART * (HK / 2); j < (PART + 1) * (HK / 2); ++j) {
         const float b = Bs[(half * HK + j) * ldb + b_col + l31];
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
@@ -93,20 +98,21 @@ __global__ __launch_bounds__(256) void igemm2_fwd(const float* __restrict__ X, c
                                                   float* __restrict__ Y, Geom g, Epilogue ep, int M, int K,
                                                   int ktiles_per_split, float* __restrict__ slab) {
     using T = T2<BM, BN>;
-    __shared__ __attribute__((aligned(16))) float As[BM * LDR];
-    __shared__ __attribute__((aligned(16))) float Bs[BN * LDR];
+    constexpr int ASZ = BM * LDR, BSZ = BN * LDR;
+    __shared__ __attribute__((aligned(16))) float As[2 * ASZ];  // double buffered
+    __shared__ __attribute__((aligned(16))) float Bs[2 * BSZ];
     const int t = threadIdx.x;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int N = g.Nn;
-    constexpr int AC = BM / 32, BC = BN / 32;  // 16-byte chunks per thread (8 chunks per row, 256 threads)
-    const int kq = t & 7, r8 = t >> 3;
+    constexpr int AC = BM / RPP, BC = BN / RPP;  // 16-byte chunks per thread
+    const int kq = t % CPR, r8 = t / CPR;
 
     const float* a_base[AC];
     int a_h0[AC], a_w0[AC];
     bool a_ok[AC];
 #pragma unroll
     for (int i = 0; i < AC; ++i) {
-        const int m = m0 + r8 + 32 * i;
+        const int m = m0 + r8 + RPP * i;
         a_ok[i] = m < M;
         const int mm = a_ok[i] ? m : 0;
         const int hw = g.Ho * g.Wo;
@@ -120,7 +126,7 @@ __global__ __launch_bounds__(256) void igemm2_fwd(const float* __restrict__ X, c
     bool b_ok[BC];
 #pragma unroll
     for (int i = 0; i < BC; ++i) {
-        const int n = n0 + r8 + 32 * i;
+        const int n = n0 + r8 + RPP * i;
         b_ok[i] = n < N;
         b_base[i] = W + (long)(b_ok[i] ? n : 0) * K;
     }
@@ -151,16 +157,31 @@ __global__ __launch_bounds__(256) void igemm2_fwd(const float* __restrict__ X, c
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     const int wave = t >> 6, wm = wave / T::WN, wn = wave % T::WN;
-    if (kt_begin < kt_end) load_tile(kt_begin);
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        __syncthreads();
+    auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < AC; ++i) *reinterpret_cast<f32x4*>(As + (r8 + 32 * i) * LDR + kq * 4) = ra[i];
+        for (int i = 0; i < AC; ++i) *reinterpret_cast<f32x4*>(As + buf * ASZ + (r8 + RPP * i) * LDR + kq * 4) = ra[i];
 #pragma unroll
-        for (int i = 0; i < BC; ++i) *reinterpret_cast<f32x4*>(Bs + (r8 + 32 * i) * LDR + kq * 4) = rb[i];
+        for (int i = 0; i < BC; ++i) *reinterpret_cast<f32x4*>(Bs + buf * BSZ + (r8 + RPP * i) * LDR + kq * 4) = rb[i];
+    };
+    // software pipeline: stage t is multiplied out of LDS buffer t&1 while the registers of stage t+1 are
+    // written to the other buffer between the two MFMA halves and the loads of stage t+2 are issued; one
+    // barrier per stage.
+    const int nkt = kt_end - kt_begin;
+    if (nkt > 0) {
+        load_tile(kt_begin);
+        store_tile(0);
         __syncthreads();
-        if (kt + 1 < kt_end) load_tile(kt + 1);
-        mma_rr<T::TM>(As, Bs, wm * T::TM * 32, wn * 32, acc);
+        if (nkt > 1) load_tile(kt_begin + 1);
+    }
+    for (int it = 0; it < nkt; ++it) {
+        const int cur = it & 1;
+        mma_rr<T::TM, 0>(As + cur * ASZ, Bs + cur * BSZ, wm * T::TM * 32, wn * 32, acc);
+        if (it + 1 < nkt) {
+            store_tile(cur ^ 1);
+            if (it + 2 < nkt) load_tile(kt_begin + it + 2);
+        }
+        mma_rr<T::TM, 1>(As + cur * ASZ, Bs + cur * BSZ, wm * T::TM * 32, wn * 32, acc);
+        __syncthreads();
     }
 
     const int lane = t & 63, half = lane >> 5, l31 = lane & 31;
@@ -184,8 +205,9 @@ __global__ __launch_bounds__(256) void igemm2_bwd(const float* __restrict__ X, c
                                                   float* __restrict__ Y, Geom g, Epilogue ep, int S, int ktiles_per_split,
                                                   float* __restrict__ slab, long total) {
     using T = T2<BM, BN>;
-    __shared__ __attribute__((aligned(16))) float As[BM * LDR];
-    __shared__ __attribute__((aligned(16))) float Bs[BK2 * T::LDKB];
+    constexpr int ASZ = BM * LDR, BSZ = BK2 * T::LDKB;
+    __shared__ __attribute__((aligned(16))) float As[2 * ASZ];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * BSZ];
     const int t = threadIdx.x;
     const int s = g.stride;
     const int cls = blockIdx.z / S, split = blockIdx.z - cls * S;
@@ -203,14 +225,14 @@ __global__ __launch_bounds__(256) void igemm2_bwd(const float* __restrict__ X, c
     const int taps = g.KH * g.KW;
     const int nBd = nB > 0 ? nB : 1;
 
-    constexpr int AC = BM / 32;
-    const int kq = t & 7, r8 = t >> 3;
+    constexpr int AC = BM / RPP;
+    const int kq = t % CPR, r8 = t / CPR;
     const float* a_base[AC];
     int a_h0[AC], a_w0[AC];
     bool a_ok[AC];
 #pragma unroll
     for (int i = 0; i < AC; ++i) {
-        const int m = m0 + r8 + 32 * i;
+        const int m = m0 + r8 + RPP * i;
         a_ok[i] = m < M;
         const int mm = a_ok[i] ? m : 0;
         const int hw = Hoc * Woc;
@@ -263,16 +285,28 @@ __global__ __launch_bounds__(256) void igemm2_bwd(const float* __restrict__ X, c
     const int nk_total = (K + BK2 - 1) / BK2;
     const int kt_begin = split * ktiles_per_split;
     const int kt_end = min(nk_total, kt_begin + ktiles_per_split);
-    if (kt_begin < kt_end) load_tile(kt_begin);
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        __syncthreads();
+    auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < AC; ++i) *reinterpret_cast<f32x4*>(As + (r8 + 32 * i) * LDR + kq * 4) = ra[i];
+        for (int i = 0; i < AC; ++i) *reinterpret_cast<f32x4*>(As + buf * ASZ + (r8 + RPP * i) * LDR + kq * 4) = ra[i];
 #pragma unroll
-        for (int i = 0; i < BC; ++i) *reinterpret_cast<f32x4*>(Bs + (bk + KSTEP * i) * T::LDKB + bq * 4) = rb[i];
+        for (int i = 0; i < BC; ++i) *reinterpret_cast<f32x4*>(Bs + buf * BSZ + (bk + KSTEP * i) * T::LDKB + bq * 4) = rb[i];
+    };
+    const int nkt = kt_end - kt_begin;
+    if (nkt > 0) {
+        load_tile(kt_begin);
+        store_tile(0);
         __syncthreads();
-        if (kt + 1 < kt_end) load_tile(kt + 1);
-        mma_rk<T::TM>(As, Bs, T::LDKB, wm * T::TM * 32, wn * 32, acc);
+        if (nkt > 1) load_tile(kt_begin + 1);
+    }
+    for (int it = 0; it < nkt; ++it) {
+        const int cur = it & 1;
+        mma_rk<T::TM, 0>(As + cur * ASZ, Bs + cur * BSZ, T::LDKB, wm * T::TM * 32, wn * 32, acc);
+        if (it + 1 < nkt) {
+            store_tile(cur ^ 1);
+            if (it + 2 < nkt) load_tile(kt_begin + it + 2);
+        }
+        mma_rk<T::TM, 1>(As + cur * ASZ, Bs + cur * BSZ, T::LDKB, wm * T::TM * 32, wn * 32, acc);
+        __syncthreads();
     }
 
     const int lane = t & 63, half = lane >> 5, l31 = lane & 31;
@@ -301,8 +335,9 @@ template <int BM, int BN>
 __global__ __launch_bounds__(256) void igemm2_wgrad(const float* __restrict__ Sm, const float* __restrict__ Bg,
                                                     float* __restrict__ out, WGeom g, int K, int kchunk, int to_slab) {
     using T = T2<BM, BN>;
-    __shared__ __attribute__((aligned(16))) float As[BK2 * T::LDKA];
-    __shared__ __attribute__((aligned(16))) float Bs[BK2 * T::LDKB];
+    constexpr int ASZ = BK2 * T::LDKA, BSZ = BK2 * T::LDKB;
+    __shared__ __attribute__((aligned(16))) float As[2 * ASZ];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * BSZ];
     const int t = threadIdx.x;
     const int M = g.Cs, N = g.KH * g.KW * g.Cb;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
@@ -346,16 +381,28 @@ __global__ __launch_bounds__(256) void igemm2_wgrad(const float* __restrict__ Sm
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     const int wave = t >> 6, wm = wave / T::WN, wn = wave % T::WN;
-    if (k_begin < k_end) load_tile(k_begin);
-    for (int k0 = k_begin; k0 < k_end; k0 += BK2) {
-        __syncthreads();
+    auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < ACH; ++i) *reinterpret_cast<f32x4*>(As + (ak + AKS * i) * T::LDKA + aq * 4) = ra[i];
+        for (int i = 0; i < ACH; ++i) *reinterpret_cast<f32x4*>(As + buf * ASZ + (ak + AKS * i) * T::LDKA + aq * 4) = ra[i];
 #pragma unroll
-        for (int i = 0; i < BCH; ++i) *reinterpret_cast<f32x4*>(Bs + (bk + BKS * i) * T::LDKB + bq * 4) = rb[i];
+        for (int i = 0; i < BCH; ++i) *reinterpret_cast<f32x4*>(Bs + buf * BSZ + (bk + BKS * i) * T::LDKB + bq * 4) = rb[i];
+    };
+    const int nkt = k_begin < k_end ? (k_end - k_begin + BK2 - 1) / BK2 : 0;
+    if (nkt > 0) {
+        load_tile(k_begin);
+        store_tile(0);
         __syncthreads();
-        if (k0 + BK2 < k_end) load_tile(k0 + BK2);
-        mma_kk<T::TM>(As, Bs, T::LDKA, T::LDKB, wm * T::TM * 32, wn * 32, acc);
+        if (nkt > 1) load_tile(k_begin + BK2);
+    }
+    for (int it = 0; it < nkt; ++it) {
+        const int cur = it & 1;
+        mma_kk<T::TM, 0>(As + cur * ASZ, Bs + cur * BSZ, T::LDKA, T::LDKB, wm * T::TM * 32, wn * 32, acc);
+        if (it + 1 < nkt) {
+            store_tile(cur ^ 1);
+            if (it + 2 < nkt) load_tile(k_begin + (it + 2) * BK2);
+        }
+        mma_kk<T::TM, 1>(As + cur * ASZ, Bs + cur * BSZ, T::LDKA, T::LDKB, wm * T::TM * 32, wn * 32, acc);
+        __syncthreads();
     }
 
     const int lane = t & 63, half = lane >> 5, l31 = lane & 31;
