@@ -11,7 +11,10 @@
  *   - activations are NHWC ("channels_last"): x[n][h][w][c]; conv weights are [Co][KH][KW][Ci]
  *     and transposed-conv weights [Ci][KH][KW][Co] in memory (the channels_last image of the
  *     reference's OIHW / IOHW parameter shapes), Linear weights [out][in];
- *   - `ws`/`ws_bytes`: scratch for split-K partials; may be NULL/0 (then no split-K);
+ *   - `ws`/`ws_bytes`: scratch for split-K partials / reduction partials; may be NULL/0 where stated (then no
+ *     split-K).  The FIRST 4096 BYTES of the workspace are the library's hand-off counters: they must be zero
+ *     before the first call (hipMemset once), are left zero by every call, and one workspace must only be used
+ *     by one stream at a time; everything after the header is plain scratch with no state between calls;
  *   - return 0 on success, <0 on invalid argument (-1), unsupported shape (-2) or launch
  *     failure (-3); movae_last_error() gives the text for the calling thread.
  */
@@ -70,10 +73,12 @@ int movae_convT2d_wgrad(const float* dy, const float* x, float* dw, float* dbias
 /* ---- BatchNorm2d (training statistics) + activation ------------------------------------------
  * nn.BatchNorm2d + nn.LeakyReLU   models/vae.py:123-125,157-158,169-170   (eps 1e-5, momentum 0.1)
  * y is the conv output [rows][c]; stats are accumulated in fp64.  `ws` must hold
- * movae_bn_ws_bytes(rows, c) bytes. */
+ * movae_bn_ws_bytes(rows, c) bytes.  num_batches_tracked (device int64, may be NULL) is incremented by the
+ * statistics kernel in training mode (torch's BatchNorm2d does it with a launch of its own). */
 size_t movae_bn_ws_bytes(int rows, int c);
 int movae_bn_act_fwd(const float* y, const float* gamma, const float* beta, float* out,
                      float* save_mean, float* save_rstd, float* running_mean, float* running_var,
+                     long long* num_batches_tracked,
                      int rows, int c, float eps, float momentum, int training, int act, float slope,
                      void* ws, size_t ws_bytes, movae_stream_t stream);
 /* dy = d(loss)/d(conv output); dgamma/dbeta written (or accumulated when accumulate!=0). */
@@ -155,9 +160,26 @@ int movae_gd_similarity(const float* J, size_t ldj, int k, size_t m, const float
  * flat multi-tensor Adam over one contiguous fp32 arena; step_dev holds the step count as float. */
 int movae_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                     float eps, float weight_decay, int decoupled_wd, int step, movae_stream_t stream);
+/* the same update for a LIST of tensors in one launch per 64 tensors (torch.optim.Adam(foreach) semantics:
+ * main.py:1169-1178 builds it, main.py:214 steps it).  p/g/m/v/numel are HOST arrays of n_tensors device
+ * pointers / element counts.  hyper_dev == NULL: `step` (>= 1) is the step count and lr the learning rate.
+ * hyper_dev != NULL: device float[2] = {step counter, lr}; the call first increments the counter on `stream`,
+ * then uses the device values (`step` and `lr` arguments are ignored) -- the form a captured hipGraph replays. */
+int movae_adam_multi(int n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v,
+                     const size_t* numel, float lr, float beta1, float beta2, float eps, float weight_decay,
+                     int decoupled_wd, int step, float* hyper_dev, movae_stream_t stream);
 /* sumsq of a flat arena into out[0] (clip_grad_norm_, main.py:211-212) */
 int movae_sumsq(const float* x, size_t n, float* out, void* ws, size_t ws_bytes, movae_stream_t stream);
 int movae_scale_by_clip(float* g, size_t n, const float* sumsq_dev, float max_norm, movae_stream_t stream);
+
+/* ---- measurement hook (bench.py's roofline leg only; no reference counterpart) ------------------------
+ * on != 0: the conv family launches ONLY its main MFMA kernel (split-K reduce / bias column-sum launches are
+ * skipped, so outputs are incomplete) so that one kernel can be timed between HIP events.  Process-wide;
+ * returns the previous setting.  Never enabled by the product path. */
+int movae_bench_main_kernel_only(int on);
+/* name (as rocprofv3 prints it, without the argument list) of the main kernel the most recent conv-family call
+ * on this process dispatched to, e.g. "igemm2_bwd<64,64>" -- lets bench.py group its HIP-event timings per kernel */
+const char* movae_bench_last_kernel(void);
 
 #ifdef __cplusplus
 }

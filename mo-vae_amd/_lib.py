@@ -35,7 +35,7 @@ SIGNATURES = {
     "movae_convT2d_dgrad": (_conv_dgrad, _i),
     "movae_convT2d_wgrad": (_conv_wgrad, _i),
     "movae_bn_ws_bytes": ([_i, _i], _z),
-    "movae_bn_act_fwd": ([_p] * 8 + [_i, _i, _f, _f, _i, _i, _f, _p, _z, _p], _i),
+    "movae_bn_act_fwd": ([_p] * 9 + [_i, _i, _f, _f, _i, _i, _f, _p, _z, _p], _i),
     "movae_bn_act_bwd": ([_p] * 9 + [_i, _i, _i, _f, _i, _p, _z, _p], _i),
     "movae_act_fwd": ([_p, _p, _z, _i, _f, _p], _i),
     "movae_act_bwd": ([_p, _p, _p, _z, _i, _f, _p], _i),
@@ -63,8 +63,11 @@ SIGNATURES = {
     "movae_combine": ([_p, _z, _i, _z, _p, _p, _i, _p], _i),
     "movae_gd_similarity": ([_p, _z, _i, _z, _p, _p, _p, _z, _p], _i),
     "movae_adam_step": ([_p, _p, _p, _p, _z, _f, _f, _f, _f, _f, _i, _i, _p], _i),
+    "movae_adam_multi": ([_i, _p, _p, _p, _p, _p, _f, _f, _f, _f, _f, _i, _i, _p, _p], _i),
     "movae_sumsq": ([_p, _z, _p, _p, _z, _p], _i),
     "movae_scale_by_clip": ([_p, _z, _p, _f, _p], _i),
+    "movae_bench_main_kernel_only": ([_i], _i),
+    "movae_bench_last_kernel": ([], C.c_char_p),
 }
 
 _lib = None
@@ -125,12 +128,30 @@ _workspaces = {}
 WS_BYTES = 96 << 20
 
 
-def workspace(device):
-    """Persistent per-device scratch (split-K slabs, reduction partials).  Stream-ordered reuse."""
+# Forking conv wgrad onto a second stream measured SLOWER on MI355X (C2 graph replay 2.42 ms vs 2.24 ms: the tiny
+# layers are launch/latency bound and the fork/join events cost more than the overlap wins) -> opt-in only.
+SIDE_STREAM_WGRAD = bool(os.environ.get("MOVAE_SIDE_STREAM"))
+_side_streams = {}
+
+
+def side_stream(device):
+    """One forked HIP stream per device for launches that are independent of the main chain (conv wgrad)."""
     key = (device.type, device.index)
+    s = _side_streams.get(key)
+    if s is None:
+        s = torch.cuda.Stream(device)
+        _side_streams[key] = s
+    return s
+
+
+def workspace(device, slot=0):
+    """Persistent per-device scratch (split-K slabs, reduction partials).  Stream-ordered reuse; `slot` 1 is the
+    side stream's own arena (a workspace serves one stream at a time)."""
+    key = (device.type, device.index, slot)
     ws = _workspaces.get(key)
     if ws is None:
-        ws = torch.empty(WS_BYTES, dtype=torch.uint8, device=device)
+        # zero-filled: the first 4 KiB hold the in-launch hand-off counters (include/movae.h), which must start at zero
+        ws = torch.zeros(WS_BYTES, dtype=torch.uint8, device=device)
         _workspaces[key] = ws
     return ws
 

@@ -422,10 +422,11 @@ extern "C" {
 
 size_t movae_gram_ws_bytes(int k, size_t m) {
     if (k <= 0) return 0;
-    return (size_t)gram_blocks(m) * (size_t)(k * (k + 1) / 2) * sizeof(double);
+    return MOVAE_WS_HEADER_BYTES + (size_t)gram_blocks(m) * (size_t)(k * (k + 1) / 2) * sizeof(double);
 }
 
 int movae_gram(const float* J, size_t ldj, int k, size_t m, float* G, void* ws, size_t ws_bytes, movae_stream_t stream) {
+    MOVAE_WS_SCRATCH(ws, ws_bytes);
     MOVAE_CHECK_ARG(J && G && m > 0 && ldj >= m, "movae_gram: bad argument");
     MOVAE_CHECK_ARG(k >= 1 && k <= MAXK, "movae_gram: k=%d outside 1..%d", k, MAXK);
     MOVAE_CHECK_ARG(ws && ws_bytes >= movae_gram_ws_bytes(k, m), "movae_gram: workspace too small");
@@ -455,6 +456,7 @@ int movae_combine(const float* J, size_t ldj, int k, size_t m, const float* w, f
 
 int movae_gd_similarity(const float* J, size_t ldj, int k, size_t m, const float* w, float* out, void* ws, size_t ws_bytes,
                         movae_stream_t stream) {
+    MOVAE_WS_SCRATCH(ws, ws_bytes);
     MOVAE_CHECK_ARG(J && w && out && m > 0 && k >= 1 && k <= MAXK, "movae_gd_similarity: bad argument");
     const int nb = gram_blocks(m);
     MOVAE_CHECK_ARG(ws && ws_bytes >= (size_t)nb * 3 * sizeof(double), "movae_gd_similarity: workspace too small");

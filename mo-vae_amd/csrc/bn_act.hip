@@ -2,6 +2,7 @@
 // HBM-bound: the statistics pass reads y once (fp64 accumulation, deterministic two-stage
 // reduction), the apply pass reads y and writes out once.  Backward mirrors it.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -69,8 +70,9 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
 __global__ __launch_bounds__(64) void bn_stats_final(const double* __restrict__ part, int nblk, int rows, int C, float eps,
                                                      float momentum, float* __restrict__ save_mean,
                                                      float* __restrict__ save_rstd, float* __restrict__ running_mean,
-                                                     float* __restrict__ running_var) {
+                                                     float* __restrict__ running_var, long long* __restrict__ nbt) {
     const int c = blockIdx.x;
+    if (nbt && c == 0 && threadIdx.x == 0) nbt[0] += 1;  // nn.BatchNorm2d.num_batches_tracked, no launch of its own
     double s = 0.0, q = 0.0;
     for (int b = threadIdx.x; b < nblk; b += 64) {
         s += part[((long)b * C + c) * 2 + 0];
@@ -208,7 +210,7 @@ inline Split4 make_split4(int rows, int c) {
     const int cq = c / 4;
     s.CQB = pow2_ge(cq) < 256 ? pow2_ge(cq) : 256;
     s.RG = 256 / s.CQB;
-    int rpb = ceil_div(rows, 1024);
+    int rpb = ceil_div(rows, 256);  // <= 256 partial blocks: the in-launch fold by the last block stays short
     rpb = ceil_div(rpb, s.RG) * s.RG;
     if (rpb < s.RG * 8) rpb = s.RG * 8;
     s.rows_per_block = rpb;
@@ -234,7 +236,10 @@ __device__ __forceinline__ void block_fold(double (&v)[NV], double* sh, int CQB,
 }
 
 __global__ __launch_bounds__(256) void bn_stats_partial4(const float* __restrict__ y, double* __restrict__ part, int rows,
-                                                         int C, int CQB, int rows_per_block) {
+                                                         int C, int CQB, int rows_per_block, unsigned* __restrict__ counter,
+                                                         float eps, float momentum, float* __restrict__ save_mean,
+                                                         float* __restrict__ save_rstd, float* __restrict__ running_mean,
+                                                         float* __restrict__ running_var, long long* __restrict__ nbt) {
     __shared__ double sh[8 * 256];
     const int t = threadIdx.x, RG = 256 / CQB, cl = t % CQB, rg = t / CQB, CQ = C / 4;
     const long r0 = (long)blockIdx.x * rows_per_block, r1 = min((long)rows, r0 + rows_per_block);
@@ -242,13 +247,20 @@ __global__ __launch_bounds__(256) void bn_stats_partial4(const float* __restrict
         const int cq = cb + cl;
         double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (cq < CQ)
-            for (long r = r0 + rg; r < r1; r += RG) {
-                const f32x4 x = *reinterpret_cast<const f32x4*>(y + r * C + cq * 4);
+            for (long r = r0 + rg; r < r1; r += 4 * RG) {  // 4 independent 16-byte loads in flight per lane
+                f32x4 x[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    v[j] += (double)x[j];
-                    v[4 + j] += (double)x[j] * (double)x[j];
+                for (int u = 0; u < 4; ++u) {
+                    const long rr = r + (long)u * RG;
+                    x[u] = rr < r1 ? *reinterpret_cast<const f32x4*>(y + rr * C + cq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[j] += (double)x[u][j];
+                        v[4 + j] += (double)x[u][j] * (double)x[u][j];
+                    }
             }
         block_fold<8>(v, sh, CQB, RG, cl, rg);
         if (rg == 0 && cq < CQ)
@@ -258,13 +270,40 @@ __global__ __launch_bounds__(256) void bn_stats_partial4(const float* __restrict
                 part[((long)blockIdx.x * C + cq * 4 + j) * 2 + 1] = v[4 + j];
             }
     }
+    if (counter == nullptr || !arrive_last(counter, gridDim.x)) return;
+    // last block: one wave per channel folds the block partials (fp64) and publishes mean / rstd / running stats
+    if (nbt && t == 0) nbt[0] += 1;
+    const int lane = t & 63, nblk = gridDim.x;
+    for (int c = t >> 6; c < C; c += 4) {
+        double s = 0.0, q = 0.0;
+        for (int b = lane; b < nblk; b += 64) {
+            s += part[((long)b * C + c) * 2 + 0];
+            q += part[((long)b * C + c) * 2 + 1];
+        }
+        s = wave_sum(s);
+        q = wave_sum(q);
+        if (lane == 0) {
+            const double mean = s / rows;
+            double var = q / rows - mean * mean;
+            if (var < 0.0) var = 0.0;
+            save_mean[c] = (float)mean;
+            save_rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+            if (running_mean) {
+                const double unb = rows > 1 ? var * ((double)rows / (rows - 1)) : var;
+                running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+                running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+            }
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_partial4(const float* __restrict__ dout, const float* __restrict__ y,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        double* __restrict__ part, int rows, int C, int CQB,
-                                                       int rows_per_block, int act, float slope) {
+                                                       int rows_per_block, int act, float slope,
+                                                       unsigned* __restrict__ counter, float* __restrict__ sums,
+                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
     __shared__ double sh[8 * 256];
     const int t = threadIdx.x, RG = 256 / CQB, cl = t % CQB, rg = t / CQB, CQ = C / 4;
     const long r0 = (long)blockIdx.x * rows_per_block, r1 = min((long)rows, r0 + rows_per_block);
@@ -274,17 +313,25 @@ __global__ __launch_bounds__(256) void bn_bwd_partial4(const float* __restrict__
         if (cq < CQ) {
             const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + cq * 4), rs = *reinterpret_cast<const f32x4*>(rstd + cq * 4);
             const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + cq * 4), be = *reinterpret_cast<const f32x4*>(beta + cq * 4);
-            for (long r = r0 + rg; r < r1; r += RG) {
-                const f32x4 yy = *reinterpret_cast<const f32x4*>(y + r * C + cq * 4);
-                const f32x4 go = *reinterpret_cast<const f32x4*>(dout + r * C + cq * 4);
+            for (long r = r0 + rg; r < r1; r += 4 * RG) {  // 8 independent 16-byte loads in flight per lane
+                f32x4 yy[4], go[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float xh = (yy[j] - mu[j]) * rs[j];
-                    const float o = apply_act(xh * ga[j] + be[j], act, slope);
-                    const float dz = go[j] * act_grad_from_out(o, act, slope);
-                    v[j] += (double)dz;
-                    v[4 + j] += (double)dz * (double)xh;
+                for (int u = 0; u < 4; ++u) {
+                    const long rr = r + (long)u * RG;
+                    const bool ok = rr < r1;
+                    yy[u] = ok ? *reinterpret_cast<const f32x4*>(y + rr * C + cq * 4) : mu;
+                    go[u] = ok ? *reinterpret_cast<const f32x4*>(dout + rr * C + cq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float xh = (yy[u][j] - mu[j]) * rs[j];
+                        const float o = apply_act(xh * ga[j] + be[j], act, slope);
+                        const float dz = go[u][j] * act_grad_from_out(o, act, slope);
+                        v[j] += (double)dz;
+                        v[4 + j] += (double)dz * (double)xh;
+                    }
             }
         }
         block_fold<8>(v, sh, CQB, RG, cl, rg);
@@ -294,6 +341,23 @@ __global__ __launch_bounds__(256) void bn_bwd_partial4(const float* __restrict__
                 part[((long)blockIdx.x * C + cq * 4 + j) * 2 + 0] = v[j];
                 part[((long)blockIdx.x * C + cq * 4 + j) * 2 + 1] = v[4 + j];
             }
+    }
+    if (counter == nullptr || !arrive_last(counter, gridDim.x)) return;
+    const int lane = t & 63, nblk = gridDim.x;
+    for (int c = t >> 6; c < C; c += 4) {
+        double s = 0.0, q = 0.0;
+        for (int b = lane; b < nblk; b += 64) {
+            s += part[((long)b * C + c) * 2 + 0];
+            q += part[((long)b * C + c) * 2 + 1];
+        }
+        s = wave_sum(s);
+        q = wave_sum(q);
+        if (lane == 0) {
+            sums[2 * c + 0] = (float)(s / rows);
+            sums[2 * c + 1] = (float)(q / rows);
+            if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)q : (float)q;
+            if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s : (float)s;
+        }
     }
 }
 
@@ -318,9 +382,219 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4(const float* __restrict__ d
     }
 }
 
+// ---- one-launch BatchNorm for short tensors ----------------------------------------------------------------------
+// rows <= small_rows(): a block owns 16 adjacent channels (one 64-byte segment of every row), walks all rows twice
+// (statistics, then apply; the second walk hits L2) and needs no partial buffer, no second and third launch.  The
+// step's deep layers (rows = batch * 16 ... batch) are launch-latency bound, not bandwidth bound.
+__device__ __forceinline__ double quad_col_sum(double v) {  // sum over the 16 lanes of a wave that share (lane & 3)
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+// v[8] per thread -> s[16], q[16] per block (thread t < 16 returns its channel's pair)
+__device__ __forceinline__ void small_fold(double (&v)[8], double (*sh)[4][8], int t, double& s, double& q) {
+    const int cl = t & 3, wave = t >> 6;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = quad_col_sum(v[j]);
+    if ((t & 63) < 4)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sh[wave][cl][j] = v[j];
+    __syncthreads();
+    s = q = 0.0;
+    if (t < 16)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            s += sh[w][t >> 2][t & 3];
+            q += sh[w][t >> 2][4 + (t & 3)];
+        }
+}
+
+__global__ __launch_bounds__(256) void bn_fwd_small(const float* __restrict__ y, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, float* __restrict__ out,
+                                                    float* __restrict__ save_mean, float* __restrict__ save_rstd,
+                                                    float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                    long long* __restrict__ nbt, int rows, int C, float eps, float momentum,
+                                                    int act, float slope) {
+    __shared__ double sh[4][4][8];
+    __shared__ float stat[2][16];
+    const int t = threadIdx.x, cl = t & 3, rg = t >> 2;
+    const int c0 = blockIdx.x * 16 + cl * 4;
+    const bool ok = c0 < C;
+    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (ok)
+        for (int r = rg; r < rows; r += 256) {
+            f32x4 x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int rr = r + u * 64;
+                x[u] = rr < rows ? *reinterpret_cast<const f32x4*>(y + (long)rr * C + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] += (double)x[u][j];
+                    v[4 + j] += (double)x[u][j] * (double)x[u][j];
+                }
+        }
+    double s, q;
+    small_fold(v, sh, t, s, q);
+    if (t < 16) {
+        const int c = blockIdx.x * 16 + t;
+        if (c < C) {
+            const double mean = s / rows;
+            double var = q / rows - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float m = (float)mean, rs = (float)(1.0 / sqrt(var + (double)eps));
+            save_mean[c] = m;
+            save_rstd[c] = rs;
+            stat[0][t] = m;
+            stat[1][t] = rs;
+            if (running_mean) {
+                const double unb = rows > 1 ? var * ((double)rows / (rows - 1)) : var;
+                running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+                running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+            }
+        }
+        if (nbt && blockIdx.x == 0 && t == 0) nbt[0] += 1;
+    }
+    __syncthreads();
+    if (!ok) return;
+    f32x4 sc, sf;  // out = y * sc + sf
+    {
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0), be = *reinterpret_cast<const f32x4*>(beta + c0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sc[j] = stat[1][cl * 4 + j];  // keep the 3-launch kernels' evaluation order: (y - mean) * rstd * gamma + beta
+            sf[j] = stat[0][cl * 4 + j];
+        }
+        for (int r = rg; r < rows; r += 256) {
+            f32x4 x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int rr = r + u * 64;
+                if (rr < rows) x[u] = *reinterpret_cast<const f32x4*>(y + (long)rr * C + c0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int rr = r + u * 64;
+                if (rr < rows) {
+                    f32x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = apply_act((x[u][j] - sf[j]) * sc[j] * ga[j] + be[j], act, slope);
+                    *reinterpret_cast<f32x4*>(out + (long)rr * C + c0) = o;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_small(const float* __restrict__ dout, const float* __restrict__ y,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                    float* __restrict__ dy, float* __restrict__ dgamma,
+                                                    float* __restrict__ dbeta, int rows, int C, int act, float slope,
+                                                    int accumulate) {
+    __shared__ double sh[4][4][8];
+    __shared__ float stat[2][16];
+    const int t = threadIdx.x, cl = t & 3, rg = t >> 2;
+    const int c0 = blockIdx.x * 16 + cl * 4;
+    const bool ok = c0 < C;
+    f32x4 mu = {0.f, 0.f, 0.f, 0.f}, rs = mu, ga = mu, be = mu;
+    if (ok) {
+        mu = *reinterpret_cast<const f32x4*>(mean + c0);
+        rs = *reinterpret_cast<const f32x4*>(rstd + c0);
+        ga = *reinterpret_cast<const f32x4*>(gamma + c0);
+        be = *reinterpret_cast<const f32x4*>(beta + c0);
+    }
+    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (ok)
+        for (int r = rg; r < rows; r += 256) {
+            f32x4 yy[4], go[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int rr = r + u * 64;
+                const bool in = rr < rows;
+                yy[u] = in ? *reinterpret_cast<const f32x4*>(y + (long)rr * C + c0) : mu;
+                go[u] = in ? *reinterpret_cast<const f32x4*>(dout + (long)rr * C + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xh = (yy[u][j] - mu[j]) * rs[j];
+                    const float o = apply_act(xh * ga[j] + be[j], act, slope);
+                    const float dz = go[u][j] * act_grad_from_out(o, act, slope);
+                    v[j] += (double)dz;
+                    v[4 + j] += (double)dz * (double)xh;
+                }
+        }
+    double s, q;
+    small_fold(v, sh, t, s, q);
+    if (t < 16) {
+        const int c = blockIdx.x * 16 + t;
+        if (c < C) {
+            stat[0][t] = (float)(s / rows);
+            stat[1][t] = (float)(q / rows);
+            if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)q : (float)q;
+            if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s : (float)s;
+        }
+    }
+    __syncthreads();
+    if (!ok) return;
+    f32x4 m1, m2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        m1[j] = stat[0][cl * 4 + j];
+        m2[j] = stat[1][cl * 4 + j];
+    }
+    for (int r = rg; r < rows; r += 256) {
+        f32x4 yy[4], go[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = r + u * 64;
+            if (rr < rows) {
+                yy[u] = *reinterpret_cast<const f32x4*>(y + (long)rr * C + c0);
+                go[u] = *reinterpret_cast<const f32x4*>(dout + (long)rr * C + c0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = r + u * 64;
+            if (rr < rows) {
+                f32x4 o4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xh = (yy[u][j] - mu[j]) * rs[j];
+                    const float o = apply_act(xh * ga[j] + be[j], act, slope);
+                    const float dz = go[u][j] * act_grad_from_out(o, act, slope);
+                    o4[j] = ga[j] * rs[j] * (dz - m1[j] - xh * m2[j]);
+                }
+                *reinterpret_cast<f32x4*>(dy + (long)rr * C + c0) = o4;
+            }
+        }
+    }
+}
+
+inline int small_rows() {  // MOVAE_BN_SMALL_ROWS: largest row count served by the one-launch kernels (0 disables them)
+    static const int v = getenv("MOVAE_BN_SMALL_ROWS") ? atoi(getenv("MOVAE_BN_SMALL_ROWS")) : 4096;
+    return v;
+}
+
 inline int grid_for(long total) {
     long g = (total + 255) / 256;
     return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+
+// The "last block folds the partials" variant (arrive_last) is kept for experiments only: measured on MI355X
+// it is SLOWER than a second tiny launch for these kernels (C2 step 3.2 ms vs 2.25 ms) because every block pays
+// an agent-scope release (L2 write-back) while the conv outputs are still dirty in L2.  MOVAE_INLAUNCH=1 enables it.
+inline bool in_launch_final() {
+    static const bool v = getenv("MOVAE_INLAUNCH") != nullptr;
+    return v;
 }
 
 inline bool al16(const void* a, const void* b = nullptr, const void* c = nullptr) {
@@ -334,32 +608,45 @@ extern "C" {
 size_t movae_bn_ws_bytes(int rows, int c) {
     if (rows <= 0 || c <= 0) return 0;
     const int nblk = (c % 4 == 0) ? make_split4(rows, c).nblk : make_split(rows, c).nblk;
-    return (size_t)nblk * c * 2 * sizeof(double) + (size_t)c * 2 * sizeof(float) + 64;
+    return MOVAE_WS_HEADER_BYTES + (size_t)nblk * c * 2 * sizeof(double) + (size_t)c * 2 * sizeof(float) + 64;
 }
 
 int movae_bn_act_fwd(const float* y, const float* gamma, const float* beta, float* out, float* save_mean, float* save_rstd,
-                     float* running_mean, float* running_var, int rows, int c, float eps, float momentum, int training,
-                     int act, float slope, void* ws, size_t ws_bytes, movae_stream_t stream) {
+                     float* running_mean, float* running_var, long long* num_batches_tracked, int rows, int c, float eps,
+                     float momentum, int training, int act, float slope, void* ws, size_t ws_bytes, movae_stream_t stream) {
     MOVAE_CHECK_ARG(y && gamma && beta && out && save_mean && save_rstd, "movae_bn_act_fwd: null pointer");
     MOVAE_CHECK_ARG(rows > 0 && c > 0, "movae_bn_act_fwd: bad shape rows=%d c=%d", rows, c);
     hipStream_t st = (hipStream_t)stream;
+    long long* nbt = training ? num_batches_tracked : nullptr;
+    if (training && rows <= small_rows() && c % 4 == 0 && al16(y, out) && al16(gamma, beta)) {
+        hipLaunchKernelGGL(bn_fwd_small, dim3(ceil_div(c, 16)), dim3(256), 0, st, y, gamma, beta, out, save_mean, save_rstd,
+                           running_mean, running_var, nbt, rows, c, eps, momentum, act, slope);
+        MOVAE_CHECK_LAUNCH("bn_fwd_small");
+        return MOVAE_OK;
+    }
     if (training) {
         MOVAE_CHECK_ARG(ws && ws_bytes >= movae_bn_ws_bytes(rows, c), "movae_bn_act_fwd: workspace too small");
-        double* part = static_cast<double*>(ws);
+        unsigned* counter = static_cast<unsigned*>(ws);
+        double* part = reinterpret_cast<double*>(static_cast<char*>(ws) + MOVAE_WS_HEADER_BYTES);
         int nblk;
         if (c % 4 == 0 && al16(y)) {
             const Split4 s = make_split4(rows, c);
-            nblk = s.nblk;
-            hipLaunchKernelGGL(bn_stats_partial4, dim3(s.nblk), dim3(256), 0, st, y, part, rows, c, s.CQB, s.rows_per_block);
+            hipLaunchKernelGGL(bn_stats_partial4, dim3(s.nblk), dim3(256), 0, st, y, part, rows, c, s.CQB, s.rows_per_block,
+                               in_launch_final() ? counter : nullptr, eps, momentum, save_mean, save_rstd, running_mean,
+                               running_var, nbt);
+            MOVAE_CHECK_LAUNCH("bn_stats_partial4");
+            nblk = in_launch_final() ? 0 : s.nblk;  // 0: statistics finished in-launch by the last block
         } else {
             const Split s = make_split(rows, c);
             nblk = s.nblk;
             hipLaunchKernelGGL(bn_stats_partial, dim3(s.nblk), dim3(256), 0, st, y, part, rows, c, s.CB, s.rows_per_block);
         }
         MOVAE_CHECK_LAUNCH("bn_stats_partial");
-        hipLaunchKernelGGL(bn_stats_final, dim3(c), dim3(64), 0, st, part, nblk, rows, c, eps, momentum,
-                           save_mean, save_rstd, running_mean, running_var);
-        MOVAE_CHECK_LAUNCH("bn_stats_final");
+        if (nblk > 0) {
+            hipLaunchKernelGGL(bn_stats_final, dim3(c), dim3(64), 0, st, part, nblk, rows, c, eps, momentum, save_mean,
+                               save_rstd, running_mean, running_var, nbt);
+            MOVAE_CHECK_LAUNCH("bn_stats_final");
+        }
     } else {
         MOVAE_CHECK_ARG(running_mean && running_var, "movae_bn_act_fwd: eval mode needs running statistics");
         hipLaunchKernelGGL(bn_eval_prepare, dim3(ceil_div(c, 128)), dim3(128), 0, st, running_mean, running_var, eps,
@@ -383,16 +670,26 @@ int movae_bn_act_bwd(const float* dout, const float* y, const float* gamma, cons
                      int accumulate, void* ws, size_t ws_bytes, movae_stream_t stream) {
     MOVAE_CHECK_ARG(dout && y && gamma && beta && save_mean && save_rstd && dy, "movae_bn_act_bwd: null pointer");
     MOVAE_CHECK_ARG(rows > 0 && c > 0, "movae_bn_act_bwd: bad shape rows=%d c=%d", rows, c);
+    if (rows <= small_rows() && c % 4 == 0 && al16(dout, y, dy) && al16(gamma, beta) && al16(save_mean, save_rstd)) {
+        hipLaunchKernelGGL(bn_bwd_small, dim3(ceil_div(c, 16)), dim3(256), 0, (hipStream_t)stream, dout, y, gamma, beta, save_mean,
+                           save_rstd, dy, dgamma, dbeta, rows, c, act, slope, accumulate);
+        MOVAE_CHECK_LAUNCH("bn_bwd_small");
+        return MOVAE_OK;
+    }
     MOVAE_CHECK_ARG(ws && ws_bytes >= movae_bn_ws_bytes(rows, c), "movae_bn_act_bwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    double* part = static_cast<double*>(ws);
+    unsigned* counter = static_cast<unsigned*>(ws);
+    double* part = reinterpret_cast<double*>(static_cast<char*>(ws) + MOVAE_WS_HEADER_BYTES);
     const bool vec = c % 4 == 0 && al16(dout, y, dy) && al16(gamma, beta) && al16(save_mean, save_rstd);
     int nblk;
+    float* sums;
     if (vec) {
         const Split4 s = make_split4(rows, c);
         nblk = s.nblk;
+        sums = reinterpret_cast<float*>(part + (size_t)nblk * c * 2);
         hipLaunchKernelGGL(bn_bwd_partial4, dim3(s.nblk), dim3(256), 0, st, dout, y, gamma, beta, save_mean, save_rstd, part,
-                           rows, c, s.CQB, s.rows_per_block, act, slope);
+                           rows, c, s.CQB, s.rows_per_block, act, slope, in_launch_final() ? counter : nullptr, sums, dgamma,
+                           dbeta, accumulate);
     } else {
         const Split s = make_split(rows, c);
         nblk = s.nblk;
@@ -400,9 +697,11 @@ int movae_bn_act_bwd(const float* dout, const float* y, const float* gamma, cons
                            rows, c, s.CB, s.rows_per_block, act, slope);
     }
     MOVAE_CHECK_LAUNCH("bn_bwd_partial");
-    float* sums = reinterpret_cast<float*>(part + (size_t)nblk * c * 2);
-    hipLaunchKernelGGL(bn_bwd_final, dim3(c), dim3(64), 0, st, part, nblk, rows, c, sums, dgamma, dbeta, accumulate);
-    MOVAE_CHECK_LAUNCH("bn_bwd_final");
+    if (!vec || !in_launch_final()) {
+        sums = reinterpret_cast<float*>(part + (size_t)nblk * c * 2);
+        hipLaunchKernelGGL(bn_bwd_final, dim3(c), dim3(64), 0, st, part, nblk, rows, c, sums, dgamma, dbeta, accumulate);
+        MOVAE_CHECK_LAUNCH("bn_bwd_final");
+    }
     const long total = (long)rows * c;
     if (vec)
         hipLaunchKernelGGL(bn_bwd_apply4, dim3(grid_for(total / 4)), dim3(256), 0, st, dout, y, gamma, beta, save_mean, save_rstd,

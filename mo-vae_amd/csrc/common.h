@@ -68,6 +68,47 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// ---- in-launch "last block finishes" hand-off ---------------------------------------------------------
+// Two-stage reductions write per-block partials and let the LAST block to arrive fold them, instead of a
+// second launch (a dependent kernel boundary costs ~1.5-2 us plus the tiny kernel itself).  Placement
+// independent: every storing wave drains its stores, one lane publishes with an agent-scope release before
+// the ticket, the last arriver takes an agent-scope acquire before any wave of its block reads the partials
+// (cdna_hip_programming.md Guideline 16, counter form).  The counter word lives in the caller's workspace
+// header (MOVAE_WS_HEADER_BYTES, zero on first use) and is re-armed to zero by the last block.
+#define MOVAE_WS_HEADER_BYTES 4096
+
+// plain-scratch users skip the counter header so it stays zero between the launches that use it
+#define MOVAE_WS_SCRATCH(ws, ws_bytes)                                         \
+    do {                                                                       \
+        if ((ws) && (ws_bytes) > (size_t)MOVAE_WS_HEADER_BYTES) {              \
+            (ws) = static_cast<char*>(ws) + MOVAE_WS_HEADER_BYTES;             \
+            (ws_bytes) -= MOVAE_WS_HEADER_BYTES;                               \
+        } else {                                                               \
+            (ws) = nullptr;                                                    \
+            (ws_bytes) = 0;                                                    \
+        }                                                                      \
+    } while (0)
+
+__device__ __forceinline__ bool arrive_last(unsigned* counter, unsigned nblk) {
+    __shared__ unsigned s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned last = ticket == nblk - 1 ? 1u : 0u;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    return s_last != 0;
+}
+
 // block-wide sum for 256-thread blocks; result valid in every thread
 __device__ __forceinline__ double block_sum_256(double v, double* sh /* >= 4 doubles */) {
     v = wave_sum(v);

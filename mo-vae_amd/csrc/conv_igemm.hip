@@ -498,8 +498,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_flat(const float* __restric
     }
 }
 
+const char* g_last_kernel = "";  // movae_bench_last_kernel(): main kernel chosen by the most recent conv-family dispatch
+bool g_bench_main_only = false;  // movae_bench_main_kernel_only(): time the MFMA kernel without its epilogue launches
+
 inline int launch_reduce(const float* slab, float* out, long total, int S, int N, const float* bias, int act, float slope,
                          int accumulate, hipStream_t st) {
+    if (g_bench_main_only) return MOVAE_OK;
     if (S >= 8 && total <= (1L << 20)) {
         hipLaunchKernelGGL(splitk_reduce, dim3(ceil_div(total, 16)), dim3(256), 0, st, slab, out, total, S, N, bias, act, slope,
                            accumulate);
@@ -535,6 +539,11 @@ inline int choose_split(long tiles, int nk, size_t per_slab_bytes, size_t ws_byt
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+inline long big_tile_min() {  // minimum number of 128x128 work items before the big tile is preferred
+    static const long v = getenv("MOVAE_BIG_TILE_MIN") ? atol(getenv("MOVAE_BIG_TILE_MIN")) : 256;
+    return v;
+}
+
 template <int BM, int BN>
 int launch_fwd_t(const float* X, const float* W, float* Y, const Geom& g, const Epilogue& ep, int M, int K, bool vec,
                  void* ws, size_t ws_bytes, hipStream_t st) {
@@ -567,17 +576,19 @@ int launch_fwd(const float* X, const float* W, float* Y, const Geom& g, const Ep
         return MOVAE_EINVAL;
     }
     const int M = (int)Ml, K = (int)Kl;
-    if (thin::thin_in_ok(g)) return thin::launch_thin_in<false>(X, W, Y, g, ep, st);
-    if (thin::thin_out_ok(g, X)) return thin::launch_thin_out_fwd(X, W, Y, g, ep, st);
+    if (thin::thin_in_ok(g)) return (g_last_kernel = "thin_in_k<fwd>", thin::launch_thin_in<false>(X, W, Y, g, ep, st));
+    if (thin::thin_out_ok(g, X)) return (g_last_kernel = "thin_out_fwd_k", thin::launch_thin_out_fwd(X, W, Y, g, ep, st));
     if (g.Cr % 4 == 0 && aligned16(X) && aligned16(W)) {  // fast path (igemm_v2.h)
-        if (g.Nn <= 32) return v2::launch_fwd2<128, 32>(X, W, Y, g, ep, M, K, ws, ws_bytes, st);
-        if (Ml >= 128 * 512) return v2::launch_fwd2<128, 64>(X, W, Y, g, ep, M, K, ws, ws_bytes, st);
-        return v2::launch_fwd2<64, 64>(X, W, Y, g, ep, M, K, ws, ws_bytes, st);
+        if (g.Nn <= 32) return (g_last_kernel = "igemm2_fwd<128,32>", v2::launch_fwd2<128, 32>(X, W, Y, g, ep, M, K, ws, ws_bytes, st));
+        // 2x2 register tiling (64x64 per wave) once the 128x128 grid alone fills the chip
+        if (g.Nn >= 128 && (Ml / 128) * (g.Nn / 128) >= big_tile_min()) return (g_last_kernel = "igemm2_fwd<128,128>", v2::launch_fwd2<128, 128>(X, W, Y, g, ep, M, K, ws, ws_bytes, st));
+        if (Ml >= 128 * 512) return (g_last_kernel = "igemm2_fwd<128,64>", v2::launch_fwd2<128, 64>(X, W, Y, g, ep, M, K, ws, ws_bytes, st));
+        return (g_last_kernel = "igemm2_fwd<64,64>", v2::launch_fwd2<64, 64>(X, W, Y, g, ep, M, K, ws, ws_bytes, st));
     }
     const bool vec = (g.Cr % BK == 0) && aligned16(X) && aligned16(W);
-    if (g.Nn <= 32) return launch_fwd_t<128, 32>(X, W, Y, g, ep, M, K, vec, ws, ws_bytes, st);
-    if (Ml >= 128 * 512) return launch_fwd_t<128, 64>(X, W, Y, g, ep, M, K, vec, ws, ws_bytes, st);
-    return launch_fwd_t<64, 64>(X, W, Y, g, ep, M, K, vec, ws, ws_bytes, st);
+    if (g.Nn <= 32) return (g_last_kernel = "igemm_fwd<128,32>", launch_fwd_t<128, 32>(X, W, Y, g, ep, M, K, vec, ws, ws_bytes, st));
+    if (Ml >= 128 * 512) return (g_last_kernel = "igemm_fwd<128,64>", launch_fwd_t<128, 64>(X, W, Y, g, ep, M, K, vec, ws, ws_bytes, st));
+    return (g_last_kernel = "igemm_fwd<64,64>", launch_fwd_t<64, 64>(X, W, Y, g, ep, M, K, vec, ws, ws_bytes, st));
 }
 
 template <int BM, int BN>
@@ -612,16 +623,18 @@ int launch_bwd(const float* X, const float* W, float* Y, const Geom& g, const Ep
         return MOVAE_EINVAL;
     }
     const long Mc = Ml / (g.stride * g.stride);
-    if (thin::thin_in_ok(g)) return thin::launch_thin_in<true>(X, W, Y, g, ep, st);
+    if (thin::thin_in_ok(g)) return (g_last_kernel = "thin_in_k<bwd>", thin::launch_thin_in<true>(X, W, Y, g, ep, st));
     if (g.Cr % 4 == 0 && g.Nn % 4 == 0 && aligned16(X) && aligned16(W)) {  // fast path (igemm_v2.h)
-        if (g.Nn <= 32) return v2::launch_bwd2<128, 32>(X, W, Y, g, ep, ws, ws_bytes, st);
-        if (Mc >= 128 * 512) return v2::launch_bwd2<128, 64>(X, W, Y, g, ep, ws, ws_bytes, st);
-        return v2::launch_bwd2<64, 64>(X, W, Y, g, ep, ws, ws_bytes, st);
+        if (g.Nn <= 32) return (g_last_kernel = "igemm2_bwd<128,32>", v2::launch_bwd2<128, 32>(X, W, Y, g, ep, ws, ws_bytes, st));
+        if (g.Nn >= 128 && (Mc / 128) * (g.Nn / 128) * g.stride * g.stride >= big_tile_min())
+            return (g_last_kernel = "igemm2_bwd<128,128>", v2::launch_bwd2<128, 128>(X, W, Y, g, ep, ws, ws_bytes, st));
+        if (Mc >= 128 * 512) return (g_last_kernel = "igemm2_bwd<128,64>", v2::launch_bwd2<128, 64>(X, W, Y, g, ep, ws, ws_bytes, st));
+        return (g_last_kernel = "igemm2_bwd<64,64>", v2::launch_bwd2<64, 64>(X, W, Y, g, ep, ws, ws_bytes, st));
     }
     const bool vec = (g.Cr % BK == 0) && (g.Nn % 4 == 0) && aligned16(X) && aligned16(W);
-    if (g.Nn <= 32) return launch_bwd_t<128, 32>(X, W, Y, g, ep, vec, ws, ws_bytes, st);
-    if (Mc >= 128 * 512) return launch_bwd_t<128, 64>(X, W, Y, g, ep, vec, ws, ws_bytes, st);
-    return launch_bwd_t<64, 64>(X, W, Y, g, ep, vec, ws, ws_bytes, st);
+    if (g.Nn <= 32) return (g_last_kernel = "igemm_bwd<128,32>", launch_bwd_t<128, 32>(X, W, Y, g, ep, vec, ws, ws_bytes, st));
+    if (Mc >= 128 * 512) return (g_last_kernel = "igemm_bwd<128,64>", launch_bwd_t<128, 64>(X, W, Y, g, ep, vec, ws, ws_bytes, st));
+    return (g_last_kernel = "igemm_bwd<64,64>", launch_bwd_t<64, 64>(X, W, Y, g, ep, vec, ws, ws_bytes, st));
 }
 
 template <int BM, int BN>
@@ -666,13 +679,15 @@ int launch_wgrad(const float* S, const float* Bg, float* dW, const WGeom& g, int
     }
     const int vec = ((g.Cs % 4 == 0 && aligned16(S)) ? 1 : 0) | ((g.Cb % 4 == 0 && aligned16(Bg)) ? 2 : 0);
     const int N = g.KH * g.KW * g.Cb;
-    if (thin::thin_wgrad_ok(g) && ws) return thin::launch_thin_wgrad(S, Bg, dW, g, (int)Kl, accumulate, ws, ws_bytes, st);
+    if (thin::thin_wgrad_ok(g) && ws) return (g_last_kernel = "thin_wgrad", thin::launch_thin_wgrad(S, Bg, dW, g, (int)Kl, accumulate, ws, ws_bytes, st));
     if (vec == 3) {  // fast path (igemm_v2.h)
-        if (N <= 32) return v2::launch_wgrad2<128, 32>(S, Bg, dW, g, (int)Kl, accumulate, ws, ws_bytes, st);
-        return v2::launch_wgrad2<64, 64>(S, Bg, dW, g, (int)Kl, accumulate, ws, ws_bytes, st);
+        if (N <= 32) return (g_last_kernel = "igemm2_wgrad<128,32>", v2::launch_wgrad2<128, 32>(S, Bg, dW, g, (int)Kl, accumulate, ws, ws_bytes, st));
+        if (g.Cs >= 128 && (long)(g.Cs / 128) * (N / 128) * (Kl / 512) >= big_tile_min())
+            return (g_last_kernel = "igemm2_wgrad<128,128>", v2::launch_wgrad2<128, 128>(S, Bg, dW, g, (int)Kl, accumulate, ws, ws_bytes, st));
+        return (g_last_kernel = "igemm2_wgrad<64,64>", v2::launch_wgrad2<64, 64>(S, Bg, dW, g, (int)Kl, accumulate, ws, ws_bytes, st));
     }
-    if (N <= 32) return launch_wgrad_t<128, 32>(S, Bg, dW, g, (int)Kl, vec, accumulate, ws, ws_bytes, st);
-    return launch_wgrad_t<64, 64>(S, Bg, dW, g, (int)Kl, vec, accumulate, ws, ws_bytes, st);
+    if (N <= 32) return (g_last_kernel = "igemm_wgrad<128,32>", launch_wgrad_t<128, 32>(S, Bg, dW, g, (int)Kl, vec, accumulate, ws, ws_bytes, st));
+    return (g_last_kernel = "igemm_wgrad<64,64>", launch_wgrad_t<64, 64>(S, Bg, dW, g, (int)Kl, vec, accumulate, ws, ws_bytes, st));
 }
 
 int check_conv_shape(const char* who, int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride,
@@ -703,9 +718,18 @@ int check_conv_shape(const char* who, int n, int hi, int wi, int ci, int ho, int
 
 extern "C" {
 
+const char* movae_bench_last_kernel(void) { return g_last_kernel; }
+
+int movae_bench_main_kernel_only(int on) {
+    const int prev = g_bench_main_only ? 1 : 0;
+    g_bench_main_only = on != 0;
+    return prev;
+}
+
 int movae_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int n, int hi, int wi, int ci, int ho,
                      int wo, int co, int kh, int kw, int stride, int pad, int act, float slope, void* ws, size_t ws_bytes,
                      movae_stream_t stream) {
+    MOVAE_WS_SCRATCH(ws, ws_bytes);
     MOVAE_CHECK_ARG(x && w && y, "movae_conv2d_fwd: null pointer");
     if (int rc = check_conv_shape("movae_conv2d_fwd", n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, false)) return rc;
     Geom g{n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad};
@@ -714,6 +738,7 @@ int movae_conv2d_fwd(const float* x, const float* w, const float* bias, float* y
 
 int movae_conv2d_dgrad(const float* dy, const float* w, float* dx, int n, int hi, int wi, int ci, int ho, int wo, int co,
                        int kh, int kw, int stride, int pad, void* ws, size_t ws_bytes, movae_stream_t stream) {
+    MOVAE_WS_SCRATCH(ws, ws_bytes);
     MOVAE_CHECK_ARG(dy && w && dx, "movae_conv2d_dgrad: null pointer");
     if (int rc = check_conv_shape("movae_conv2d_dgrad", n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, false)) return rc;
     // gathered tensor = dy (ho x wo x co), output grid = dx (hi x wi x ci); W[co][tap][ci] is the [Cr][tap][Nn] image
@@ -724,17 +749,21 @@ int movae_conv2d_dgrad(const float* dy, const float* w, float* dx, int n, int hi
 int movae_conv2d_wgrad(const float* dy, const float* x, float* dw, float* dbias, int n, int hi, int wi, int ci, int ho,
                        int wo, int co, int kh, int kw, int stride, int pad, int accumulate, void* ws, size_t ws_bytes,
                        movae_stream_t stream) {
+    void* ws_full = ws;
+    const size_t ws_full_bytes = ws_bytes;
+    MOVAE_WS_SCRATCH(ws, ws_bytes);
     MOVAE_CHECK_ARG(dy && x && dw, "movae_conv2d_wgrad: null pointer");
     if (int rc = check_conv_shape("movae_conv2d_wgrad", n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, false)) return rc;
     WGeom g{n, ho, wo, co, hi, wi, ci, kh, kw, stride, pad};
     if (int rc = launch_wgrad(dy, x, dw, g, accumulate, ws, ws_bytes, (hipStream_t)stream)) return rc;
-    if (dbias) return movae_colsum(dy, dbias, n * ho * wo, co, accumulate, ws, ws_bytes, stream);
+    if (dbias && !g_bench_main_only) return movae_colsum(dy, dbias, n * ho * wo, co, accumulate, ws_full, ws_full_bytes, stream);
     return MOVAE_OK;
 }
 
 int movae_convT2d_fwd(const float* x, const float* w, const float* bias, float* y, int n, int hi, int wi, int ci, int ho,
                       int wo, int co, int kh, int kw, int stride, int pad, int act, float slope, void* ws, size_t ws_bytes,
                       movae_stream_t stream) {
+    MOVAE_WS_SCRATCH(ws, ws_bytes);
     MOVAE_CHECK_ARG(x && w && y, "movae_convT2d_fwd: null pointer");
     if (int rc = check_conv_shape("movae_convT2d_fwd", n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, true)) return rc;
     Geom g{n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad};
@@ -743,6 +772,7 @@ int movae_convT2d_fwd(const float* x, const float* w, const float* bias, float* 
 
 int movae_convT2d_dgrad(const float* dy, const float* w, float* dx, int n, int hi, int wi, int ci, int ho, int wo, int co,
                         int kh, int kw, int stride, int pad, void* ws, size_t ws_bytes, movae_stream_t stream) {
+    MOVAE_WS_SCRATCH(ws, ws_bytes);
     MOVAE_CHECK_ARG(dy && w && dx, "movae_convT2d_dgrad: null pointer");
     if (int rc = check_conv_shape("movae_convT2d_dgrad", n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, true)) return rc;
     // dx[p][ci] = sum dy[p*s - pad + tap][co] * W[ci][tap][co]  : FWD form over dy with W as [Nn=ci][tap][Cr=co]
@@ -753,11 +783,14 @@ int movae_convT2d_dgrad(const float* dy, const float* w, float* dx, int n, int h
 int movae_convT2d_wgrad(const float* dy, const float* x, float* dw, float* dbias, int n, int hi, int wi, int ci, int ho,
                         int wo, int co, int kh, int kw, int stride, int pad, int accumulate, void* ws, size_t ws_bytes,
                         movae_stream_t stream) {
+    void* ws_full = ws;
+    const size_t ws_full_bytes = ws_bytes;
+    MOVAE_WS_SCRATCH(ws, ws_bytes);
     MOVAE_CHECK_ARG(dy && x && dw, "movae_convT2d_wgrad: null pointer");
     if (int rc = check_conv_shape("movae_convT2d_wgrad", n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, true)) return rc;
     WGeom g{n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad};
     if (int rc = launch_wgrad(x, dy, dw, g, accumulate, ws, ws_bytes, (hipStream_t)stream)) return rc;
-    if (dbias) return movae_colsum(dy, dbias, n * ho * wo, co, accumulate, ws, ws_bytes, stream);
+    if (dbias && !g_bench_main_only) return movae_colsum(dy, dbias, n * ho * wo, co, accumulate, ws_full, ws_full_bytes, stream);
     return MOVAE_OK;
 }
 

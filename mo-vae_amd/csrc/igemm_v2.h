@@ -27,37 +27,44 @@ constexpr int RPP = 256 / CPR;        // rows staged per pass of the 256 threads
 
 template <int BM, int BN>
 struct T2 {
-    static constexpr int WN = BN / 32;
-    static constexpr int WM = 4 / WN;
-    static constexpr int TM = BM / (WM * 32);
-    static constexpr int LDKA = BM + 4;  // k-major leading dims
+    static constexpr int WN = BN >= 64 ? 2 : 1;  // waves along N
+    static constexpr int WM = 4 / WN;            // waves along M
+    static constexpr int TM = BM / (WM * 32);    // 32x32 accumulators per wave along M ...
+    static constexpr int TN = BN / (WN * 32);    // ... and along N (2x2 = 64x64 per wave for the 128x128 tile)
+    static constexpr int LDKA = BM + 4;          // k-major leading dims
     static constexpr int LDKB = BN + 4;
-    static_assert(TM >= 1, "tile");
+    static constexpr bool DB = (BM + BN) <= 192; // double-buffered LDS stages while they fit in 64 KiB
+    static_assert(TM >= 1 && TN >= 1, "tile");
 };
 
 // A row-major, B row-major (FWD)
-template <int TM, int PART>  // PART 0/1: first / second half of the stage's k range
+template <int TM, int TN, int PART>  // PART 0/1: first / second half of the stage's k range
 __device__ __forceinline__ void mma_rr(const float* __restrict__ As, const float* __restrict__ Bs, int a_row, int b_row,
-                                       f32x16 (&acc)[TM]) {
+                                       f32x16 (&acc)[TM * TN]) {
     const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
 #pragma unroll
     for (int jj = PART * (HK / 8); jj < (PART + 1) * (HK / 8); ++jj) {
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(Bs + (b_row + l31) * LDR + half * HK + jj * 4);
-        f32x4 a4[TM];
+        f32x4 a4[TM], b4[TN];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+            b4[tn] = *reinterpret_cast<const f32x4*>(Bs + (b_row + tn * 32 + l31) * LDR + half * HK + jj * 4);
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
             a4[tm] = *reinterpret_cast<const f32x4*>(As + (a_row + tm * 32 + l31) * LDR + half * HK + jj * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[tm][e], b4[e], acc[tm], 0, 0, 0);
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm * TN + tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[tm][e], b4[tn][e], acc[tm * TN + tn], 0, 0, 0);
     }
 }
 
 // A row-major, B k-major (BWD)
-template <int TM, int PART>
+template <int TM, int TN, int PART>
 __device__ __forceinline__ void mma_rk(const float* __restrict__ As, const float* __restrict__ Bs, int ldb, int a_row,
-                                       int b_col, f32x16 (&acc)[TM]) {
+                                       int b_col, f32x16 (&acc)[TM * TN]) {
     const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
 #pragma unroll
     for (int jj = PART * (HK / 8); jj < (PART + 1) * (HK / 8); ++jj) {
@@ -67,26 +74,35 @@ __device__ __forceinline__ void mma_rk(const float* __restrict__ As, const float
             a4[tm] = *reinterpret_cast<const f32x4*>(As + (a_row + tm * 32 + l31) * LDR + half * HK + jj * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float b = Bs[(half * HK + jj * 4 + e) * ldb + b_col + l31];
+            float b[TN];
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[tm][e], b, acc[tm], 0, 0, 0);
+            for (int tn = 0; tn < TN; ++tn) b[tn] = Bs[(half * HK + jj * 4 + e) * ldb + b_col + tn * 32 + l31];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm * TN + tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[tm][e], b[tn], acc[tm * TN + tn], 0, 0, 0);
         }
     }
 }
 
 // A k-major, B k-major (WGRAD)
-template <int TM, int PART>
+template <int TM, int TN, int PART>
 __device__ __forceinline__ void mma_kk(const float* __restrict__ As, const float* __restrict__ Bs, int lda, int ldb,
-                                       int a_col, int b_col, f32x16 (&acc)[TM]) {
+                                       int a_col, int b_col, f32x16 (&acc)[TM * TN]) {
     const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
 #pragma unroll
     for (int j = PART * (HK / 2); j < (PART + 1) * (HK / 2); ++j) {
-        const float b = Bs[(half * HK + j) * ldb + b_col + l31];
+        float a[TM], b[TN];
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            const float a = As[(half * HK + j) * lda + a_col + tm * 32 + l31];
-            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[tm], 0, 0, 0);
-        }
+        for (int tn = 0; tn < TN; ++tn) b[tn] = Bs[(half * HK + j) * ldb + b_col + tn * 32 + l31];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) a[tm] = As[(half * HK + j) * lda + a_col + tm * 32 + l31];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                acc[tm * TN + tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm * TN + tn], 0, 0, 0);
     }
 }
 
@@ -99,8 +115,8 @@ __global__ __launch_bounds__(256) void igemm2_fwd(const float* __restrict__ X, c
                                                   int ktiles_per_split, float* __restrict__ slab) {
     using T = T2<BM, BN>;
     constexpr int ASZ = BM * LDR, BSZ = BN * LDR;
-    __shared__ __attribute__((aligned(16))) float As[2 * ASZ];  // double buffered
-    __shared__ __attribute__((aligned(16))) float Bs[2 * BSZ];
+    __shared__ __attribute__((aligned(16))) float As[(T::DB ? 2 : 1) * ASZ];  // double buffered when it fits
+    __shared__ __attribute__((aligned(16))) float Bs[(T::DB ? 2 : 1) * BSZ];
     const int t = threadIdx.x;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int N = g.Nn;
@@ -151,9 +167,9 @@ __global__ __launch_bounds__(256) void igemm2_fwd(const float* __restrict__ X, c
         for (int i = 0; i < BC; ++i) rb[i] = (kv && b_ok[i]) ? *reinterpret_cast<const f32x4*>(b_base[i] + kk) : ZERO4;
     };
 
-    f32x16 acc[T::TM];
+    f32x16 acc[T::TM * T::TN];
 #pragma unroll
-    for (int i = 0; i < T::TM; ++i)
+    for (int i = 0; i < T::TM * T::TN; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     const int wave = t >> 6, wm = wave / T::WN, wn = wave % T::WN;
@@ -167,36 +183,52 @@ __global__ __launch_bounds__(256) void igemm2_fwd(const float* __restrict__ X, c
     // written to the other buffer between the two MFMA halves and the loads of stage t+2 are issued; one
     // barrier per stage.
     const int nkt = kt_end - kt_begin;
-    if (nkt > 0) {
-        load_tile(kt_begin);
-        store_tile(0);
-        __syncthreads();
-        if (nkt > 1) load_tile(kt_begin + 1);
-    }
-    for (int it = 0; it < nkt; ++it) {
-        const int cur = it & 1;
-        mma_rr<T::TM, 0>(As + cur * ASZ, Bs + cur * BSZ, wm * T::TM * 32, wn * 32, acc);
-        if (it + 1 < nkt) {
-            store_tile(cur ^ 1);
-            if (it + 2 < nkt) load_tile(kt_begin + it + 2);
+    if (T::DB) {
+        if (nkt > 0) {
+            load_tile(kt_begin);
+            store_tile(0);
+            __syncthreads();
+            if (nkt > 1) load_tile(kt_begin + 1);
         }
-        mma_rr<T::TM, 1>(As + cur * ASZ, Bs + cur * BSZ, wm * T::TM * 32, wn * 32, acc);
-        __syncthreads();
+        for (int it = 0; it < nkt; ++it) {
+            const int cur = it & 1;
+            mma_rr<T::TM, T::TN, 0>(As + cur * ASZ, Bs + cur * BSZ, wm * T::TM * 32, wn * T::TN * 32, acc);
+            if (it + 1 < nkt) {
+                store_tile(cur ^ 1);
+                if (it + 2 < nkt) load_tile(kt_begin + it + 2);
+            }
+            mma_rr<T::TM, T::TN, 1>(As + cur * ASZ, Bs + cur * BSZ, wm * T::TM * 32, wn * T::TN * 32, acc);
+            __syncthreads();
+        }
+    } else {  // single LDS stage (128x128 tile): barrier, store, barrier, prefetch, multiply
+        if (nkt > 0) load_tile(kt_begin);
+        for (int it = 0; it < nkt; ++it) {
+            __syncthreads();
+            store_tile(0);
+            __syncthreads();
+            if (it + 1 < nkt) load_tile(kt_begin + it + 1);
+            mma_rr<T::TM, T::TN, 0>(As, Bs, wm * T::TM * 32, wn * T::TN * 32, acc);
+            mma_rr<T::TM, T::TN, 1>(As, Bs, wm * T::TM * 32, wn * T::TN * 32, acc);
+        }
     }
 
     const int lane = t & 63, half = lane >> 5, l31 = lane & 31;
-    const int n = n0 + wn * 32 + l31;
-    if (n >= N) return;
     const bool to_slab = slab != nullptr;
-    const float bv = (!to_slab && ep.bias) ? ep.bias[n] : 0.f;
     float* out = to_slab ? slab + (long)blockIdx.z * M * N : Y;
 #pragma unroll
-    for (int tm = 0; tm < T::TM; ++tm)
+    for (int tn = 0; tn < T::TN; ++tn) {
+        const int n = n0 + wn * T::TN * 32 + tn * 32 + l31;
+        if (n >= N) continue;
+        const float bv = (!to_slab && ep.bias) ? ep.bias[n] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * T::TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (m < M) out[(long)m * N + n] = to_slab ? acc[tm][r] : apply_act(acc[tm][r] + bv, ep.act, ep.slope);
-        }
+        for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * T::TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float v = acc[tm * T::TN + tn][r];
+                if (m < M) out[(long)m * N + n] = to_slab ? v : apply_act(v + bv, ep.act, ep.slope);
+            }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -206,8 +238,8 @@ __global__ __launch_bounds__(256) void igemm2_bwd(const float* __restrict__ X, c
                                                   float* __restrict__ slab, long total) {
     using T = T2<BM, BN>;
     constexpr int ASZ = BM * LDR, BSZ = BK2 * T::LDKB;
-    __shared__ __attribute__((aligned(16))) float As[2 * ASZ];
-    __shared__ __attribute__((aligned(16))) float Bs[2 * BSZ];
+    __shared__ __attribute__((aligned(16))) float As[(T::DB ? 2 : 1) * ASZ];
+    __shared__ __attribute__((aligned(16))) float Bs[(T::DB ? 2 : 1) * BSZ];
     const int t = threadIdx.x;
     const int s = g.stride;
     const int cls = blockIdx.z / S, split = blockIdx.z - cls * S;
@@ -276,9 +308,9 @@ __global__ __launch_bounds__(256) void igemm2_bwd(const float* __restrict__ X, c
         }
     };
 
-    f32x16 acc[T::TM];
+    f32x16 acc[T::TM * T::TN];
 #pragma unroll
-    for (int i = 0; i < T::TM; ++i)
+    for (int i = 0; i < T::TM * T::TN; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     const int wave = t >> 6, wm = wave / T::WN, wn = wave % T::WN;
@@ -292,40 +324,55 @@ __global__ __launch_bounds__(256) void igemm2_bwd(const float* __restrict__ X, c
         for (int i = 0; i < BC; ++i) *reinterpret_cast<f32x4*>(Bs + buf * BSZ + (bk + KSTEP * i) * T::LDKB + bq * 4) = rb[i];
     };
     const int nkt = kt_end - kt_begin;
-    if (nkt > 0) {
-        load_tile(kt_begin);
-        store_tile(0);
-        __syncthreads();
-        if (nkt > 1) load_tile(kt_begin + 1);
-    }
-    for (int it = 0; it < nkt; ++it) {
-        const int cur = it & 1;
-        mma_rk<T::TM, 0>(As + cur * ASZ, Bs + cur * BSZ, T::LDKB, wm * T::TM * 32, wn * 32, acc);
-        if (it + 1 < nkt) {
-            store_tile(cur ^ 1);
-            if (it + 2 < nkt) load_tile(kt_begin + it + 2);
+    if (T::DB) {
+        if (nkt > 0) {
+            load_tile(kt_begin);
+            store_tile(0);
+            __syncthreads();
+            if (nkt > 1) load_tile(kt_begin + 1);
         }
-        mma_rk<T::TM, 1>(As + cur * ASZ, Bs + cur * BSZ, T::LDKB, wm * T::TM * 32, wn * 32, acc);
-        __syncthreads();
+        for (int it = 0; it < nkt; ++it) {
+            const int cur = it & 1;
+            mma_rk<T::TM, T::TN, 0>(As + cur * ASZ, Bs + cur * BSZ, T::LDKB, wm * T::TM * 32, wn * T::TN * 32, acc);
+            if (it + 1 < nkt) {
+                store_tile(cur ^ 1);
+                if (it + 2 < nkt) load_tile(kt_begin + it + 2);
+            }
+            mma_rk<T::TM, T::TN, 1>(As + cur * ASZ, Bs + cur * BSZ, T::LDKB, wm * T::TM * 32, wn * T::TN * 32, acc);
+            __syncthreads();
+        }
+    } else {  // single LDS stage (128x128 tile): barrier, store, barrier, prefetch, multiply
+        if (nkt > 0) load_tile(kt_begin);
+        for (int it = 0; it < nkt; ++it) {
+            __syncthreads();
+            store_tile(0);
+            __syncthreads();
+            if (it + 1 < nkt) load_tile(kt_begin + it + 1);
+            mma_rk<T::TM, T::TN, 0>(As, Bs, T::LDKB, wm * T::TM * 32, wn * T::TN * 32, acc);
+            mma_rk<T::TM, T::TN, 1>(As, Bs, T::LDKB, wm * T::TM * 32, wn * T::TN * 32, acc);
+        }
     }
 
     const int lane = t & 63, half = lane >> 5, l31 = lane & 31;
-    const int n = n0 + wn * 32 + l31;
-    if (n >= N) return;
     const bool to_slab = slab != nullptr;
-    const float bv = (!to_slab && ep.bias) ? ep.bias[n] : 0.f;
     float* out = to_slab ? slab + (long)split * total : Y;
 #pragma unroll
     for (int tm = 0; tm < T::TM; ++tm)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm * T::TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (m < M) {
-                const int hw = Hoc * Woc;
-                const int img = m / hw, rem = m - img * hw;
-                const int hc = rem / Woc, wc = rem - hc * Woc;
-                const long p = ((long)img * g.Ho + (hc * s + ph)) * g.Wo + (wc * s + pw);
-                out[p * N + n] = to_slab ? acc[tm][r] : apply_act(acc[tm][r] + bv, ep.act, ep.slope);
+            if (m >= M) continue;
+            const int hw = Hoc * Woc;
+            const int img = m / hw, rem = m - img * hw;
+            const int hc = rem / Woc, wc = rem - hc * Woc;
+            const long p = ((long)img * g.Ho + (hc * s + ph)) * g.Wo + (wc * s + pw);
+#pragma unroll
+            for (int tn = 0; tn < T::TN; ++tn) {
+                const int n = n0 + wn * T::TN * 32 + tn * 32 + l31;
+                if (n >= N) continue;
+                const float bv = (!to_slab && ep.bias) ? ep.bias[n] : 0.f;
+                const float v = acc[tm * T::TN + tn][r];
+                out[p * N + n] = to_slab ? v : apply_act(v + bv, ep.act, ep.slope);
             }
         }
 }
@@ -336,8 +383,8 @@ __global__ __launch_bounds__(256) void igemm2_wgrad(const float* __restrict__ Sm
                                                     float* __restrict__ out, WGeom g, int K, int kchunk, int to_slab) {
     using T = T2<BM, BN>;
     constexpr int ASZ = BK2 * T::LDKA, BSZ = BK2 * T::LDKB;
-    __shared__ __attribute__((aligned(16))) float As[2 * ASZ];
-    __shared__ __attribute__((aligned(16))) float Bs[2 * BSZ];
+    __shared__ __attribute__((aligned(16))) float As[(T::DB ? 2 : 1) * ASZ];
+    __shared__ __attribute__((aligned(16))) float Bs[(T::DB ? 2 : 1) * BSZ];
     const int t = threadIdx.x;
     const int M = g.Cs, N = g.KH * g.KW * g.Cb;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
@@ -375,9 +422,9 @@ __global__ __launch_bounds__(256) void igemm2_wgrad(const float* __restrict__ Sm
         }
     };
 
-    f32x16 acc[T::TM];
+    f32x16 acc[T::TM * T::TN];
 #pragma unroll
-    for (int i = 0; i < T::TM; ++i)
+    for (int i = 0; i < T::TM * T::TN; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     const int wave = t >> 6, wm = wave / T::WN, wn = wave % T::WN;
@@ -388,34 +435,49 @@ __global__ __launch_bounds__(256) void igemm2_wgrad(const float* __restrict__ Sm
         for (int i = 0; i < BCH; ++i) *reinterpret_cast<f32x4*>(Bs + buf * BSZ + (bk + BKS * i) * T::LDKB + bq * 4) = rb[i];
     };
     const int nkt = k_begin < k_end ? (k_end - k_begin + BK2 - 1) / BK2 : 0;
-    if (nkt > 0) {
-        load_tile(k_begin);
-        store_tile(0);
-        __syncthreads();
-        if (nkt > 1) load_tile(k_begin + BK2);
-    }
-    for (int it = 0; it < nkt; ++it) {
-        const int cur = it & 1;
-        mma_kk<T::TM, 0>(As + cur * ASZ, Bs + cur * BSZ, T::LDKA, T::LDKB, wm * T::TM * 32, wn * 32, acc);
-        if (it + 1 < nkt) {
-            store_tile(cur ^ 1);
-            if (it + 2 < nkt) load_tile(k_begin + (it + 2) * BK2);
+    if (T::DB) {
+        if (nkt > 0) {
+            load_tile(k_begin);
+            store_tile(0);
+            __syncthreads();
+            if (nkt > 1) load_tile(k_begin + BK2);
         }
-        mma_kk<T::TM, 1>(As + cur * ASZ, Bs + cur * BSZ, T::LDKA, T::LDKB, wm * T::TM * 32, wn * 32, acc);
-        __syncthreads();
+        for (int it = 0; it < nkt; ++it) {
+            const int cur = it & 1;
+            mma_kk<T::TM, T::TN, 0>(As + cur * ASZ, Bs + cur * BSZ, T::LDKA, T::LDKB, wm * T::TM * 32, wn * T::TN * 32, acc);
+            if (it + 1 < nkt) {
+                store_tile(cur ^ 1);
+                if (it + 2 < nkt) load_tile(k_begin + (it + 2) * BK2);
+            }
+            mma_kk<T::TM, T::TN, 1>(As + cur * ASZ, Bs + cur * BSZ, T::LDKA, T::LDKB, wm * T::TM * 32, wn * T::TN * 32, acc);
+            __syncthreads();
+        }
+    } else {  // single LDS stage (128x128 tile): barrier, store, barrier, prefetch, multiply
+        if (nkt > 0) load_tile(k_begin);
+        for (int it = 0; it < nkt; ++it) {
+            __syncthreads();
+            store_tile(0);
+            __syncthreads();
+            if (it + 1 < nkt) load_tile(k_begin + (it + 1) * BK2);
+            mma_kk<T::TM, T::TN, 0>(As, Bs, T::LDKA, T::LDKB, wm * T::TM * 32, wn * T::TN * 32, acc);
+            mma_kk<T::TM, T::TN, 1>(As, Bs, T::LDKA, T::LDKB, wm * T::TM * 32, wn * T::TN * 32, acc);
+        }
     }
 
     const int lane = t & 63, half = lane >> 5, l31 = lane & 31;
-    const int n = n0 + wn * 32 + l31;
-    if (n >= N) return;
     float* dst = to_slab ? out + (long)blockIdx.z * M * N : out;
 #pragma unroll
-    for (int tm = 0; tm < T::TM; ++tm)
+    for (int tn = 0; tn < T::TN; ++tn) {
+        const int n = n0 + wn * T::TN * 32 + tn * 32 + l31;
+        if (n >= N) continue;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * T::TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (m < M) dst[(long)m * N + n] = acc[tm][r];
-        }
+        for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * T::TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < M) dst[(long)m * N + n] = acc[tm * T::TN + tn][r];
+            }
+    }
 }
 
 #undef ZERO4

@@ -280,10 +280,11 @@ inline int grid_for(long total) {
 
 extern "C" {
 
-size_t movae_reduce_ws_bytes(size_t n) { return (size_t)red_blocks(n) * sizeof(double); }
+size_t movae_reduce_ws_bytes(size_t n) { return MOVAE_WS_HEADER_BYTES + (size_t)red_blocks(n) * sizeof(double); }
 
 int movae_recon_loss_fwd(const float* recons, const float* inputs, float* out, size_t n, int kind, float scale, void* ws,
                          size_t ws_bytes, movae_stream_t stream) {
+    MOVAE_WS_SCRATCH(ws, ws_bytes);
     MOVAE_CHECK_ARG(recons && inputs && out && n > 0, "movae_recon_loss_fwd: bad argument");
     MOVAE_CHECK_ARG(kind >= 0 && kind <= 3, "movae_recon_loss_fwd: unknown objective %d", kind);
     MOVAE_CHECK_ARG(ws && ws_bytes >= movae_reduce_ws_bytes(n), "movae_recon_loss_fwd: workspace too small");
@@ -308,6 +309,7 @@ int movae_recon_loss_bwd(const float* recons, const float* inputs, const float* 
 
 int movae_kl_fwd(const float* mu, const float* log_var, float* out, int b, int d, float scale, void* ws, size_t ws_bytes,
                  movae_stream_t stream) {
+    MOVAE_WS_SCRATCH(ws, ws_bytes);
     MOVAE_CHECK_ARG(mu && log_var && out && b > 0 && d > 0, "movae_kl_fwd: bad argument");
     const size_t n = (size_t)b * d;
     MOVAE_CHECK_ARG(ws && ws_bytes >= movae_reduce_ws_bytes(n), "movae_kl_fwd: workspace too small");
@@ -332,6 +334,7 @@ int movae_kl_bwd(const float* mu, const float* log_var, const float* gscale_dev,
 
 int movae_tc_decomp_fwd(const float* z, const float* mu, const float* log_var, const float* log_iw, float* out,
                         float* lse_joint, float* lse_marg, int b, int d, void* ws, size_t ws_bytes, movae_stream_t stream) {
+    MOVAE_WS_SCRATCH(ws, ws_bytes);
     MOVAE_CHECK_ARG(z && mu && log_var && log_iw && out && lse_joint && lse_marg, "movae_tc_decomp_fwd: null pointer");
     MOVAE_CHECK_ARG(b > 1 && d > 0 && d <= 64 * TC_DU, "movae_tc_decomp_fwd: need b > 1 and d <= %d (got b=%d d=%d)", 64 * TC_DU, b, d);
     MOVAE_CHECK_ARG(ws && ws_bytes >= (size_t)b * 3 * sizeof(float), "movae_tc_decomp_fwd: workspace too small");

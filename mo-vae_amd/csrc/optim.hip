@@ -25,6 +25,78 @@ __global__ __launch_bounds__(256) void adam_k(float* __restrict__ p, const float
     }
 }
 
+// ---- multi-tensor Adam: ONE launch for a whole parameter list (the step's ~50 tensors range from 32 to 1.2M elements; a
+// launch per tensor -- or torch's capturable foreach path, ~110 launches -- costs more than the arithmetic) ----------
+constexpr int ADAM_MT = 64;  // tensors per launch: 64 * (4 pointers + count) = 2.3 KB of kernel arguments
+struct AdamTable {
+    float* p[ADAM_MT];
+    const float* g[ADAM_MT];
+    float* m[ADAM_MT];
+    float* v[ADAM_MT];
+    unsigned n[ADAM_MT];
+};
+
+__device__ __forceinline__ void adam_one(float& pi, float gi, float& mi, float& vi, float lr, float b1, float b2, float eps,
+                                         float wd, int decoupled, float step_size, float bc2_sqrt) {
+    if (wd != 0.f) {
+        if (decoupled) pi *= 1.f - lr * wd;
+        else gi += wd * pi;
+    }
+    mi = mi + (gi - mi) * (1.f - b1);
+    vi = vi * b2 + (1.f - b2) * gi * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi = pi - step_size * (mi / denom);
+}
+
+// grid = (blocks per tensor, tensors).  hyper (optional) = device {step, lr}: the step counter has already been
+// incremented by adam_tick on the same stream, so a captured hipGraph replays with a live counter / learning rate.
+__global__ __launch_bounds__(256) void adam_multi_k(AdamTable tab, float lr, float b1, float b2, float eps, float wd, int decoupled,
+                                                    float bc1, float bc2_sqrt, const float* __restrict__ hyper) {
+    const int t = blockIdx.y;
+    const unsigned n = tab.n[t];
+    if ((unsigned)blockIdx.x * 1024u >= n) return;
+    if (hyper) {
+        const double step = (double)hyper[0];
+        lr = hyper[1];
+        bc1 = (float)(1.0 - pow((double)b1, step));
+        bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, step));
+    }
+    const float step_size = lr / bc1;
+    float* __restrict__ p = tab.p[t];
+    const float* __restrict__ g = tab.g[t];
+    float* __restrict__ m = tab.m[t];
+    float* __restrict__ v = tab.v[t];
+    const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                       reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+    const unsigned stride = gridDim.x * 1024u;
+    for (unsigned base = blockIdx.x * 1024u; base < n; base += stride) {
+        const unsigned i = base + threadIdx.x * 4;
+        if (i >= n) break;
+        if (vec && i + 4 <= n) {
+            f32x4 pv = *reinterpret_cast<f32x4*>(p + i), mv = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float pj = pv[j], mj = mv[j], vj = vv[j];
+                adam_one(pj, gv[j], mj, vj, lr, b1, b2, eps, wd, decoupled, step_size, bc2_sqrt);
+                pv[j] = pj; mv[j] = mj; vv[j] = vj;
+            }
+            *reinterpret_cast<f32x4*>(p + i) = pv;
+            *reinterpret_cast<f32x4*>(m + i) = mv;
+            *reinterpret_cast<f32x4*>(v + i) = vv;
+        } else {
+            const unsigned e = min(i + 4, n);
+            for (unsigned k = i; k < e; ++k) {
+                float pj = p[k], mj = m[k], vj = v[k];
+                adam_one(pj, g[k], mj, vj, lr, b1, b2, eps, wd, decoupled, step_size, bc2_sqrt);
+                p[k] = pj; m[k] = mj; v[k] = vj;
+            }
+        }
+    }
+}
+
+__global__ void adam_tick(float* hyper) { hyper[0] += 1.f; }
+
 __global__ __launch_bounds__(256) void sumsq_partial(const float* __restrict__ x, long n, double* __restrict__ part) {
     __shared__ double sh[4];
     double s = 0.0;
@@ -68,7 +140,42 @@ int movae_adam_step(float* p, const float* g, float* m, float* v, size_t n, floa
     return MOVAE_OK;
 }
 
+int movae_adam_multi(int n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v, const size_t* numel,
+                     float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled_wd, int step,
+                     float* hyper_dev, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(n_tensors >= 0 && (n_tensors == 0 || (p && g && m && v && numel)), "movae_adam_multi: null table");
+    MOVAE_CHECK_ARG(hyper_dev || step >= 1, "movae_adam_multi: step must be >= 1 when no device counter is given");
+    float bc1 = 1.f, bc2_sqrt = 1.f;
+    if (hyper_dev) {
+        hipLaunchKernelGGL(adam_tick, dim3(1), dim3(1), 0, (hipStream_t)stream, hyper_dev);
+        MOVAE_CHECK_LAUNCH("adam_tick");
+    } else {
+        bc1 = (float)(1.0 - pow((double)beta1, step));
+        bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, step));
+    }
+    for (int t0 = 0; t0 < n_tensors; t0 += ADAM_MT) {
+        AdamTable tab;
+        const int cnt = n_tensors - t0 < ADAM_MT ? n_tensors - t0 : ADAM_MT;
+        size_t nmax = 0;
+        for (int i = 0; i < cnt; ++i) {
+            MOVAE_CHECK_ARG(p[t0 + i] && g[t0 + i] && m[t0 + i] && v[t0 + i], "movae_adam_multi: null tensor");
+            MOVAE_CHECK_ARG(numel[t0 + i] > 0 && numel[t0 + i] < 0xffffffffUL, "movae_adam_multi: tensor size out of range");
+            tab.p[i] = p[t0 + i]; tab.g[i] = g[t0 + i]; tab.m[i] = m[t0 + i]; tab.v[i] = v[t0 + i];
+            tab.n[i] = (unsigned)numel[t0 + i];
+            if (numel[t0 + i] > nmax) nmax = numel[t0 + i];
+        }
+        for (int i = cnt; i < ADAM_MT; ++i) { tab.p[i] = nullptr; tab.g[i] = nullptr; tab.m[i] = nullptr; tab.v[i] = nullptr; tab.n[i] = 0; }
+        size_t bx = (nmax + 1023) / 1024;
+        if (bx > 256) bx = 256;
+        hipLaunchKernelGGL(adam_multi_k, dim3((unsigned)bx, (unsigned)cnt), dim3(256), 0, (hipStream_t)stream, tab, lr, beta1, beta2,
+                           eps, weight_decay, decoupled_wd, bc1, bc2_sqrt, (const float*)hyper_dev);
+        MOVAE_CHECK_LAUNCH("adam_multi");
+    }
+    return MOVAE_OK;
+}
+
 int movae_sumsq(const float* x, size_t n, float* out, void* ws, size_t ws_bytes, movae_stream_t stream) {
+    MOVAE_WS_SCRATCH(ws, ws_bytes);
     MOVAE_CHECK_ARG(x && out && n > 0, "movae_sumsq: bad argument");
     const int nb = blocks_for(n);
     MOVAE_CHECK_ARG(ws && ws_bytes >= (size_t)nb * sizeof(double), "movae_sumsq: workspace too small");

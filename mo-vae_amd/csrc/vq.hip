@@ -184,6 +184,7 @@ extern "C" {
 
 int movae_vq_nearest_fwd(const float* x, const float* e, float* q, int64_t* idx, float* sse, int32_t* used_count, int rows,
                          int k, int d, void* ws, size_t ws_bytes, movae_stream_t stream) {
+    MOVAE_WS_SCRATCH(ws, ws_bytes);
     MOVAE_CHECK_ARG(x && e && q && idx && sse, "movae_vq_nearest_fwd: null pointer");
     MOVAE_CHECK_ARG(rows > 0 && k > 0 && d > 0, "movae_vq_nearest_fwd: bad shape rows=%d k=%d d=%d", rows, k, d);
     hipStream_t st = (hipStream_t)stream;

@@ -80,10 +80,9 @@ class BatchNorm2d(tnn.Module):
         self.eps, self.momentum, self.num_features = eps, momentum, c
 
     def forward(self, y, act=None):
-        if self.training:
-            self.num_batches_tracked.add_(1)
+        # num_batches_tracked += 1 happens inside the statistics kernel (training mode only)
         return ops.batch_norm_act(y, self.weight, self.bias, self.running_mean, self.running_var, self.training, self.eps,
-                                  self.momentum, act, LRELU_SLOPE)
+                                  self.momentum, act, LRELU_SLOPE, self.num_batches_tracked)
 
     def extra_repr(self):
         return f"{self.num_features}"

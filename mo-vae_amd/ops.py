@@ -26,6 +26,15 @@ def _sink(param, shape):
     return torch.empty(shape, dtype=param.dtype, device=param.device)
 
 
+def _sink_zeros(param, shape):
+    """An all-zero gradient: sinks are zero-initialised by their owner (autojac.JacobianBuffer) and written at most
+    once, so a registered sink is returned untouched -- no fill launch."""
+    dst = GRAD_SINK.pop(param.data_ptr(), None) if GRAD_SINK else None
+    if dst is not None and dst.numel() == param.numel():
+        return dst.view(shape)
+    return torch.zeros(shape, dtype=param.dtype, device=param.device)
+
+
 def _ws(t):
     w = L.workspace(t.device)
     return w.data_ptr(), w.numel()
@@ -163,26 +172,38 @@ class Conv(Function):
             dy = dpre
         pre = "movae_convT2d_" if ctx.transposed else "movae_conv2d_"
         dx = dw = db = None
+        need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        # dgrad and wgrad only share read-only operands: when both are needed the wgrad (+ its reduce / bias sum)
+        # is issued on a forked side stream with its own scratch arena and joined afterwards, so the two short,
+        # latency-bound launches overlap on the device (also inside a captured hipGraph, as parallel branches)
+        fork = L.SIDE_STREAM_WGRAD and need_w and ctx.needs_input_grad[0]
+        if fork:
+            main, side = torch.cuda.current_stream(dy.device), L.side_stream(dy.device)
+            side.wait_stream(main)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             wm = weight_mem(w)
             _call(pre + "dgrad", dy.data_ptr(), wm.data_ptr(), dx.data_ptr(), n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad,
                   wsp, wsb, st)
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+        if fork:
+            ws2 = L.workspace(dy.device, slot=1)
+            wsp, wsb, st = ws2.data_ptr(), ws2.numel(), side.cuda_stream
+        if need_w:
             wm_shape = (ci, kh, kw, co) if ctx.transposed else (co, kh, kw, ci)
             dwm = _sink(w, wm_shape)
             db_k = None
             if ctx.has_bias and ctx.needs_input_grad[2]:
-                db = _sink(b, (co,))
                 if ctx.bias_grad_is_zero:
                     # the bias feeds a training-mode BatchNorm, which subtracts the batch mean: d(loss)/d(bias) == 0
                     # identically (the reference's value is rounding noise of order 1e-9); no column-sum pass
-                    db.zero_()
+                    db = _sink_zeros(b, (co,))
                 else:
-                    db_k = db
+                    db = db_k = _sink(b, (co,))
             _call(pre + "wgrad", dy.data_ptr(), x.data_ptr(), dwm.data_ptr(), L.ptr(db_k), n, hi, wi, ci, ho, wo, co, kh, kw,
                   stride, pad, 0, wsp, wsb, st)
             dw = dwm.permute(0, 3, 1, 2)
+        if fork:
+            main.wait_stream(side)
         return dx, dw, db, None, None, None, None, None, None, None
 
 
@@ -204,7 +225,7 @@ def linear(x, w, b=None, act=None, slope=0.01):
 # ---------------------------------------------------------------------------------------------
 class BatchNormAct(Function):
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, training, eps, momentum, act, slope):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, training, eps, momentum, act, slope, num_batches_tracked=None):
         L.require_gpu(y)
         y = _c(y)
         c = y.shape[-1]
@@ -214,7 +235,7 @@ class BatchNormAct(Function):
         rstd = torch.empty(c, dtype=y.dtype, device=y.device)
         wsp, wsb = _ws(y)
         _call("movae_bn_act_fwd", y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), mean.data_ptr(),
-              rstd.data_ptr(), L.ptr(running_mean), L.ptr(running_var), rows, c, float(eps), float(momentum),
+              rstd.data_ptr(), L.ptr(running_mean), L.ptr(running_var), L.ptr(num_batches_tracked), rows, c, float(eps), float(momentum),
               1 if training else 0, L.ACT[act], float(slope), wsp, wsb, _st(y))
         ctx.act, ctx.slope, ctx.training = act, slope, training
         ctx.save_for_backward(y, gamma, beta, mean, rstd)
@@ -236,11 +257,13 @@ class BatchNormAct(Function):
         _call("movae_bn_act_bwd", dout.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
               rstd.data_ptr(), dy.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, c, L.ACT[ctx.act], float(ctx.slope), 0,
               wsp, wsb, _st(y))
-        return dy, dg, db, None, None, None, None, None, None, None
+        return dy, dg, db, None, None, None, None, None, None, None, None
 
 
-def batch_norm_act(y, gamma, beta, running_mean, running_var, training, eps=1e-5, momentum=0.1, act=None, slope=0.01):
-    return BatchNormAct.apply(y, gamma, beta, running_mean, running_var, training, eps, momentum, act, slope)
+def batch_norm_act(y, gamma, beta, running_mean, running_var, training, eps=1e-5, momentum=0.1, act=None, slope=0.01,
+                   num_batches_tracked=None):
+    """num_batches_tracked (int64 device scalar) is incremented inside the statistics kernel in training mode."""
+    return BatchNormAct.apply(y, gamma, beta, running_mean, running_var, training, eps, momentum, act, slope, num_batches_tracked)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -20,6 +20,7 @@ from . import aggregation
 from . import autojac
 from .aggregation import MGDA
 from .models import get_network
+from .optim import FusedAdam, FusedAdamW
 from .parallel import DataParallelGrads
 
 _current_step = 0
@@ -100,8 +101,8 @@ class GraphedTrainStep:
     """The whole optimisation step (forward, losses, K per-loss backward passes, Gram / solve / combine,
     optimizer) captured ONCE into a hipGraph and replayed per batch: the step is ~250 short kernels, so
     eager launches are host-bound; a replay is one submission.  No tracing compiler is involved -- the
-    graph holds exactly the launches the eager step made.  The optimizer must be constructed with
-    capturable=True (its step counter then lives on the device).
+    graph holds exactly the launches the eager step made.  The optimizer must keep its step counter on
+    the device: make_optimizer(..., capturable=True) -> FusedAdam(device_step=True).
 
     Data parallel (dp given): the step is two graphs around ONE eager collective --
     graph 1 = forward/backward + flatten of every gradient into a static flat bucket, then
@@ -150,6 +151,8 @@ class GraphedTrainStep:
 
     def step(self, images):
         self.static_x.copy_(images, non_blocking=True)
+        if hasattr(self.opt, "sync_hyper"):
+            self.opt.sync_hyper()  # lr schedulers change the host value between replays
         self.graph.replay()
         if self.graph2 is not None:
             torch.distributed.all_reduce(self.flat)
@@ -352,10 +355,10 @@ def make_optimizer(net, args, capturable=False):
     """main.py:1169-1178.  capturable=True keeps Adam's step counter on the device (hipGraph replay)."""
     if args.optimizer == "sgd":
         return optim.SGD(net.parameters(), lr=args.lr, momentum=args.momentum, weight_decay=args.wd)
-    if args.optimizer == "adam":
-        return optim.Adam(net.parameters(), lr=args.lr, weight_decay=args.wd, capturable=capturable)
+    if args.optimizer == "adam":  # same arithmetic and state_dict as torch.optim.Adam, one launch per step (optim.py)
+        return FusedAdam(net.parameters(), lr=args.lr, weight_decay=args.wd, device_step=capturable)
     if args.optimizer == "adamw":
-        return optim.AdamW(net.parameters(), lr=args.lr, weight_decay=args.wd, capturable=capturable)
+        return FusedAdamW(net.parameters(), lr=args.lr, weight_decay=args.wd, device_step=capturable)
     if args.optimizer == "rmsprop":
         return optim.RMSprop(net.parameters(), lr=args.lr, weight_decay=args.wd)
     raise ValueError(f"Optimizer {args.optimizer} not supported")

@@ -128,7 +128,9 @@ def test_linear_fwd_bwd(M, shape):
     close(bg.grad, br.grad, "db")
 
 
-@pytest.mark.parametrize("shape", [(4, 8, 5, 5), (6, 32, 8, 8), (3, 20, 3, 3), (64, 512, 1, 1), (2, 3, 4, 4)])
+@pytest.mark.parametrize("shape", [(4, 8, 5, 5), (6, 32, 8, 8), (3, 20, 3, 3), (64, 512, 1, 1), (2, 3, 4, 4),
+                                   # rows > 4096: the three-launch path (partials / final / apply); 4096: the boundary
+                                   (32, 16, 16, 16), (5, 24, 31, 33), (16, 32, 16, 16), (9, 6, 24, 24)])
 def test_batchnorm_act_train(M, shape):
     ops, _ = M
     n, c, h, w = shape
@@ -145,7 +147,9 @@ def test_batchnorm_act_train(M, shape):
     xg = nhwc(x)
     gg, bg = g.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
     rm, rv = torch.zeros(c).cuda(), torch.ones(c).cuda()
-    y = ops.batch_norm_act(xg, gg, bg, rm, rv, True, 1e-5, 0.1, "lrelu", 0.01)
+    nbt = torch.tensor(41, dtype=torch.long).cuda()
+    y = ops.batch_norm_act(xg, gg, bg, rm, rv, True, 1e-5, 0.1, "lrelu", 0.01, nbt)
+    assert int(nbt.item()) == 42  # num_batches_tracked is incremented inside the statistics kernel
     y.backward(gy.permute(0, 2, 3, 1).contiguous().cuda())
     close(back(y), yr, "y")
     close(back(xg.grad), xr.grad, "dx", rtol=1e-3)
@@ -155,8 +159,9 @@ def test_batchnorm_act_train(M, shape):
     close(rv, bn.running_var, "running_var")
     # eval mode uses the running statistics
     bn.eval()
-    ye = ops.batch_norm_act(xg.detach(), gg.detach(), bg.detach(), rm, rv, False, 1e-5, 0.1, None, 0.01)
+    ye = ops.batch_norm_act(xg.detach(), gg.detach(), bg.detach(), rm, rv, False, 1e-5, 0.1, None, 0.01, nbt)
     close(back(ye), bn(x), "eval")
+    assert int(nbt.item()) == 42  # untouched in eval mode
 
 
 def test_layout_roundtrip_and_flatten(M):
@@ -405,6 +410,57 @@ def test_adam_and_clip(M):
     gr.grad = g.clone()
     torch.nn.utils.clip_grad_norm_([gr], 1.0)
     close(gg, gr.grad, "clip", rtol=1e-5)
+
+
+@pytest.mark.parametrize("mode", ["adam", "adam_wd", "adamw", "adam_device_step"])
+def test_fused_adam_matches_torch_adam(M, mode):
+    """optim.FusedAdam (movae_adam_multi, one launch for the whole list) vs torch.optim.Adam/AdamW on CPU: ragged
+    sizes, a channels_last conv weight, a parameter whose grad is None on one step (own bias correction), an lr
+    change between steps, and a state_dict round trip into torch's own optimizer."""
+    from movae_amd.optim import FusedAdam, FusedAdamW
+
+    shapes = [(7,), (64, 32, 3, 3), (1,), (1023,), (130, 5), (4096 * 3 + 1,)]
+    ref = [rnd(*s, seed=10 + i) for i, s in enumerate(shapes)]
+    ref[1] = ref[1].contiguous(memory_format=torch.channels_last)
+    pr = [t.clone().requires_grad_(True) for t in ref]
+    pg = [t.cuda().requires_grad_(True) for t in ref]
+    assert pg[1].is_contiguous(memory_format=torch.channels_last) and not pg[1].is_contiguous()
+    kw = dict(lr=1e-3, weight_decay=0.05 if mode in ("adam_wd", "adamw") else 0.0)
+    if mode == "adamw":
+        o_ref, o_gpu = torch.optim.AdamW(pr, **kw), FusedAdamW(pg, **kw)
+    else:
+        o_ref = torch.optim.Adam(pr, **kw)
+        o_gpu = FusedAdam(pg, device_step=(mode == "adam_device_step"), **kw)
+    for step in range(1, 6):
+        if step == 4:
+            for o in (o_ref, o_gpu):
+                o.param_groups[0]["lr"] = 3e-4
+        for i, (a, b) in enumerate(zip(pr, pg)):
+            gi = rnd(*shapes[i], seed=100 * step + i) * (0.5 + step)
+            skip = (i == 3 and step == 2 and mode != "adam_device_step")  # one shared device counter in device_step mode
+            a.grad = None if skip else gi.clone()
+            b.grad = None if skip else gi.cuda()
+        o_ref.step()
+        o_gpu.step()
+    for i, (a, b) in enumerate(zip(pr, pg)):
+        close(b, a, f"{mode} param {i}", rtol=2e-5, atol=2e-6)
+    sd = o_gpu.state_dict()
+    assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+    assert float(sd["state"][0]["step"]) == 5.0
+    close(sd["state"][1]["exp_avg"], o_ref.state_dict()["state"][1]["exp_avg"], "exp_avg", rtol=1e-5, atol=1e-7)
+    twin = torch.optim.Adam([t.detach().clone().requires_grad_(True) for t in pg], lr=1e-3)
+    twin.load_state_dict(sd)  # checkpoints are interchangeable with torch's optimizer
+    # and back: torch's state loads into FusedAdam and the next step continues from it
+    o2 = FusedAdam(pg, lr=3e-4, weight_decay=kw["weight_decay"], decoupled_weight_decay=(mode == "adamw"),
+                   device_step=(mode == "adam_device_step"))
+    o2.load_state_dict(sd)
+    for i, (a, b) in enumerate(zip(pr, pg)):
+        gi = rnd(*shapes[i], seed=999 + i)
+        a.grad, b.grad = gi.clone(), gi.cuda()
+    o_ref.step()
+    o2.step()
+    for i, (a, b) in enumerate(zip(pr, pg)):
+        close(b, a, f"{mode} after reload, param {i}", rtol=2e-5, atol=2e-6)
 
 
 def test_invalid_arguments_raise(M):
