@@ -180,6 +180,9 @@ int movae_bench_main_kernel_only(int on);
 /* name (as rocprofv3 prints it, without the argument list) of the main kernel the most recent conv-family call
  * on this process dispatched to, e.g. "igemm2_bwd<64,64>" -- lets bench.py group its HIP-event timings per kernel */
 const char* movae_bench_last_kernel(void);
+/* s > 0 pins the conv family's split-K factor (tools/conv_microbench.py tuning sweeps); 0 restores the heuristic.
+ * Returns the previous value. */
+int movae_bench_force_split(int s);
 
 #ifdef __cplusplus
 }

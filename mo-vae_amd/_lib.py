@@ -68,6 +68,7 @@ SIGNATURES = {
     "movae_scale_by_clip": ([_p, _z, _p, _f, _p], _i),
     "movae_bench_main_kernel_only": ([_i], _i),
     "movae_bench_last_kernel": ([], C.c_char_p),
+    "movae_bench_force_split": ([_i], _i),
 }
 
 _lib = None

@@ -499,6 +499,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_flat(const float* __restric
 }
 
 const char* g_last_kernel = "";  // movae_bench_last_kernel(): main kernel chosen by the most recent conv-family dispatch
+int g_force_split = 0;           // movae_bench_force_split(): > 0 pins the split-K factor (tuning sweeps)
 bool g_bench_main_only = false;  // movae_bench_main_kernel_only(): time the MFMA kernel without its epilogue launches
 
 inline int launch_reduce(const float* slab, float* out, long total, int S, int N, const float* bias, int act, float slope,
@@ -517,18 +518,41 @@ inline int launch_reduce(const float* slab, float* out, long total, int S, int N
     return MOVAE_OK;
 }
 
-// split-K factor: enough blocks to occupy 256 CUs a few times over, at least MIN_KT k-tiles per split
-inline int choose_split(long tiles, int nk, size_t per_slab_bytes, size_t ws_bytes, bool have_ws) {
-    // splitting pays only when the unsplit grid cannot fill the chip once (256 CUs); every split costs one slab
-    // write + read of the whole output, so large outputs stay unsplit
-    static const int tune_tiles = getenv("MOVAE_SPLIT_TILES") ? atoi(getenv("MOVAE_SPLIT_TILES")) : 192;
-    static const int tune_target = getenv("MOVAE_SPLIT_TARGET") ? atoi(getenv("MOVAE_SPLIT_TARGET")) : 768;
-    if (!have_ws || tiles > tune_tiles || nk < 4) return 1;
-    long S = (tune_target + tiles - 1) / tiles;
-    if (S > nk / 2) S = nk / 2;
-    if (S > 128) S = 128;
-    while (S > 1 && per_slab_bytes * (size_t)S > ws_bytes) --S;
-    return S < 2 ? 1 : (int)S;
+// split-K factor from a small cost model fitted to tools/conv_microbench.py --sweep-split on MI355X (tools/split_model.py
+// holds the same rule and the fit):   T(S) = rounds * (t0 + k-tiles-per-split * tk * share) + [S>1] * (t_reduce + S * out * c)
+//   * 256 CUs hold two 256-thread blocks each; a CU holding two runs each ~1.6x slower, so 256 < blocks < 512 is the worst
+//     place to be and blocks <= 256 the best unless the k loop per block stays long;
+//   * every split writes and re-reads the whole output once (slab), ~0.87 us per MB at the rate these short kernels reach;
+//   * tk = time of one 32-deep k-tile for a 64x64 block (~1 us: latency bound, one block per CU cannot hide the
+//     global->LDS->MFMA chain), scaled by tile area.
+enum { FORM_FWD = 0, FORM_BWD = 1, FORM_WGRAD = 2 };
+inline int choose_split(int form, int tile_area, int bk, long tiles, int nk, size_t per_slab_bytes, size_t ws_bytes, bool have_ws) {
+    if (!have_ws || nk < 2) return 1;
+    long smax = nk < 256 ? nk : 256;
+    while (smax > 1 && per_slab_bytes * (size_t)smax > ws_bytes) --smax;
+    if (g_force_split > 0) return (int)(g_force_split < smax ? g_force_split : smax);  // movae_bench_force_split()
+    static const int legacy_tiles = getenv("MOVAE_SPLIT_TILES") ? atoi(getenv("MOVAE_SPLIT_TILES")) : -1;
+    if (legacy_tiles >= 0 && tiles > legacy_tiles) return 1;
+    const bool big = tile_area >= 128 * 128;
+    const double form_tk = form == FORM_FWD ? 1.0 : (form == FORM_BWD ? 1.25 : 0.9);
+    const double tk = form_tk * (tile_area / 4096.0) * (big ? 0.83 : 1.0) * (bk / 32.0);
+    const double out_mb = (double)per_slab_bytes * 1e-6;
+    int best = 1;
+    double best_t = 0.0;
+    for (long S = 1; S <= smax; ++S) {
+        const long kps = (nk + S - 1) / S;
+        if ((nk + kps - 1) / kps != S) continue;  // the launchers round S to this value anyway
+        const long blocks = tiles * S;
+        const long rounds = (blocks + 511) / 512;
+        const double share = blocks <= 256 ? 1.0 : 1.6;
+        double t = rounds * (2.0 + kps * tk * share);
+        if (S > 1) t += 2.5 + S * out_mb * 0.87;
+        if (S == 1 || t < best_t * 0.97) {  // fewer splits unless the gain is clear
+            best = (int)S;
+            best_t = t;
+        }
+    }
+    return best;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -550,7 +574,7 @@ int launch_fwd_t(const float* X, const float* W, float* Y, const Geom& g, const 
     const int gx = ceil_div(M, BM), gy = ceil_div(g.Nn, BN);
     const int nk = ceil_div(K, BK);
     const long tiles = (long)gx * gy;
-    int S = choose_split(tiles, nk, (size_t)M * g.Nn * sizeof(float), ws_bytes, ws != nullptr);
+    int S = choose_split(FORM_FWD, BM * BN, BK, tiles, nk, (size_t)M * g.Nn * sizeof(float), ws_bytes, ws != nullptr);
     const int per_split = ceil_div(nk, S);
     S = ceil_div(nk, per_split);
     float* slab = S > 1 ? static_cast<float*>(ws) : nullptr;
@@ -599,7 +623,7 @@ int launch_bwd_t(const float* X, const float* W, float* Y, const Geom& g, const 
     const int gx = ceil_div(Mmax, BM), gy = ceil_div(g.Nn, BN);
     const int nk_max = ceil_div((long)ceil_div(g.KH, s) * ceil_div(g.KW, s) * g.Cr, BK);
     const long total = (long)g.Nimg * g.Ho * g.Wo * g.Nn;
-    int S = choose_split((long)gx * gy * s * s, nk_max, (size_t)total * sizeof(float), ws_bytes, ws != nullptr);
+    int S = choose_split(FORM_BWD, BM * BN, BK, (long)gx * gy * s * s, nk_max, (size_t)total * sizeof(float), ws_bytes, ws != nullptr);
     const int per_split = ceil_div(nk_max, S);
     S = ceil_div(nk_max, per_split);
     float* slab = S > 1 ? static_cast<float*>(ws) : nullptr;
@@ -643,7 +667,7 @@ int launch_wgrad_t(const float* S, const float* Bg, float* dW, const WGeom& g, i
     const int M = g.Cs, N = g.KH * g.KW * g.Cb;
     const int gx = ceil_div(M, BM), gy = ceil_div(N, BN);
     const long tiles = (long)gx * gy;
-    int Sp = choose_split(tiles, ceil_div(K, BK), (size_t)M * N * sizeof(float), ws_bytes, ws != nullptr);
+    int Sp = choose_split(FORM_WGRAD, BM * BN, BK, tiles, ceil_div(K, BK), (size_t)M * N * sizeof(float), ws_bytes, ws != nullptr);
     int kchunk = ceil_div(ceil_div(K, Sp), BK) * BK;
     Sp = ceil_div(K, kchunk);
     const bool slab = Sp > 1 || accumulate;
@@ -719,6 +743,12 @@ int check_conv_shape(const char* who, int n, int hi, int wi, int ci, int ho, int
 extern "C" {
 
 const char* movae_bench_last_kernel(void) { return g_last_kernel; }
+
+int movae_bench_force_split(int s) {
+    const int prev = g_force_split;
+    g_force_split = s > 0 ? s : 0;
+    return prev;
+}
 
 int movae_bench_main_kernel_only(int on) {
     const int prev = g_bench_main_only ? 1 : 0;

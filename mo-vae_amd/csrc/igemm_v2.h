@@ -488,7 +488,7 @@ int launch_fwd2(const float* X, const float* W, float* Y, const Geom& g, const E
                 size_t ws_bytes, hipStream_t st) {
     const int gx = ceil_div(M, BM), gy = ceil_div(g.Nn, BN);
     const int nk = ceil_div(K, BK2);
-    int S = choose_split((long)gx * gy, nk, (size_t)M * g.Nn * sizeof(float), ws_bytes, ws != nullptr);
+    int S = choose_split(FORM_FWD, BM * BN, BK2, (long)gx * gy, nk, (size_t)M * g.Nn * sizeof(float), ws_bytes, ws != nullptr);
     const int per_split = ceil_div(nk, S);
     S = ceil_div(nk, per_split);
     float* slab = S > 1 ? static_cast<float*>(ws) : nullptr;
@@ -506,7 +506,7 @@ int launch_bwd2(const float* X, const float* W, float* Y, const Geom& g, const E
     const int gx = ceil_div(Mmax, BM), gy = ceil_div(g.Nn, BN);
     const int nk_max = ceil_div((long)ceil_div(g.KH, s) * ceil_div(g.KW, s) * g.Cr, BK2);
     const long total = (long)g.Nimg * g.Ho * g.Wo * g.Nn;
-    int S = choose_split((long)gx * gy * s * s, nk_max, (size_t)total * sizeof(float), ws_bytes, ws != nullptr);
+    int S = choose_split(FORM_BWD, BM * BN, BK2, (long)gx * gy * s * s, nk_max, (size_t)total * sizeof(float), ws_bytes, ws != nullptr);
     const int per_split = ceil_div(nk_max, S);
     S = ceil_div(nk_max, per_split);
     float* slab = S > 1 ? static_cast<float*>(ws) : nullptr;
@@ -521,7 +521,7 @@ int launch_wgrad2(const float* Sm, const float* Bg, float* dW, const WGeom& g, i
                   hipStream_t st) {
     const int M = g.Cs, N = g.KH * g.KW * g.Cb;
     const int gx = ceil_div(M, BM), gy = ceil_div(N, BN);
-    int Sp = choose_split((long)gx * gy, ceil_div(K, BK2), (size_t)M * N * sizeof(float), ws_bytes, ws != nullptr);
+    int Sp = choose_split(FORM_WGRAD, BM * BN, BK2, (long)gx * gy, ceil_div(K, BK2), (size_t)M * N * sizeof(float), ws_bytes, ws != nullptr);
     const int kchunk = ceil_div(ceil_div(K, Sp), BK2) * BK2;
     Sp = ceil_div(K, kchunk);
     const bool slab = Sp > 1 || accumulate;

@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--only", type=str, default="")
     ap.add_argument("--shapes", type=str, default="c2")
     ap.add_argument("--index", type=int, nargs="*", default=None)
+    ap.add_argument("--sweep-split", type=int, nargs="*", default=None,
+                    help="time every call with the split-K factor pinned to each value (0 = the library's heuristic)")
     a = ap.parse_args()
     lib = L.load()
     dev = torch.device("cuda:0")
@@ -90,10 +92,23 @@ def main():
         for name, (fn, args) in calls.items():
             if a.only and a.only != name:
                 continue
+            if a.sweep_split:
+                res = []
+                for sp in a.sweep_split:
+                    lib.movae_bench_force_split(sp)
+                    res.append((sp, time_call(fn, args, a.reps)))
+                lib.movae_bench_force_split(0)
+                fn(*(args + (0,)))
+                kern = lib.movae_bench_last_kernel().decode()
+                best = min(res, key=lambda r: r[1])
+                print(f"{line} {name:5s} {kern:22s} best S={best[0]:3d} {best[1]:6.1f}us | " +
+                      " ".join(f"{sp}:{us:.1f}" for sp, us in res), flush=True)
+                continue
             us = time_call(fn, args, a.reps)
             tot += us
             line += f" {name} {us:7.1f}us {gf / us * 1e3:6.1f}TF/s |"
-        print(line, flush=True)
+        if not a.sweep_split:
+            print(line, flush=True)
     print(f"sum {tot:.1f} us")
 
 
