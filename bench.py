@@ -109,10 +109,23 @@ def cpu_baseline(cfg, seconds):
                 sample=f"{n} steps of {cfg['label']} (oracle/step.py, PyTorch-CPU fp32, {dt:.1f} s)")
 
 
-def measure_dominant_kernel(recorded, device, reps=20):
-    """HIP-event timing of the conv-family launches captured from one real step: every captured call is
-    re-issued `reps` times back to back on the launch stream (same arguments, same live buffers) between
-    two events.  Returns per-call rows and the family aggregate."""
+FAMILY = [("conv", "movae_conv"), ("batchnorm", "movae_bn_"), ("loss", "movae_recon"), ("loss", "movae_kl"), ("loss", "movae_tc"),
+          ("vq", "movae_vq"), ("aggregation", "movae_gram"), ("aggregation", "movae_weights"), ("aggregation", "movae_combine"),
+          ("aggregation", "movae_gd_"), ("optimizer", "movae_adam"), ("optimizer", "movae_sumsq"), ("optimizer", "movae_scale_by"),
+          ("elementwise", "movae_")]
+
+
+def family_of(name):
+    return next(f for f, pre in FAMILY if name.startswith(pre))
+
+
+def measure_dominant_kernel(recorded, device, reps=20, live=False):
+    """HIP-event timing of the launches captured from one real step: every captured call is re-issued `reps`
+    times back to back on the launch stream between two events.
+    live=False (eager step): conv-family calls only, on freshly synthesized operands of the recorded geometry.
+    live=True  (calls recorded while the step was captured into a hipGraph, whose pool keeps every operand
+    alive): every C-ABI call of the step, on the step's own operands.
+    Returns (conv rows, {family: us per step} for the non-conv calls)."""
     import movae_amd._lib as L
 
     lib = L.load()
@@ -164,12 +177,22 @@ def measure_dominant_kernel(recorded, device, reps=20):
         e1.synchronize()
         return e0.elapsed_time(e1) * 1e3 / reps
 
+    other = {}
     for name, rec in recorded:
-        if name not in CONV_CALLS:
-            continue
         fn = getattr(lib, name)
-        a0, keep = synth(name, rec)
-        a = a0 + (0,)
+        if name not in CONV_CALLS:
+            if live:
+                fam = family_of(name)
+                us = timed(fn, tuple(rec))
+                other[fam] = other.get(fam, 0.0) + us
+                rows.append(dict(call=name, kernel=fam, shape=[x for x in rec if isinstance(x, int) and 0 < x < (1 << 31)][:4],
+                                 us=us, us_main=us, gflop=0.0))
+            continue
+        if live:
+            a = tuple(rec)
+        else:
+            a0, keep = synth(name, rec)
+            a = a0 + (0,)
         us = timed(fn, a)                      # the whole call: main kernel + split-K reduce / bias column-sum
         kernel = lib.movae_bench_last_kernel().decode()
         lib.movae_bench_main_kernel_only(1)
@@ -179,7 +202,7 @@ def measure_dominant_kernel(recorded, device, reps=20):
             lib.movae_bench_main_kernel_only(0)
         rows.append(dict(call=name, kernel=kernel, shape=list(conv_call_key(name, a)[1:]), us=us, us_main=us_main,
                          gflop=conv_call_flops(name, a) / 1e9))
-    return rows
+    return rows, other
 
 
 def main():
@@ -222,7 +245,7 @@ def main():
     net, opt, agg, a, pool = build_workload(cfg, device, capturable=use_graph)
     if dp is not None:
         dp.attach(net)
-    graphed = GraphedTrainStep(net, opt, agg, a, pool[0], dp=dp) if use_graph else None
+    graphed = GraphedTrainStep(net, opt, agg, a, pool[0], dp=dp, record_calls=(rank == 0 and not args.no_roofline)) if use_graph else None
     if graphed is not None and dp is not None:
         # watchdog: if graph replay + collective misbehaves on this node (observed when several ranks share one
         # GPU under gloo), every rank falls back to the eager step together
@@ -262,12 +285,17 @@ def main():
 
     roofline = None
     if rank == 0 and not args.no_roofline:
-        recorded = []
-        L.TRACE = lambda name, cargs: recorded.append((name, cargs))
-        keep = step(0, eager=True)  # noqa: F841 -- keeps this step's buffers alive while its launches are replayed
-        L.TRACE = None
+        live = graphed is not None and len(graphed.calls) > 0
+        if live:
+            recorded = graphed.calls  # operands owned by the captured graph's pool: re-issued in place
+        else:
+            recorded = []
+            L.TRACE = lambda name, cargs: recorded.append((name, cargs))
+            keep = step(0, eager=True)  # noqa: F841
+            L.TRACE = None
         torch.cuda.synchronize()
-        rows = measure_dominant_kernel(recorded, device)
+        all_rows, other = measure_dominant_kernel(recorded, device, live=live)
+        rows = [r for r in all_rows if r["call"] in CONV_CALLS]
         tot_us = sum(r["us"] for r in rows)
         tot_gf = sum(r["gflop"] for r in rows)
         traffic = None
@@ -296,10 +324,11 @@ def main():
                                             tflops=round(v["gflop"] * 1e3 / v["us"], 2) if v["us"] > 0 else 0.0)
                                     for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["us"])},
                         conv_family=dict(launches_per_step=len(rows), us_per_step=round(tot_us, 1), tflops=round(fam, 3),
-                                         frac=round(fam / FP32_MFMA_PEAK_TFLOPS, 4)))
+                                         frac=round(fam / FP32_MFMA_PEAK_TFLOPS, 4)),
+                        other_families_us_per_step={k: round(v, 1) for k, v in sorted(other.items())} if other else None)
         if args.kernel_table:
             with open(args.kernel_table, "w") as f:
-                json.dump(rows, f, indent=1)
+                json.dump(all_rows, f, indent=1)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(cfg, args.cpu_seconds)

@@ -383,33 +383,22 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4(const float* __restrict__ d
 }
 
 // ---- one-launch BatchNorm for short tensors ----------------------------------------------------------------------
-// rows <= small_rows(): a block owns 16 adjacent channels (one 64-byte segment of every row), walks all rows twice
-// (statistics, then apply; the second walk hits L2) and needs no partial buffer, no second and third launch.  The
-// step's deep layers (rows = batch * 16 ... batch) are launch-latency bound, not bandwidth bound.
-__device__ __forceinline__ double quad_col_sum(double v) {  // sum over the 16 lanes of a wave that share (lane & 3)
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
-}
-
-// v[8] per thread -> s[16], q[16] per block (thread t < 16 returns its channel's pair)
-__device__ __forceinline__ void small_fold(double (&v)[8], double (*sh)[4][8], int t, double& s, double& q) {
-    const int cl = t & 3, wave = t >> 6;
+// rows <= small_rows(): a block owns 4 adjacent channels (one 16-byte column), its 256 threads stride over the rows
+// (at most 4 rows per thread), twice -- statistics, then apply; the second walk hits L2 -- and needs no partial buffer
+// and no second / third launch.  These layers (rows = batch * 4 ... batch) are launch-latency bound: a dependent launch
+// costs ~1.7 us inside a replayed graph, more than the whole tensor takes to stream.  Longer tensors lose here (one
+// block per column cannot keep enough loads in flight: measured 31 us vs ~9 us for rows = 4096) and take the
+// three-launch path.
+// v[8] per thread -> (s[4], q[4]) of the block, returned to every thread through LDS
+__device__ __forceinline__ void small_fold(double (&v)[8], double (*sh)[8], int t) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = quad_col_sum(v[j]);
-    if ((t & 63) < 4)
+    for (int j = 0; j < 8; ++j) v[j] = wave_sum(v[j]);
+    if ((t & 63) == 0)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sh[wave][cl][j] = v[j];
+        for (int j = 0; j < 8; ++j) sh[t >> 6][j] = v[j];
     __syncthreads();
-    s = q = 0.0;
-    if (t < 16)
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            s += sh[w][t >> 2][t & 3];
-            q += sh[w][t >> 2][4 + (t & 3)];
-        }
+    for (int j = 0; j < 8; ++j) v[j] = sh[0][j] + sh[1][j] + sh[2][j] + sh[3][j];
 }
 
 __global__ __launch_bounds__(256) void bn_fwd_small(const float* __restrict__ y, const float* __restrict__ gamma,
@@ -418,76 +407,51 @@ __global__ __launch_bounds__(256) void bn_fwd_small(const float* __restrict__ y,
                                                     float* __restrict__ running_mean, float* __restrict__ running_var,
                                                     long long* __restrict__ nbt, int rows, int C, float eps, float momentum,
                                                     int act, float slope) {
-    __shared__ double sh[4][4][8];
-    __shared__ float stat[2][16];
-    const int t = threadIdx.x, cl = t & 3, rg = t >> 2;
-    const int c0 = blockIdx.x * 16 + cl * 4;
-    const bool ok = c0 < C;
+    __shared__ double sh[4][8];
+    const int t = threadIdx.x;
+    const int c0 = blockIdx.x * 4;
+    f32x4 x[4];
     double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (ok)
-        for (int r = rg; r < rows; r += 256) {
-            f32x4 x[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int rr = r + u * 64;
-                x[u] = rr < rows ? *reinterpret_cast<const f32x4*>(y + (long)rr * C + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+    for (int u = 0; u < 4; ++u) {  // rows <= 1024: every row of the column is held in registers for the apply pass
+        const int r = t + u * 256;
+        x[u] = r < rows ? *reinterpret_cast<const f32x4*>(y + (long)r * C + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    v[j] += (double)x[u][j];
-                    v[4 + j] += (double)x[u][j] * (double)x[u][j];
-                }
+        for (int j = 0; j < 4; ++j) {
+            v[j] += (double)x[u][j];
+            v[4 + j] += (double)x[u][j] * (double)x[u][j];
         }
-    double s, q;
-    small_fold(v, sh, t, s, q);
-    if (t < 16) {
-        const int c = blockIdx.x * 16 + t;
-        if (c < C) {
-            const double mean = s / rows;
-            double var = q / rows - mean * mean;
-            if (var < 0.0) var = 0.0;
-            const float m = (float)mean, rs = (float)(1.0 / sqrt(var + (double)eps));
-            save_mean[c] = m;
-            save_rstd[c] = rs;
-            stat[0][t] = m;
-            stat[1][t] = rs;
+    }
+    small_fold(v, sh, t);
+    f32x4 mu, rs;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const double mean = v[j] / rows;
+        double var = v[4 + j] / rows - mean * mean;
+        if (var < 0.0) var = 0.0;
+        mu[j] = (float)mean;
+        rs[j] = (float)(1.0 / sqrt(var + (double)eps));
+        if (t == j) {
+            const int c = c0 + j;
+            save_mean[c] = mu[j];
+            save_rstd[c] = rs[j];
             if (running_mean) {
                 const double unb = rows > 1 ? var * ((double)rows / (rows - 1)) : var;
                 running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
                 running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
             }
         }
-        if (nbt && blockIdx.x == 0 && t == 0) nbt[0] += 1;
     }
-    __syncthreads();
-    if (!ok) return;
-    f32x4 sc, sf;  // out = y * sc + sf
-    {
-        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0), be = *reinterpret_cast<const f32x4*>(beta + c0);
+    if (nbt && blockIdx.x == 0 && t == 0) nbt[0] += 1;
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0), be = *reinterpret_cast<const f32x4*>(beta + c0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            sc[j] = stat[1][cl * 4 + j];  // keep the 3-launch kernels' evaluation order: (y - mean) * rstd * gamma + beta
-            sf[j] = stat[0][cl * 4 + j];
-        }
-        for (int r = rg; r < rows; r += 256) {
-            f32x4 x[4];
+    for (int u = 0; u < 4; ++u) {
+        const int r = t + u * 256;
+        if (r < rows) {
+            f32x4 o;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int rr = r + u * 64;
-                if (rr < rows) x[u] = *reinterpret_cast<const f32x4*>(y + (long)rr * C + c0);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int rr = r + u * 64;
-                if (rr < rows) {
-                    f32x4 o;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = apply_act((x[u][j] - sf[j]) * sc[j] * ga[j] + be[j], act, slope);
-                    *reinterpret_cast<f32x4*>(out + (long)rr * C + c0) = o;
-                }
-            }
+            for (int j = 0; j < 4; ++j) o[j] = apply_act((x[u][j] - mu[j]) * rs[j] * ga[j] + be[j], act, slope);
+            *reinterpret_cast<f32x4*>(out + (long)r * C + c0) = o;
         }
     }
 }
@@ -498,90 +462,55 @@ __global__ __launch_bounds__(256) void bn_bwd_small(const float* __restrict__ do
                                                     float* __restrict__ dy, float* __restrict__ dgamma,
                                                     float* __restrict__ dbeta, int rows, int C, int act, float slope,
                                                     int accumulate) {
-    __shared__ double sh[4][4][8];
-    __shared__ float stat[2][16];
-    const int t = threadIdx.x, cl = t & 3, rg = t >> 2;
-    const int c0 = blockIdx.x * 16 + cl * 4;
-    const bool ok = c0 < C;
-    f32x4 mu = {0.f, 0.f, 0.f, 0.f}, rs = mu, ga = mu, be = mu;
-    if (ok) {
-        mu = *reinterpret_cast<const f32x4*>(mean + c0);
-        rs = *reinterpret_cast<const f32x4*>(rstd + c0);
-        ga = *reinterpret_cast<const f32x4*>(gamma + c0);
-        be = *reinterpret_cast<const f32x4*>(beta + c0);
-    }
+    __shared__ double sh[4][8];
+    const int t = threadIdx.x;
+    const int c0 = blockIdx.x * 4;
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c0), rs = *reinterpret_cast<const f32x4*>(rstd + c0);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0), be = *reinterpret_cast<const f32x4*>(beta + c0);
+    f32x4 xh[4], dz[4];  // kept in registers for the second pass
     double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (ok)
-        for (int r = rg; r < rows; r += 256) {
-            f32x4 yy[4], go[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int rr = r + u * 64;
-                const bool in = rr < rows;
-                yy[u] = in ? *reinterpret_cast<const f32x4*>(y + (long)rr * C + c0) : mu;
-                go[u] = in ? *reinterpret_cast<const f32x4*>(dout + (long)rr * C + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+    for (int u = 0; u < 4; ++u) {
+        const int r = t + u * 256;
+        const bool in = r < rows;
+        const f32x4 yy = in ? *reinterpret_cast<const f32x4*>(y + (long)r * C + c0) : mu;
+        const f32x4 go = in ? *reinterpret_cast<const f32x4*>(dout + (long)r * C + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float xh = (yy[u][j] - mu[j]) * rs[j];
-                    const float o = apply_act(xh * ga[j] + be[j], act, slope);
-                    const float dz = go[u][j] * act_grad_from_out(o, act, slope);
-                    v[j] += (double)dz;
-                    v[4 + j] += (double)dz * (double)xh;
-                }
-        }
-    double s, q;
-    small_fold(v, sh, t, s, q);
-    if (t < 16) {
-        const int c = blockIdx.x * 16 + t;
-        if (c < C) {
-            stat[0][t] = (float)(s / rows);
-            stat[1][t] = (float)(q / rows);
-            if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)q : (float)q;
-            if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s : (float)s;
+        for (int j = 0; j < 4; ++j) {
+            xh[u][j] = (yy[j] - mu[j]) * rs[j];
+            const float o = apply_act(xh[u][j] * ga[j] + be[j], act, slope);
+            dz[u][j] = go[j] * act_grad_from_out(o, act, slope);
+            v[j] += (double)dz[u][j];
+            v[4 + j] += (double)dz[u][j] * (double)xh[u][j];
         }
     }
-    __syncthreads();
-    if (!ok) return;
+    small_fold(v, sh, t);
     f32x4 m1, m2;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        m1[j] = stat[0][cl * 4 + j];
-        m2[j] = stat[1][cl * 4 + j];
-    }
-    for (int r = rg; r < rows; r += 256) {
-        f32x4 yy[4], go[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int rr = r + u * 64;
-            if (rr < rows) {
-                yy[u] = *reinterpret_cast<const f32x4*>(y + (long)rr * C + c0);
-                go[u] = *reinterpret_cast<const f32x4*>(dout + (long)rr * C + c0);
-            }
+        m1[j] = (float)(v[j] / rows);
+        m2[j] = (float)(v[4 + j] / rows);
+        if (t == j) {
+            const int c = c0 + j;
+            if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)v[4 + j] : (float)v[4 + j];
+            if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)v[j] : (float)v[j];
         }
+    }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int rr = r + u * 64;
-            if (rr < rows) {
-                f32x4 o4;
+    for (int u = 0; u < 4; ++u) {
+        const int r = t + u * 256;
+        if (r < rows) {
+            f32x4 o4;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float xh = (yy[u][j] - mu[j]) * rs[j];
-                    const float o = apply_act(xh * ga[j] + be[j], act, slope);
-                    const float dz = go[u][j] * act_grad_from_out(o, act, slope);
-                    o4[j] = ga[j] * rs[j] * (dz - m1[j] - xh * m2[j]);
-                }
-                *reinterpret_cast<f32x4*>(dy + (long)rr * C + c0) = o4;
-            }
+            for (int j = 0; j < 4; ++j) o4[j] = ga[j] * rs[j] * (dz[u][j] - m1[j] - xh[u][j] * m2[j]);
+            *reinterpret_cast<f32x4*>(dy + (long)r * C + c0) = o4;
         }
     }
 }
 
 inline int small_rows() {  // MOVAE_BN_SMALL_ROWS: largest row count served by the one-launch kernels (0 disables them)
-    static const int v = getenv("MOVAE_BN_SMALL_ROWS") ? atoi(getenv("MOVAE_BN_SMALL_ROWS")) : 4096;
-    return v;
+    static const int v = getenv("MOVAE_BN_SMALL_ROWS") ? atoi(getenv("MOVAE_BN_SMALL_ROWS")) : 1024;
+    return v < 1024 ? v : 1024;  // the kernels hold the whole column in registers: 4 rows per thread
 }
 
 inline int grid_for(long total) {
@@ -619,7 +548,7 @@ int movae_bn_act_fwd(const float* y, const float* gamma, const float* beta, floa
     hipStream_t st = (hipStream_t)stream;
     long long* nbt = training ? num_batches_tracked : nullptr;
     if (training && rows <= small_rows() && c % 4 == 0 && al16(y, out) && al16(gamma, beta)) {
-        hipLaunchKernelGGL(bn_fwd_small, dim3(ceil_div(c, 16)), dim3(256), 0, st, y, gamma, beta, out, save_mean, save_rstd,
+        hipLaunchKernelGGL(bn_fwd_small, dim3(c / 4), dim3(256), 0, st, y, gamma, beta, out, save_mean, save_rstd,
                            running_mean, running_var, nbt, rows, c, eps, momentum, act, slope);
         MOVAE_CHECK_LAUNCH("bn_fwd_small");
         return MOVAE_OK;
@@ -671,7 +600,7 @@ int movae_bn_act_bwd(const float* dout, const float* y, const float* gamma, cons
     MOVAE_CHECK_ARG(dout && y && gamma && beta && save_mean && save_rstd && dy, "movae_bn_act_bwd: null pointer");
     MOVAE_CHECK_ARG(rows > 0 && c > 0, "movae_bn_act_bwd: bad shape rows=%d c=%d", rows, c);
     if (rows <= small_rows() && c % 4 == 0 && al16(dout, y, dy) && al16(gamma, beta) && al16(save_mean, save_rstd)) {
-        hipLaunchKernelGGL(bn_bwd_small, dim3(ceil_div(c, 16)), dim3(256), 0, (hipStream_t)stream, dout, y, gamma, beta, save_mean,
+        hipLaunchKernelGGL(bn_bwd_small, dim3(c / 4), dim3(256), 0, (hipStream_t)stream, dout, y, gamma, beta, save_mean,
                            save_rstd, dy, dgamma, dbeta, rows, c, act, slope, accumulate);
         MOVAE_CHECK_LAUNCH("bn_bwd_small");
         return MOVAE_OK;

@@ -108,7 +108,7 @@ class GraphedTrainStep:
     graph 1 = forward/backward + flatten of every gradient into a static flat bucket, then
     `all_reduce(bucket)` over RCCL, then graph 2 = 1/N scaling + optimizer step on views of the bucket."""
 
-    def __init__(self, net, optimizer, aggregator, args, example, warmup=3, dp=None):
+    def __init__(self, net, optimizer, aggregator, args, example, warmup=3, dp=None, record_calls=False):
         if type(net).__name__ not in GRAPH_SAFE_ARCHS:
             raise NotImplementedError(f"{type(net).__name__}: forward syncs with the host (codebook usage / anneal counter); "
                                       "use the eager train_step")
@@ -130,10 +130,18 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         self.graph2 = None
         optimizer.zero_grad(set_to_none=True)
-        if dp is None:
-            with torch.cuda.graph(self.graph):
-                self.loss_dict, self.outputs = train_step(net, self.static_x, optimizer, aggregator, args)
-            return
+        #: (name, args) of every C-ABI launch in the captured step; the pointers stay valid (graph-pool memory) for the
+        #: life of this object, which lets bench.py re-issue and time each launch on the step's real operands
+        self.calls = []
+        if record_calls:
+            L.TRACE = lambda name, cargs: self.calls.append((name, cargs))
+        try:
+            if dp is None:
+                with torch.cuda.graph(self.graph):
+                    self.loss_dict, self.outputs = train_step(net, self.static_x, optimizer, aggregator, args)
+                return
+        finally:
+            L.TRACE = None
         params = [p for p in net.parameters() if p.requires_grad]
         # the bucket handed to the collective is an ordinary allocation (not graph-pool memory)
         self.flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=example.device)

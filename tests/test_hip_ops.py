@@ -129,8 +129,10 @@ def test_linear_fwd_bwd(M, shape):
 
 
 @pytest.mark.parametrize("shape", [(4, 8, 5, 5), (6, 32, 8, 8), (3, 20, 3, 3), (64, 512, 1, 1), (2, 3, 4, 4),
-                                   # rows > 4096: the three-launch path (partials / final / apply); 4096: the boundary
-                                   (32, 16, 16, 16), (5, 24, 31, 33), (16, 32, 16, 16), (9, 6, 24, 24)])
+                                   # rows > 1024: the three-launch path (partials / final / apply); 1024: the boundary of
+                                   # the one-launch kernels (whole column in registers)
+                                   (32, 16, 16, 16), (5, 24, 31, 33), (16, 32, 16, 16), (9, 6, 24, 24), (4, 8, 16, 16),
+                                   (5, 8, 15, 15), (2, 4, 1, 1), (3, 12, 17, 19)])
 def test_batchnorm_act_train(M, shape):
     ops, _ = M
     n, c, h, w = shape
