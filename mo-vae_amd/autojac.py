@@ -11,9 +11,14 @@ J lives in one padded device buffer whose columns follow the parameters' memory 
 aggregated vector is handed to .grad as views (no scatter copies), and a loss with no path to the
 features (e.g. VQ embedding_loss) costs no backward pass -- its row is simply left zero.
 """
+import os
+
 import torch
 
 from . import ops
+
+#: MOVAE_BATCHED_VJP=0 falls back to one torch.autograd pass per loss through the shared graph
+BATCHED_VJP = os.environ.get("MOVAE_BATCHED_VJP", "1") != "0"
 
 
 def _leaf_tensors(roots, excluded=()):
@@ -91,6 +96,122 @@ class JacobianBuffer:
                     dst.copy_(_mem_flat(g))
 
 
+def _group(t, g):
+    """Group g of a stacked gradient (a [G, ...] tensor or a list of G tensors)."""
+    return None if t is None else t[g]
+
+
+def _accumulate_stacked(a, b, G):
+    if a is None:
+        return b
+    if isinstance(a, (list, tuple)) or isinstance(b, (list, tuple)):
+        return [a[g] + b[g] for g in range(G)]
+    return a + b
+
+
+def _batched_pullback(features, feat_grads, rows, jb):
+    """Pull G = len(rows) cotangents of `features` back through the shared graph in ONE traversal and write row
+    rows[g] of the Jacobian arena for group g.
+
+    torch.autograd runs one pass per cotangent; the shared encoder's layers are tiny at the step's batch sizes,
+    so each pass is a chain of launches that cannot fill the chip.  The pull-back is linear in the cotangent and
+    per-sample for every op except BatchNorm (whose batch means are taken per group), so this walker executes
+    each node once on the stacked cotangents [G, ...]: nodes created by ops.py expose `backward_batched`
+    (dgrad over G*n images in one launch); any other node (views, reshapes, slices ...) is called once per group.
+    feat_grads[g][f] is d(loss rows[g]) / d(features[f]) or None."""
+    G = len(rows)
+    # ---- discover the graph below the features and count incoming edges -------------------------------------------
+    roots = []
+    for f, feat in enumerate(features):
+        fn = feat.grad_fn
+        if fn is None:
+            continue
+        gs = [feat_grads[g][f] for g in range(G)]
+        if all(x is None for x in gs):
+            continue
+        ref = next(x for x in gs if x is not None)
+        gs = [x if x is not None else torch.zeros_like(ref) for x in gs]
+        roots.append((fn, feat.output_nr, gs))
+    deps, seen, stack = {}, set(), [fn for fn, _, _ in roots]
+    while stack:
+        fn = stack.pop()
+        if fn in seen:
+            continue
+        seen.add(fn)
+        for nf, _ in fn.next_functions:
+            if nf is not None:
+                deps[nf] = deps.get(nf, 0) + 1
+                stack.append(nf)
+    pending = {}  # node -> {input_nr: stacked grad}
+    for fn, nr, gs in roots:
+        slot = pending.setdefault(fn, {})
+        slot[nr] = _accumulate_stacked(slot.get(nr), gs, G)
+    ready = [fn for fn in {r[0] for r in roots} if deps.get(fn, 0) == 0]
+    col = {id(p): (p, off) for p, off in zip(jb.params, jb.offsets)}
+    ops.GRAD_SINK_ROWS = [jb.sinks(r) for r in rows]
+    try:
+        while ready:
+            fn = ready.pop()
+            got = pending.pop(fn, {})
+            var = getattr(fn, "variable", None)
+            outs = None
+            if var is not None:  # AccumulateGrad: a leaf
+                ent = col.get(id(var))
+                if ent is not None and 0 in got:
+                    p, off = ent
+                    for g in range(G):
+                        src = _group(got[0], g)
+                        dst = jb.buf[rows[g]][off: off + p.numel()]
+                        if src.data_ptr() != dst.data_ptr():  # not already written in place through the sink
+                            dst.copy_(_mem_flat(src))
+                continue
+            edges = list(fn.next_functions)
+            if got:
+                n_in = max(got) + 1
+                args = [got.get(i) for i in range(n_in)]
+                cls = getattr(fn, "_forward_cls", None)
+                if cls is not None:  # a torch.autograd.Function node (ops.py): backward returns one value per forward ARGUMENT
+                    if hasattr(cls, "backward_batched"):
+                        outs = cls.backward_batched(fn, G, *args)
+                    else:
+                        per = []
+                        for g in range(G):
+                            r = cls.backward(fn, *[_group(a, g) for a in args])
+                            per.append(r if isinstance(r, tuple) else (r,))
+                        outs = tuple(None if all(per[g][i] is None for g in range(G)) else [per[g][i] for g in range(G)]
+                                     for i in range(len(per[0])))
+                    if not isinstance(outs, tuple):
+                        outs = (outs,)
+                    # edges exist per TENSOR argument; the ones that are not None are, in order, the arguments that need grad
+                    need = [i for i, nd in enumerate(fn.needs_input_grad) if nd]
+                    live = [j for j, (nf, _) in enumerate(edges) if nf is not None]
+                    if len(need) != len(live):
+                        raise NotImplementedError("cannot align backward outputs with graph edges")
+                    aligned = [None] * len(edges)
+                    for j, i in zip(live, need):
+                        aligned[j] = outs[i] if i < len(outs) else None
+                    outs = tuple(aligned)
+                else:  # a torch-native node (views, reshapes, slices ...): once per group
+                    per = []
+                    for g in range(G):
+                        r = fn(*[_group(a, g) for a in args])
+                        per.append(r if isinstance(r, tuple) else (r,))
+                    outs = tuple(None if all(per[g][i] is None for g in range(G)) else [per[g][i] for g in range(G)]
+                                 for i in range(len(per[0])))
+            for i, (nf, nr) in enumerate(edges):
+                if nf is None:
+                    continue
+                o = outs[i] if outs is not None and i < len(outs) else None
+                if o is not None:
+                    slot = pending.setdefault(nf, {})
+                    slot[nr] = _accumulate_stacked(slot.get(nr), o, G)
+                deps[nf] -= 1
+                if deps[nf] == 0:
+                    ready.append(nf)
+    finally:
+        ops.GRAD_SINK_ROWS = None
+
+
 def _aggregate_into_grads(jb, aggregator):
     g = aggregator(jb.J)
     for p, off in zip(jb.params, jb.offsets):
@@ -114,13 +235,23 @@ def mtl_backward(losses, features, aggregator, tasks_params=None, shared_params=
     shared_params = list(shared_params)
     jb = JacobianBuffer(shared_params, len(losses), features[0].device)
     feat_diff = [f for f in features if f.requires_grad]
+    feat_grads = []
     for i, (loss, tp) in enumerate(zip(losses, tasks_params)):
         tp = list(tp)
         got = torch.autograd.grad(loss, tp + feat_diff, retain_graph=True, allow_unused=True)
         for p, g in zip(tp, got[: len(tp)]):
             if g is not None:
                 _accumulate(p, g)
-        gf = got[len(tp):]
+        feat_grads.append(got[len(tp):])
+    live_rows = [i for i, gf in enumerate(feat_grads) if any(g is not None for g in gf)]
+    batched = BATCHED_VJP and shared_params and len(live_rows) > 1
+    if batched:
+        try:
+            _batched_pullback(feat_diff, [feat_grads[i] for i in live_rows], live_rows, jb)
+        except NotImplementedError:
+            batched = False  # a node the walker cannot align: one autograd pass per loss instead (rows are rewritten)
+    for i in ([] if batched else live_rows):
+        gf = feat_grads[i]
         live = [(f, g) for f, g in zip(feat_diff, gf) if g is not None]
         if not live or not shared_params:
             continue  # no path from this loss to the shared parameters: zero Jacobian row

@@ -484,6 +484,54 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ s
     }
 }
 
+// many slabs (S >= 64) over few outputs: 64 split-lanes x 4 float4 columns per block, 4 independent 16-byte loads in
+// flight per lane; the 16 split-lanes of a wave fold with shuffles, the 4 waves through LDS.  Deterministic.
+__global__ __launch_bounds__(256) void splitk_reduce_wide(const float* __restrict__ slab, float* __restrict__ out, long total,
+                                                          int S, int N, const float* __restrict__ bias, int act, float slope,
+                                                          int accumulate) {
+    const int il = threadIdx.x & 3, sl = threadIdx.x >> 2;
+    const long i = ((long)blockIdx.x * 4 + il) * 4;
+    f32x4 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (i < total)
+        for (int z = sl; z < S; z += 256) {
+            f32x4 x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int zz = z + u * 64;
+                x[u] = zz < S ? *reinterpret_cast<const f32x4*>(slab + (long)zz * total + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] += x[u];
+        }
+    f32x4 v = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float s = v[j];
+        s += __shfl_xor(s, 4, 64);
+        s += __shfl_xor(s, 8, 64);
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        v[j] = s;
+    }
+    __shared__ f32x4 sh[4][4];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) < 4) sh[w][il] = v;
+    __syncthreads();
+    if (threadIdx.x < 4 && i < total) {
+        v = (sh[0][il] + sh[1][il]) + (sh[2][il] + sh[3][il]);
+        f32x4 o = accumulate ? *reinterpret_cast<const f32x4*>(out + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float r = v[j];
+            if (bias) r += bias[(i + j) % N];
+            o[j] += apply_act(r, act, slope);
+        }
+        *reinterpret_cast<f32x4*>(out + i) = o;
+    }
+}
+
 // few slabs over many outputs: one thread per output, grid-stride
 __global__ __launch_bounds__(256) void splitk_reduce_flat(const float* __restrict__ slab, float* __restrict__ out, long total,
                                                           int S, int N, const float* __restrict__ bias, int act, float slope,
@@ -505,7 +553,11 @@ bool g_bench_main_only = false;  // movae_bench_main_kernel_only(): time the MFM
 inline int launch_reduce(const float* slab, float* out, long total, int S, int N, const float* bias, int act, float slope,
                          int accumulate, hipStream_t st) {
     if (g_bench_main_only) return MOVAE_OK;
-    if (S >= 8 && total <= (1L << 20)) {
+    if (S >= 64 && total % 4 == 0 && total <= (1L << 20) &&
+        ((reinterpret_cast<uintptr_t>(slab) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+        hipLaunchKernelGGL(splitk_reduce_wide, dim3(ceil_div(total, 16)), dim3(256), 0, st, slab, out, total, S, N, bias, act,
+                           slope, accumulate);
+    } else if (S >= 8 && total <= (1L << 20)) {
         hipLaunchKernelGGL(splitk_reduce, dim3(ceil_div(total, 16)), dim3(256), 0, st, slab, out, total, S, N, bias, act, slope,
                            accumulate);
     } else {

@@ -26,6 +26,26 @@ def _sink(param, shape):
     return torch.empty(shape, dtype=param.dtype, device=param.device)
 
 
+#: batched pull-back (autojac._batched_pullback): one sink dict per cotangent group, same keys as GRAD_SINK
+GRAD_SINK_ROWS = None
+
+
+def _sink_row(g, param, shape, zeros=False):
+    """Destination of group g's gradient of `param` in a batched backward (J row of that group when registered)."""
+    rows = GRAD_SINK_ROWS
+    dst = rows[g].pop(param.data_ptr(), None) if rows else None
+    if dst is not None and dst.numel() == param.numel():
+        return dst.view(shape)
+    return (torch.zeros if zeros else torch.empty)(shape, dtype=param.dtype, device=param.device)
+
+
+def _stacked(t, G):
+    """[G, ...] contiguous tensor from a stacked tensor or a list of G per-group tensors."""
+    if isinstance(t, (list, tuple)):
+        return torch.stack([_c(x) for x in t])
+    return _c(t)
+
+
 def _sink_zeros(param, shape):
     """An all-zero gradient: sinks are zero-initialised by their owner (autojac.JacobianBuffer) and written at most
     once, so a registered sink is returned untouched -- no fill launch."""
@@ -85,6 +105,14 @@ class NchwToNhwc(Function):
         _call("movae_nhwc_to_nchw", dy.data_ptr(), dx.data_ptr(), n, c, h, w, _st(dy))
         return dx
 
+    @staticmethod
+    def backward_batched(ctx, G, dy):
+        dy = _stacked(dy, G)
+        _, n, h, w, c = dy.shape
+        dx = torch.empty((G, n, c, h, w), dtype=dy.dtype, device=dy.device)
+        _call("movae_nhwc_to_nchw", dy.data_ptr(), dx.data_ptr(), G * n, c, h, w, _st(dy))
+        return (dx,)
+
 
 class NhwcToNchw(Function):
     @staticmethod
@@ -103,6 +131,14 @@ class NhwcToNchw(Function):
         dx = torch.empty((n, h, w, c), dtype=dy.dtype, device=dy.device)
         _call("movae_nchw_to_nhwc", dy.data_ptr(), dx.data_ptr(), n, c, h, w, _st(dy))
         return dx
+
+    @staticmethod
+    def backward_batched(ctx, G, dy):
+        dy = _stacked(dy, G)
+        _, n, c, h, w = dy.shape
+        dx = torch.empty((G, n, h, w, c), dtype=dy.dtype, device=dy.device)
+        _call("movae_nchw_to_nhwc", dy.data_ptr(), dx.data_ptr(), G * n, c, h, w, _st(dy))
+        return (dx,)
 
 
 def to_nhwc(x):
@@ -206,6 +242,46 @@ class Conv(Function):
             main.wait_stream(side)
         return dx, dw, db, None, None, None, None, None, None, None
 
+    @staticmethod
+    def backward_batched(ctx, G, dy):
+        """The backward of G cotangents at once (autojac._batched_pullback): dy is [G, n, ho, wo, co] (or a list of
+        G tensors).  dgrad runs as ONE launch over G*n images -- the pull-back is linear and per-sample, and the deep
+        layers' grids are far too small to fill the chip one cotangent at a time; wgrad runs per group (its
+        reduction is over the group's own pixels) straight into that group's Jacobian row."""
+        x, w, y, b = ctx.saved_tensors
+        dy = _stacked(dy, G)
+        n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad = ctx.geom
+        st = _st(dy)
+        wsp, wsb = _ws(dy)
+        if L.ACT[ctx.act]:
+            dpre = torch.empty_like(dy)
+            for g in range(G):
+                _call("movae_act_bwd", dy[g].data_ptr(), y.data_ptr(), dpre[g].data_ptr(), y.numel(), L.ACT[ctx.act],
+                      float(ctx.slope), st)
+            dy = dpre
+        pre = "movae_convT2d_" if ctx.transposed else "movae_conv2d_"
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((G,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+            wm = weight_mem(w)
+            _call(pre + "dgrad", dy.data_ptr(), wm.data_ptr(), dx.data_ptr(), G * n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad,
+                  wsp, wsb, st)
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or need_b:
+            wm_shape = (ci, kh, kw, co) if ctx.transposed else (co, kh, kw, ci)
+            dw, db = [], ([] if need_b else None)
+            for g in range(G):
+                dwm = _sink_row(g, w, wm_shape)
+                db_k = None
+                if need_b:
+                    dbg = _sink_row(g, b, (co,), zeros=ctx.bias_grad_is_zero)
+                    db.append(dbg)
+                    db_k = None if ctx.bias_grad_is_zero else dbg
+                _call(pre + "wgrad", dy[g].data_ptr(), x.data_ptr(), dwm.data_ptr(), L.ptr(db_k), n, hi, wi, ci, ho, wo, co, kh, kw,
+                      stride, pad, 0, wsp, wsb, st)
+                dw.append(dwm.permute(0, 3, 1, 2))
+        return dx, dw, db, None, None, None, None, None, None, None
+
 
 def conv2d(x, w, b=None, stride=1, pad=0, act=None, slope=0.01, bias_grad_is_zero=False):
     return Conv.apply(x, w, b, stride, pad, 0, False, act, slope, bias_grad_is_zero)
@@ -259,6 +335,27 @@ class BatchNormAct(Function):
               wsp, wsb, _st(y))
         return dy, dg, db, None, None, None, None, None, None, None, None
 
+    @staticmethod
+    def backward_batched(ctx, G, dout):
+        y, gamma, beta, mean, rstd = ctx.saved_tensors
+        if not ctx.training:
+            raise RuntimeError("BatchNormAct backward is implemented for training-mode statistics only")
+        dout = _stacked(dout, G)
+        c = y.shape[-1]
+        rows = y.numel() // c
+        dy = torch.empty_like(dout)
+        wsp, wsb = _ws(y)
+        dgs, dbs = [], []
+        for g in range(G):  # the batch statistics of the cotangent are per group
+            dg = _sink_row(g, gamma, gamma.shape)
+            db = _sink_row(g, beta, beta.shape)
+            _call("movae_bn_act_bwd", dout[g].data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
+                  rstd.data_ptr(), dy[g].data_ptr(), dg.data_ptr(), db.data_ptr(), rows, c, L.ACT[ctx.act], float(ctx.slope), 0,
+                  wsp, wsb, _st(y))
+            dgs.append(dg)
+            dbs.append(db)
+        return dy, dgs, dbs, None, None, None, None, None, None, None, None
+
 
 def batch_norm_act(y, gamma, beta, running_mean, running_var, training, eps=1e-5, momentum=0.1, act=None, slope=0.01,
                    num_batches_tracked=None):
@@ -286,6 +383,16 @@ class Activation(Function):
         _call("movae_act_bwd", dy.data_ptr(), y.data_ptr(), dx.data_ptr(), dy.numel(), L.ACT[ctx.act], float(ctx.slope), _st(dy))
         return dx, None, None
 
+    @staticmethod
+    def backward_batched(ctx, G, dy):
+        (y,) = ctx.saved_tensors
+        dy = _stacked(dy, G)
+        dx = torch.empty_like(dy)
+        for g in range(G):
+            _call("movae_act_bwd", dy[g].data_ptr(), y.data_ptr(), dx[g].data_ptr(), y.numel(), L.ACT[ctx.act], float(ctx.slope),
+                  _st(dy))
+        return dx, None, None
+
 
 def activation(x, act, slope=0.01):
     if not L.ACT[act]:
@@ -304,6 +411,10 @@ class Add(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        return dy, dy
+
+    @staticmethod
+    def backward_batched(ctx, G, dy):
         return dy, dy
 
 
