@@ -60,6 +60,12 @@ int movae_conv2d_dgrad(const float* dy, const float* w, float* dx,
 int movae_conv2d_wgrad(const float* dy, const float* x, float* dw, float* dbias,
                        int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad,
                        int accumulate, void* ws, size_t ws_bytes, movae_stream_t stream);
+/* wgrad for `groups` (<= 8) cotangents of one forward in ONE launch (batched pull-back of mtl_backward's K losses):
+ * dy is stacked [groups][n][ho][wo][co], x is shared; dw / dbias are HOST arrays of `groups` device pointers (rows of
+ * the Jacobian); dbias or any dbias[i] may be NULL. */
+int movae_conv2d_wgrad_grouped(int groups, const float* dy, const float* x, float* const* dw, float* const* dbias,
+                               int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad,
+                               int accumulate, void* ws, size_t ws_bytes, movae_stream_t stream);
 int movae_convT2d_fwd(const float* x, const float* w, const float* bias, float* y,
                       int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad,
                       int act, float slope, void* ws, size_t ws_bytes, movae_stream_t stream);
@@ -69,6 +75,9 @@ int movae_convT2d_dgrad(const float* dy, const float* w, float* dx,
 int movae_convT2d_wgrad(const float* dy, const float* x, float* dw, float* dbias,
                         int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad,
                         int accumulate, void* ws, size_t ws_bytes, movae_stream_t stream);
+int movae_convT2d_wgrad_grouped(int groups, const float* dy, const float* x, float* const* dw, float* const* dbias,
+                                int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad,
+                                int accumulate, void* ws, size_t ws_bytes, movae_stream_t stream);
 
 /* ---- BatchNorm2d (training statistics) + activation ------------------------------------------
  * nn.BatchNorm2d + nn.LeakyReLU   models/vae.py:123-125,157-158,169-170   (eps 1e-5, momentum 0.1)
@@ -86,6 +95,16 @@ int movae_bn_act_bwd(const float* dout, const float* y, const float* gamma, cons
                      const float* save_mean, const float* save_rstd, float* dy, float* dgamma, float* dbeta,
                      int rows, int c, int act, float slope, int accumulate,
                      void* ws, size_t ws_bytes, movae_stream_t stream);
+
+/* the same backward for `groups` (<= 8) cotangents of ONE forward at once (the K loss cotangents of
+ * mtl_backward, main.py:188-190): dout / dy are stacked [groups][rows][c]; y and the saved statistics are shared; the
+ * batch means of the cotangent are taken per group; dgamma / dbeta are HOST arrays of `groups` device pointers
+ * (rows of the Jacobian).  ws must hold 4096 + groups * (movae_bn_ws_bytes(rows, c) - 4096) bytes. */
+int movae_bn_act_bwd_grouped(int groups, const float* dout, const float* y, const float* gamma, const float* beta,
+                             const float* save_mean, const float* save_rstd, float* dy,
+                             float* const* dgamma, float* const* dbeta,
+                             int rows, int c, int act, float slope, int accumulate,
+                             void* ws, size_t ws_bytes, movae_stream_t stream);
 
 /* ---- element-wise ---------------------------------------------------------------------------- */
 int movae_act_fwd(const float* x, float* y, size_t n, int act, float slope, movae_stream_t stream);

@@ -34,9 +34,12 @@ SIGNATURES = {
     "movae_convT2d_fwd": (_conv_fwd, _i),
     "movae_convT2d_dgrad": (_conv_dgrad, _i),
     "movae_convT2d_wgrad": (_conv_wgrad, _i),
+    "movae_conv2d_wgrad_grouped": ([_i] + _conv_wgrad, _i),
+    "movae_convT2d_wgrad_grouped": ([_i] + _conv_wgrad, _i),
     "movae_bn_ws_bytes": ([_i, _i], _z),
     "movae_bn_act_fwd": ([_p] * 9 + [_i, _i, _f, _f, _i, _i, _f, _p, _z, _p], _i),
     "movae_bn_act_bwd": ([_p] * 9 + [_i, _i, _i, _f, _i, _p, _z, _p], _i),
+    "movae_bn_act_bwd_grouped": ([_i] + [_p] * 9 + [_i, _i, _i, _f, _i, _p, _z, _p], _i),
     "movae_act_fwd": ([_p, _p, _z, _i, _f, _p], _i),
     "movae_act_bwd": ([_p, _p, _p, _z, _i, _f, _p], _i),
     "movae_add": ([_p, _p, _p, _z, _p], _i),

@@ -7,6 +7,12 @@
 namespace {
 
 constexpr int MAX_PARTS = 256;
+constexpr int MAX_GROUPS = 8;  // == MOVAE_MAX_K: cotangent groups of one batched backward (blockIdx.y)
+
+struct BnOut {  // per-group destinations of dgamma / dbeta (rows of the Jacobian arena), by value in the kernel arguments
+    float* dgamma[MAX_GROUPS];
+    float* dbeta[MAX_GROUPS];
+};
 
 __host__ __device__ inline int pow2_ge(int v) {
     int p = 1;
@@ -168,9 +174,12 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
 
 // sums[c] = (mean dz, mean dz*xhat) ; dgamma / dbeta written.  One wave per channel.
 __global__ __launch_bounds__(64) void bn_bwd_final(const double* __restrict__ part, int nblk, int rows, int C,
-                                                   float* __restrict__ sums, float* __restrict__ dgamma,
-                                                   float* __restrict__ dbeta, int accumulate) {
-    const int c = blockIdx.x;
+                                                   float* __restrict__ sums, BnOut tab, int accumulate) {
+    const int c = blockIdx.x, grp = blockIdx.y;
+    part += (long)grp * nblk * C * 2;
+    sums += (long)grp * 2 * C;
+    float* __restrict__ dgamma = tab.dgamma[grp];
+    float* __restrict__ dbeta = tab.dbeta[grp];
     double s = 0.0, q = 0.0;
     for (int b = threadIdx.x; b < nblk; b += 64) {
         s += part[((long)b * C + c) * 2 + 0];
@@ -303,8 +312,12 @@ __global__ __launch_bounds__(256) void bn_bwd_partial4(const float* __restrict__
                                                        double* __restrict__ part, int rows, int C, int CQB,
                                                        int rows_per_block, int act, float slope,
                                                        unsigned* __restrict__ counter, float* __restrict__ sums,
-                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+                                                       BnOut tab, int accumulate, long gstride) {
     __shared__ double sh[8 * 256];
+    dout += (long)blockIdx.y * gstride;                  // cotangent group; y and the statistics are shared
+    part += (long)blockIdx.y * gridDim.x * C * 2;
+    float* __restrict__ dgamma = tab.dgamma[blockIdx.y];
+    float* __restrict__ dbeta = tab.dbeta[blockIdx.y];
     const int t = threadIdx.x, RG = 256 / CQB, cl = t % CQB, rg = t / CQB, CQ = C / 4;
     const long r0 = (long)blockIdx.x * rows_per_block, r1 = min((long)rows, r0 + rows_per_block);
     for (int cb = 0; cb < CQ; cb += CQB) {
@@ -366,6 +379,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4(const float* __restrict__ d
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ sums, float* __restrict__ dy, long total, int C,
                                                      int act, float slope) {
+    dout += (long)blockIdx.y * total;  // cotangent group (stacked [G][rows][C]); y is shared
+    dy += (long)blockIdx.y * total;
+    sums += (long)blockIdx.y * 2 * C;
     const long stride = (long)gridDim.x * blockDim.x, nv = total / 4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
         const int c = (int)((i * 4) % C);
@@ -459,12 +475,15 @@ __global__ __launch_bounds__(256) void bn_fwd_small(const float* __restrict__ y,
 __global__ __launch_bounds__(256) void bn_bwd_small(const float* __restrict__ dout, const float* __restrict__ y,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                    float* __restrict__ dy, float* __restrict__ dgamma,
-                                                    float* __restrict__ dbeta, int rows, int C, int act, float slope,
+                                                    float* __restrict__ dy, BnOut tab, int rows, int C, int act, float slope,
                                                     int accumulate) {
     __shared__ double sh[4][8];
     const int t = threadIdx.x;
     const int c0 = blockIdx.x * 4;
+    dout += (long)blockIdx.y * rows * C;  // cotangent group (stacked [G][rows][C]); y is shared
+    dy += (long)blockIdx.y * rows * C;
+    float* __restrict__ dgamma = tab.dgamma[blockIdx.y];
+    float* __restrict__ dbeta = tab.dbeta[blockIdx.y];
     const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c0), rs = *reinterpret_cast<const f32x4*>(rstd + c0);
     const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0), be = *reinterpret_cast<const f32x4*>(beta + c0);
     f32x4 xh[4], dz[4];  // kept in registers for the second pass
@@ -594,52 +613,73 @@ int movae_bn_act_fwd(const float* y, const float* gamma, const float* beta, floa
     return MOVAE_OK;
 }
 
-int movae_bn_act_bwd(const float* dout, const float* y, const float* gamma, const float* beta, const float* save_mean,
-                     const float* save_rstd, float* dy, float* dgamma, float* dbeta, int rows, int c, int act, float slope,
-                     int accumulate, void* ws, size_t ws_bytes, movae_stream_t stream) {
+int movae_bn_act_bwd_grouped(int groups, const float* dout, const float* y, const float* gamma, const float* beta,
+                             const float* save_mean, const float* save_rstd, float* dy, float* const* dgamma,
+                             float* const* dbeta, int rows, int c, int act, float slope, int accumulate, void* ws,
+                             size_t ws_bytes, movae_stream_t stream) {
     MOVAE_CHECK_ARG(dout && y && gamma && beta && save_mean && save_rstd && dy, "movae_bn_act_bwd: null pointer");
     MOVAE_CHECK_ARG(rows > 0 && c > 0, "movae_bn_act_bwd: bad shape rows=%d c=%d", rows, c);
-    if (rows <= small_rows() && c % 4 == 0 && al16(dout, y, dy) && al16(gamma, beta) && al16(save_mean, save_rstd)) {
-        hipLaunchKernelGGL(bn_bwd_small, dim3(c / 4), dim3(256), 0, (hipStream_t)stream, dout, y, gamma, beta, save_mean,
-                           save_rstd, dy, dgamma, dbeta, rows, c, act, slope, accumulate);
+    MOVAE_CHECK_ARG(groups >= 1 && groups <= MAX_GROUPS, "movae_bn_act_bwd: groups=%d out of range", groups);
+    hipStream_t st = (hipStream_t)stream;
+    BnOut tab;
+    for (int g = 0; g < MAX_GROUPS; ++g) {
+        tab.dgamma[g] = (g < groups && dgamma) ? dgamma[g] : nullptr;
+        tab.dbeta[g] = (g < groups && dbeta) ? dbeta[g] : nullptr;
+    }
+    const long total = (long)rows * c;
+    const bool vec = c % 4 == 0 && al16(dout, y, dy) && al16(gamma, beta) && al16(save_mean, save_rstd);
+    if (vec && rows <= small_rows()) {
+        hipLaunchKernelGGL(bn_bwd_small, dim3(c / 4, groups), dim3(256), 0, st, dout, y, gamma, beta, save_mean, save_rstd, dy, tab,
+                           rows, c, act, slope, accumulate);
         MOVAE_CHECK_LAUNCH("bn_bwd_small");
         return MOVAE_OK;
     }
-    MOVAE_CHECK_ARG(ws && ws_bytes >= movae_bn_ws_bytes(rows, c), "movae_bn_act_bwd: workspace too small");
-    hipStream_t st = (hipStream_t)stream;
+    MOVAE_CHECK_ARG(ws && ws_bytes >= MOVAE_WS_HEADER_BYTES + (size_t)groups * (movae_bn_ws_bytes(rows, c) - MOVAE_WS_HEADER_BYTES),
+                    "movae_bn_act_bwd: workspace too small");
     unsigned* counter = static_cast<unsigned*>(ws);
     double* part = reinterpret_cast<double*>(static_cast<char*>(ws) + MOVAE_WS_HEADER_BYTES);
-    const bool vec = c % 4 == 0 && al16(dout, y, dy) && al16(gamma, beta) && al16(save_mean, save_rstd);
-    int nblk;
-    float* sums;
     if (vec) {
         const Split4 s = make_split4(rows, c);
-        nblk = s.nblk;
-        sums = reinterpret_cast<float*>(part + (size_t)nblk * c * 2);
-        hipLaunchKernelGGL(bn_bwd_partial4, dim3(s.nblk), dim3(256), 0, st, dout, y, gamma, beta, save_mean, save_rstd, part,
-                           rows, c, s.CQB, s.rows_per_block, act, slope, in_launch_final() ? counter : nullptr, sums, dgamma,
-                           dbeta, accumulate);
-    } else {
-        const Split s = make_split(rows, c);
-        nblk = s.nblk;
-        hipLaunchKernelGGL(bn_bwd_partial, dim3(s.nblk), dim3(256), 0, st, dout, y, gamma, beta, save_mean, save_rstd, part,
-                           rows, c, s.CB, s.rows_per_block, act, slope);
+        const bool fold = in_launch_final() && groups == 1;
+        float* sums = reinterpret_cast<float*>(part + (size_t)groups * s.nblk * c * 2);
+        hipLaunchKernelGGL(bn_bwd_partial4, dim3(s.nblk, groups), dim3(256), 0, st, dout, y, gamma, beta, save_mean, save_rstd, part,
+                           rows, c, s.CQB, s.rows_per_block, act, slope, fold ? counter : nullptr, sums, tab, accumulate, total);
+        MOVAE_CHECK_LAUNCH("bn_bwd_partial");
+        if (!fold) {
+            hipLaunchKernelGGL(bn_bwd_final, dim3(c, groups), dim3(64), 0, st, part, s.nblk, rows, c, sums, tab, accumulate);
+            MOVAE_CHECK_LAUNCH("bn_bwd_final");
+        }
+        hipLaunchKernelGGL(bn_bwd_apply4, dim3(grid_for(total / 4), groups), dim3(256), 0, st, dout, y, gamma, beta, save_mean,
+                           save_rstd, sums, dy, total, c, act, slope);
+        MOVAE_CHECK_LAUNCH("bn_bwd_apply");
+        return MOVAE_OK;
     }
-    MOVAE_CHECK_LAUNCH("bn_bwd_partial");
-    if (!vec || !in_launch_final()) {
-        sums = reinterpret_cast<float*>(part + (size_t)nblk * c * 2);
-        hipLaunchKernelGGL(bn_bwd_final, dim3(c), dim3(64), 0, st, part, nblk, rows, c, sums, dgamma, dbeta, accumulate);
+    // generic path (C % 4 != 0 or unaligned operands): one group at a time
+    const Split s = make_split(rows, c);
+    float* sums = reinterpret_cast<float*>(part + (size_t)s.nblk * c * 2);
+    for (int g = 0; g < groups; ++g) {
+        BnOut one = tab;
+        one.dgamma[0] = tab.dgamma[g];
+        one.dbeta[0] = tab.dbeta[g];
+        hipLaunchKernelGGL(bn_bwd_partial, dim3(s.nblk), dim3(256), 0, st, dout + g * total, y, gamma, beta, save_mean, save_rstd,
+                           part, rows, c, s.CB, s.rows_per_block, act, slope);
+        MOVAE_CHECK_LAUNCH("bn_bwd_partial");
+        hipLaunchKernelGGL(bn_bwd_final, dim3(c, 1), dim3(64), 0, st, part, s.nblk, rows, c, sums, one, accumulate);
         MOVAE_CHECK_LAUNCH("bn_bwd_final");
+        hipLaunchKernelGGL(bn_bwd_apply, dim3(grid_for(total)), dim3(256), 0, st, dout + g * total, y, gamma, beta, save_mean,
+                           save_rstd, sums, dy + g * total, total, c, act, slope);
+        MOVAE_CHECK_LAUNCH("bn_bwd_apply");
     }
-    const long total = (long)rows * c;
-    if (vec)
-        hipLaunchKernelGGL(bn_bwd_apply4, dim3(grid_for(total / 4)), dim3(256), 0, st, dout, y, gamma, beta, save_mean, save_rstd,
-                           sums, dy, total, c, act, slope);
-    else
-        hipLaunchKernelGGL(bn_bwd_apply, dim3(grid_for(total)), dim3(256), 0, st, dout, y, gamma, beta, save_mean, save_rstd,
-                           sums, dy, total, c, act, slope);
-    MOVAE_CHECK_LAUNCH("bn_bwd_apply");
     return MOVAE_OK;
+}
+
+int movae_bn_act_bwd(const float* dout, const float* y, const float* gamma, const float* beta, const float* save_mean,
+                     const float* save_rstd, float* dy, float* dgamma, float* dbeta, int rows, int c, int act, float slope,
+                     int accumulate, void* ws, size_t ws_bytes, movae_stream_t stream) {
+    float* dg[1] = {dgamma};
+    float* db[1] = {dbeta};
+    return movae_bn_act_bwd_grouped(1, dout, y, gamma, beta, save_mean, save_rstd, dy, dg, db, rows, c, act, slope, accumulate, ws,
+                                    ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -746,24 +746,35 @@ int launch_wgrad_t(const float* S, const float* Bg, float* dW, const WGeom& g, i
     return MOVAE_OK;
 }
 
-int launch_wgrad(const float* S, const float* Bg, float* dW, const WGeom& g, int accumulate, void* ws, size_t ws_bytes,
-                 hipStream_t st) {
+int launch_wgrad1(const float* S, const float* Bg, float* dW, const WGeom& g, int accumulate, void* ws, size_t ws_bytes,
+                  hipStream_t st) {  // kernels without a group dimension (thin-channel ends, generic gather path)
+    const long Kl = (long)g.Nimg * g.Hs * g.Ws;
+    const int vec = ((g.Cs % 4 == 0 && aligned16(S)) ? 1 : 0) | ((g.Cb % 4 == 0 && aligned16(Bg)) ? 2 : 0);
+    const int N = g.KH * g.KW * g.Cb;
+    if (thin::thin_wgrad_ok(g) && ws) return (g_last_kernel = "thin_wgrad", thin::launch_thin_wgrad(S, Bg, dW, g, (int)Kl, accumulate, ws, ws_bytes, st));
+    if (N <= 32) return (g_last_kernel = "igemm_wgrad<128,32>", launch_wgrad_t<128, 32>(S, Bg, dW, g, (int)Kl, vec, accumulate, ws, ws_bytes, st));
+    return (g_last_kernel = "igemm_wgrad<64,64>", launch_wgrad_t<64, 64>(S, Bg, dW, g, (int)Kl, vec, accumulate, ws, ws_bytes, st));
+}
+
+// G cotangent groups of one layer: group i reads S + i * s_gs and Bg + i * b_gs (0 = shared operand), writes dW[i]
+int launch_wgrad(const float* S, const float* Bg, float* const* dW, int G, long s_gs, long b_gs, const WGeom& g, int accumulate,
+                 void* ws, size_t ws_bytes, hipStream_t st) {
     const long Kl = (long)g.Nimg * g.Hs * g.Ws;
     if (Kl <= 0 || Kl > 0x7fffffffL || g.Cs <= 0 || g.Cb <= 0) {
         movae_set_error("wgrad: bad shape K=%ld Cs=%d Cb=%d", Kl, g.Cs, g.Cb);
         return MOVAE_EINVAL;
     }
-    const int vec = ((g.Cs % 4 == 0 && aligned16(S)) ? 1 : 0) | ((g.Cb % 4 == 0 && aligned16(Bg)) ? 2 : 0);
+    const bool vec = g.Cs % 4 == 0 && g.Cb % 4 == 0 && aligned16(S) && aligned16(Bg) && s_gs % 4 == 0 && b_gs % 4 == 0;
     const int N = g.KH * g.KW * g.Cb;
-    if (thin::thin_wgrad_ok(g) && ws) return (g_last_kernel = "thin_wgrad", thin::launch_thin_wgrad(S, Bg, dW, g, (int)Kl, accumulate, ws, ws_bytes, st));
-    if (vec == 3) {  // fast path (igemm_v2.h)
-        if (N <= 32) return (g_last_kernel = "igemm2_wgrad<128,32>", v2::launch_wgrad2<128, 32>(S, Bg, dW, g, (int)Kl, accumulate, ws, ws_bytes, st));
-        if (g.Cs >= 128 && (long)(g.Cs / 128) * (N / 128) * (Kl / 512) >= big_tile_min())
-            return (g_last_kernel = "igemm2_wgrad<128,128>", v2::launch_wgrad2<128, 128>(S, Bg, dW, g, (int)Kl, accumulate, ws, ws_bytes, st));
-        return (g_last_kernel = "igemm2_wgrad<64,64>", v2::launch_wgrad2<64, 64>(S, Bg, dW, g, (int)Kl, accumulate, ws, ws_bytes, st));
+    if (vec && !(thin::thin_wgrad_ok(g) && ws)) {  // fast path (igemm_v2.h)
+        if (N <= 32) return (g_last_kernel = "igemm2_wgrad<128,32>", v2::launch_wgrad2<128, 32>(S, Bg, dW, G, s_gs, b_gs, g, (int)Kl, accumulate, ws, ws_bytes, st));
+        if (g.Cs >= 128 && (long)(g.Cs / 128) * (N / 128) * (Kl / 512) * G >= big_tile_min())
+            return (g_last_kernel = "igemm2_wgrad<128,128>", v2::launch_wgrad2<128, 128>(S, Bg, dW, G, s_gs, b_gs, g, (int)Kl, accumulate, ws, ws_bytes, st));
+        return (g_last_kernel = "igemm2_wgrad<64,64>", v2::launch_wgrad2<64, 64>(S, Bg, dW, G, s_gs, b_gs, g, (int)Kl, accumulate, ws, ws_bytes, st));
     }
-    if (N <= 32) return (g_last_kernel = "igemm_wgrad<128,32>", launch_wgrad_t<128, 32>(S, Bg, dW, g, (int)Kl, vec, accumulate, ws, ws_bytes, st));
-    return (g_last_kernel = "igemm_wgrad<64,64>", launch_wgrad_t<64, 64>(S, Bg, dW, g, (int)Kl, vec, accumulate, ws, ws_bytes, st));
+    for (int i = 0; i < G; ++i)
+        if (int rc = launch_wgrad1(S + i * s_gs, Bg + i * b_gs, dW[i], g, accumulate, ws, ws_bytes, st)) return rc;
+    return MOVAE_OK;
 }
 
 int check_conv_shape(const char* who, int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride,
@@ -828,18 +839,32 @@ int movae_conv2d_dgrad(const float* dy, const float* w, float* dx, int n, int hi
     return launch_bwd(dy, w, dx, g, Epilogue{nullptr, MOVAE_ACT_NONE, 0.f}, ws, ws_bytes, (hipStream_t)stream);
 }
 
-int movae_conv2d_wgrad(const float* dy, const float* x, float* dw, float* dbias, int n, int hi, int wi, int ci, int ho,
-                       int wo, int co, int kh, int kw, int stride, int pad, int accumulate, void* ws, size_t ws_bytes,
-                       movae_stream_t stream) {
+int movae_conv2d_wgrad_grouped(int groups, const float* dy, const float* x, float* const* dw, float* const* dbias, int n, int hi,
+                               int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad, int accumulate,
+                               void* ws, size_t ws_bytes, movae_stream_t stream) {
     void* ws_full = ws;
     const size_t ws_full_bytes = ws_bytes;
     MOVAE_WS_SCRATCH(ws, ws_bytes);
-    MOVAE_CHECK_ARG(dy && x && dw, "movae_conv2d_wgrad: null pointer");
+    MOVAE_CHECK_ARG(dy && x && dw && groups >= 1 && groups <= 8, "movae_conv2d_wgrad: null pointer / bad group count");
+    for (int i = 0; i < groups; ++i) MOVAE_CHECK_ARG(dw[i], "movae_conv2d_wgrad: null dw");
     if (int rc = check_conv_shape("movae_conv2d_wgrad", n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, false)) return rc;
     WGeom g{n, ho, wo, co, hi, wi, ci, kh, kw, stride, pad};
-    if (int rc = launch_wgrad(dy, x, dw, g, accumulate, ws, ws_bytes, (hipStream_t)stream)) return rc;
-    if (dbias && !g_bench_main_only) return movae_colsum(dy, dbias, n * ho * wo, co, accumulate, ws_full, ws_full_bytes, stream);
+    const long dy_gs = (long)n * ho * wo * co;  // dy is stacked [groups][n][ho][wo][co]; x is shared
+    if (int rc = launch_wgrad(dy, x, dw, groups, dy_gs, 0, g, accumulate, ws, ws_bytes, (hipStream_t)stream)) return rc;
+    if (dbias && !g_bench_main_only)
+        for (int i = 0; i < groups; ++i)
+            if (dbias[i])
+                if (int rc = movae_colsum(dy + i * dy_gs, dbias[i], n * ho * wo, co, accumulate, ws_full, ws_full_bytes, stream)) return rc;
     return MOVAE_OK;
+}
+
+int movae_conv2d_wgrad(const float* dy, const float* x, float* dw, float* dbias, int n, int hi, int wi, int ci, int ho,
+                       int wo, int co, int kh, int kw, int stride, int pad, int accumulate, void* ws, size_t ws_bytes,
+                       movae_stream_t stream) {
+    float* dws[1] = {dw};
+    float* dbs[1] = {dbias};
+    return movae_conv2d_wgrad_grouped(1, dy, x, dws, dbias ? dbs : nullptr, n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, accumulate,
+                                      ws, ws_bytes, stream);
 }
 
 int movae_convT2d_fwd(const float* x, const float* w, const float* bias, float* y, int n, int hi, int wi, int ci, int ho,
@@ -862,18 +887,32 @@ int movae_convT2d_dgrad(const float* dy, const float* w, float* dx, int n, int h
     return launch_fwd(dy, w, dx, g, Epilogue{nullptr, MOVAE_ACT_NONE, 0.f}, ws, ws_bytes, (hipStream_t)stream);
 }
 
-int movae_convT2d_wgrad(const float* dy, const float* x, float* dw, float* dbias, int n, int hi, int wi, int ci, int ho,
-                        int wo, int co, int kh, int kw, int stride, int pad, int accumulate, void* ws, size_t ws_bytes,
-                        movae_stream_t stream) {
+int movae_convT2d_wgrad_grouped(int groups, const float* dy, const float* x, float* const* dw, float* const* dbias, int n, int hi,
+                                int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad, int accumulate,
+                                void* ws, size_t ws_bytes, movae_stream_t stream) {
     void* ws_full = ws;
     const size_t ws_full_bytes = ws_bytes;
     MOVAE_WS_SCRATCH(ws, ws_bytes);
-    MOVAE_CHECK_ARG(dy && x && dw, "movae_convT2d_wgrad: null pointer");
+    MOVAE_CHECK_ARG(dy && x && dw && groups >= 1 && groups <= 8, "movae_convT2d_wgrad: null pointer / bad group count");
+    for (int i = 0; i < groups; ++i) MOVAE_CHECK_ARG(dw[i], "movae_convT2d_wgrad: null dw");
     if (int rc = check_conv_shape("movae_convT2d_wgrad", n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, true)) return rc;
     WGeom g{n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad};
-    if (int rc = launch_wgrad(x, dy, dw, g, accumulate, ws, ws_bytes, (hipStream_t)stream)) return rc;
-    if (dbias && !g_bench_main_only) return movae_colsum(dy, dbias, n * ho * wo, co, accumulate, ws_full, ws_full_bytes, stream);
+    const long dy_gs = (long)n * ho * wo * co;  // the small side (x) is shared, the gathered side (dy) is per group
+    if (int rc = launch_wgrad(x, dy, dw, groups, 0, dy_gs, g, accumulate, ws, ws_bytes, (hipStream_t)stream)) return rc;
+    if (dbias && !g_bench_main_only)
+        for (int i = 0; i < groups; ++i)
+            if (dbias[i])
+                if (int rc = movae_colsum(dy + i * dy_gs, dbias[i], n * ho * wo, co, accumulate, ws_full, ws_full_bytes, stream)) return rc;
     return MOVAE_OK;
+}
+
+int movae_convT2d_wgrad(const float* dy, const float* x, float* dw, float* dbias, int n, int hi, int wi, int ci, int ho,
+                        int wo, int co, int kh, int kw, int stride, int pad, int accumulate, void* ws, size_t ws_bytes,
+                        movae_stream_t stream) {
+    float* dws[1] = {dw};
+    float* dbs[1] = {dbias};
+    return movae_convT2d_wgrad_grouped(1, dy, x, dws, dbias ? dbs : nullptr, n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, accumulate,
+                                       ws, ws_bytes, stream);
 }
 
 }  // extern "C"

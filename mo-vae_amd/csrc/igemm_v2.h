@@ -378,9 +378,16 @@ __global__ __launch_bounds__(256) void igemm2_bwd(const float* __restrict__ X, c
 }
 
 // ------------------------------------------------------------------------------------------------
+// Cotangent groups (batched pull-back): blockIdx.z = group * Sp + split.  A group adds s_gs / b_gs floats to the
+// operand bases (0 for the operand the groups share) and owns its own Sp slabs / its own destination.
+struct WOut {
+    float* p[8];
+};
+
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void igemm2_wgrad(const float* __restrict__ Sm, const float* __restrict__ Bg,
-                                                    float* __restrict__ out, WGeom g, int K, int kchunk, int to_slab) {
+                                                    float* __restrict__ out, WGeom g, int K, int kchunk, int to_slab, int Sp,
+                                                    long s_gs, long b_gs, WOut tab) {
     using T = T2<BM, BN>;
     constexpr int ASZ = BK2 * T::LDKA, BSZ = BK2 * T::LDKB;
     __shared__ __attribute__((aligned(16))) float As[(T::DB ? 2 : 1) * ASZ];
@@ -388,7 +395,10 @@ __global__ __launch_bounds__(256) void igemm2_wgrad(const float* __restrict__ Sm
     const int t = threadIdx.x;
     const int M = g.Cs, N = g.KH * g.KW * g.Cb;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int k_begin = blockIdx.z * kchunk, k_end = min(K, k_begin + kchunk);
+    const int grp = blockIdx.z / Sp, split = blockIdx.z - grp * Sp;
+    Sm += grp * s_gs;
+    Bg += grp * b_gs;
+    const int k_begin = split * kchunk, k_end = min(K, k_begin + kchunk);
     constexpr int AQ = BM / 4, BQ = BN / 4;
     constexpr int ACH = BK2 * AQ / 256, BCH = BK2 * BQ / 256;
     constexpr int AKS = 256 / AQ, BKS = 256 / BQ;
@@ -465,7 +475,7 @@ __global__ __launch_bounds__(256) void igemm2_wgrad(const float* __restrict__ Sm
     }
 
     const int lane = t & 63, half = lane >> 5, l31 = lane & 31;
-    float* dst = to_slab ? out + (long)blockIdx.z * M * N : out;
+    float* dst = to_slab ? out + (long)blockIdx.z * M * N : tab.p[grp];
 #pragma unroll
     for (int tn = 0; tn < T::TN; ++tn) {
         const int n = n0 + wn * T::TN * 32 + tn * 32 + l31;
@@ -517,22 +527,29 @@ int launch_bwd2(const float* X, const float* W, float* Y, const Geom& g, const E
 }
 
 template <int BM, int BN>
-int launch_wgrad2(const float* Sm, const float* Bg, float* dW, const WGeom& g, int K, int accumulate, void* ws, size_t ws_bytes,
-                  hipStream_t st) {
+int launch_wgrad2(const float* Sm, const float* Bg, float* const* dW, int G, long s_gs, long b_gs, const WGeom& g, int K,
+                  int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
     const int M = g.Cs, N = g.KH * g.KW * g.Cb;
     const int gx = ceil_div(M, BM), gy = ceil_div(N, BN);
-    int Sp = choose_split(FORM_WGRAD, BM * BN, BK2, (long)gx * gy, ceil_div(K, BK2), (size_t)M * N * sizeof(float), ws_bytes, ws != nullptr);
+    // the G groups run side by side, so the split factor is chosen for G times the tiles
+    int Sp = choose_split(FORM_WGRAD, BM * BN, BK2, (long)gx * gy * G, ceil_div(K, BK2), (size_t)M * N * sizeof(float) * G, ws_bytes,
+                          ws != nullptr);
     const int kchunk = ceil_div(ceil_div(K, Sp), BK2) * BK2;
     Sp = ceil_div(K, kchunk);
     const bool slab = Sp > 1 || accumulate;
-    if (slab && (!ws || (size_t)M * N * sizeof(float) * Sp > ws_bytes)) {
-        movae_set_error("wgrad: workspace too small (%zu bytes) for %d splits of %dx%d", ws_bytes, Sp, M, N);
+    if (slab && (!ws || (size_t)M * N * sizeof(float) * Sp * G > ws_bytes)) {
+        movae_set_error("wgrad: workspace too small (%zu bytes) for %d x %d splits of %dx%d", ws_bytes, G, Sp, M, N);
         return MOVAE_EINVAL;
     }
-    float* out = slab ? static_cast<float*>(ws) : dW;
-    hipLaunchKernelGGL((igemm2_wgrad<BM, BN>), dim3(gx, gy, Sp), dim3(256), 0, st, Sm, Bg, out, g, K, kchunk, slab ? 1 : 0);
+    WOut tab;
+    for (int i = 0; i < 8; ++i) tab.p[i] = i < G ? dW[i] : nullptr;
+    float* out = slab ? static_cast<float*>(ws) : nullptr;
+    hipLaunchKernelGGL((igemm2_wgrad<BM, BN>), dim3(gx, gy, Sp * G), dim3(256), 0, st, Sm, Bg, out, g, K, kchunk, slab ? 1 : 0, Sp,
+                       s_gs, b_gs, tab);
     MOVAE_CHECK_LAUNCH("igemm2_wgrad");
-    if (slab) return launch_reduce(out, dW, (long)M * N, Sp, N, nullptr, 0, 0.f, accumulate, st);
+    if (slab)
+        for (int i = 0; i < G; ++i)
+            if (int rc = launch_reduce(out + (long)i * Sp * M * N, dW[i], (long)M * N, Sp, N, nullptr, 0, 0.f, accumulate, st)) return rc;
     return MOVAE_OK;
 }
 

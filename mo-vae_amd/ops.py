@@ -5,6 +5,8 @@ libmovae_hip.so.  Activations are NHWC tensors of shape [N, H, W, C] (contiguous
 are the reference's parameter shapes ([Co,Ci,kh,kw] / [Ci,Co,kh,kw]) held in channels_last memory
 so that `w.permute(0,2,3,1)` is the contiguous [.,kh,kw,.] image the kernels read.
 """
+import ctypes as C
+
 import torch
 from torch.autograd import Function
 
@@ -246,8 +248,8 @@ class Conv(Function):
     def backward_batched(ctx, G, dy):
         """The backward of G cotangents at once (autojac._batched_pullback): dy is [G, n, ho, wo, co] (or a list of
         G tensors).  dgrad runs as ONE launch over G*n images -- the pull-back is linear and per-sample, and the deep
-        layers' grids are far too small to fill the chip one cotangent at a time; wgrad runs per group (its
-        reduction is over the group's own pixels) straight into that group's Jacobian row."""
+        layers' grids are far too small to fill the chip one cotangent at a time; wgrad is one grouped launch (each
+        group reduces over its own pixels, x is shared) writing straight into the groups' Jacobian rows."""
         x, w, y, b = ctx.saved_tensors
         dy = _stacked(dy, G)
         n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad = ctx.geom
@@ -269,17 +271,14 @@ class Conv(Function):
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] or need_b:
             wm_shape = (ci, kh, kw, co) if ctx.transposed else (co, kh, kw, ci)
-            dw, db = [], ([] if need_b else None)
-            for g in range(G):
-                dwm = _sink_row(g, w, wm_shape)
-                db_k = None
-                if need_b:
-                    dbg = _sink_row(g, b, (co,), zeros=ctx.bias_grad_is_zero)
-                    db.append(dbg)
-                    db_k = None if ctx.bias_grad_is_zero else dbg
-                _call(pre + "wgrad", dy[g].data_ptr(), x.data_ptr(), dwm.data_ptr(), L.ptr(db_k), n, hi, wi, ci, ho, wo, co, kh, kw,
-                      stride, pad, 0, wsp, wsb, st)
-                dw.append(dwm.permute(0, 3, 1, 2))
+            dwm = [_sink_row(g, w, wm_shape) for g in range(G)]
+            db = [_sink_row(g, b, (co,), zeros=ctx.bias_grad_is_zero) for g in range(G)] if need_b else None
+            arr = C.c_void_p * G
+            dbp = arr(*[t.data_ptr() for t in db]) if (need_b and not ctx.bias_grad_is_zero) else None
+            # one grouped launch: blockIdx.z = group * splits + split, x is read by every group, dy by its own
+            _call(pre + "wgrad_grouped", G, dy.data_ptr(), x.data_ptr(), arr(*[t.data_ptr() for t in dwm]), dbp, n, hi, wi, ci, ho, wo,
+                  co, kh, kw, stride, pad, 0, wsp, wsb, st)
+            dw = [t.permute(0, 3, 1, 2) for t in dwm]
         return dx, dw, db, None, None, None, None, None, None, None
 
 
@@ -345,15 +344,13 @@ class BatchNormAct(Function):
         rows = y.numel() // c
         dy = torch.empty_like(dout)
         wsp, wsb = _ws(y)
-        dgs, dbs = [], []
-        for g in range(G):  # the batch statistics of the cotangent are per group
-            dg = _sink_row(g, gamma, gamma.shape)
-            db = _sink_row(g, beta, beta.shape)
-            _call("movae_bn_act_bwd", dout[g].data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
-                  rstd.data_ptr(), dy[g].data_ptr(), dg.data_ptr(), db.data_ptr(), rows, c, L.ACT[ctx.act], float(ctx.slope), 0,
-                  wsp, wsb, _st(y))
-            dgs.append(dg)
-            dbs.append(db)
+        dgs = [_sink_row(g, gamma, gamma.shape) for g in range(G)]
+        dbs = [_sink_row(g, beta, beta.shape) for g in range(G)]
+        arr = C.c_void_p * G
+        # one grouped call: the batch statistics of the cotangent are taken per group inside the kernels (blockIdx.y)
+        _call("movae_bn_act_bwd_grouped", G, dout.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
+              rstd.data_ptr(), dy.data_ptr(), arr(*[t.data_ptr() for t in dgs]), arr(*[t.data_ptr() for t in dbs]), rows, c,
+              L.ACT[ctx.act], float(ctx.slope), 0, wsp, wsb, _st(y))
         return dy, dgs, dbs, None, None, None, None, None, None, None, None
 
 
