@@ -37,7 +37,7 @@ CONFIGS = {
 }
 
 CONV_CALLS = {"movae_conv2d_fwd", "movae_conv2d_dgrad", "movae_conv2d_wgrad", "movae_convT2d_fwd", "movae_convT2d_dgrad",
-              "movae_convT2d_wgrad"}
+              "movae_convT2d_wgrad", "movae_conv2d_wgrad_grouped", "movae_convT2d_wgrad_grouped"}
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 HBM_PEAK_GBS = 8000.0
 
@@ -47,18 +47,32 @@ class Args:
         self.__dict__.update(kw)
 
 
+def _geom_offset(name, a):
+    """(index of `n` in the C-ABI argument tuple, cotangent groups) -- the grouped wgrads carry `groups` first."""
+    if name.endswith("_grouped"):
+        return 5, int(a[0])
+    return (4 if name.endswith("_fwd") or name.endswith("_wgrad") else 3), 1
+
+
 def conv_call_flops(name, a):
     """Nominal algorithmic FLOPs of one conv-family C-ABI call (2 * MACs, padding taps counted the way
     SURVEY 8d counts them): conv = out_pixels*k*k*ci*co, transposed conv = in_pixels*k*k*ci*co."""
-    off = 4 if name.endswith("_fwd") or name.endswith("_wgrad") else 3
+    off, groups = _geom_offset(name, a)
     n, hi, wi, ci, ho, wo, co, kh, kw = a[off: off + 9]
     pix = hi * wi if "convT" in name else ho * wo
-    return 2.0 * n * pix * kh * kw * ci * co
+    return 2.0 * groups * n * pix * kh * kw * ci * co
+
+
+def conv_call_bytes(name, a):
+    """Algorithmic bytes of one conv-family call: each operand and the result touched once (fp32)."""
+    off, groups = _geom_offset(name, a)
+    n, hi, wi, ci, ho, wo, co, kh, kw = a[off: off + 9]
+    return 4.0 * (n * hi * wi * ci + groups * (n * ho * wo * co + kh * kw * ci * co))
 
 
 def conv_call_key(name, a):
-    off = 4 if name.endswith("_fwd") or name.endswith("_wgrad") else 3
-    return (name,) + tuple(a[off: off + 11])
+    off, groups = _geom_offset(name, a)
+    return (name,) + tuple(a[off: off + 11]) + ((groups,) if groups > 1 else ())
 
 
 def build_workload(cfg, device, seed=0, capturable=False):
@@ -135,14 +149,20 @@ def measure_dominant_kernel(recorded, device, reps=20, live=False):
     def synth(name, a):
         """Fresh, owned operand buffers of the recorded call's geometry (the step's own activations are
         recycled by the caching allocator, so their recorded addresses must not be reused)."""
-        off = 4 if name.endswith("_fwd") or name.endswith("_wgrad") else 3
+        off, groups = _geom_offset(name, a)
         n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad = a[off: off + 11]
         x = torch.randn(n * hi * wi * ci, device=device)
-        y = torch.randn(n * ho * wo * co, device=device)
+        y = torch.randn(groups * n * ho * wo * co, device=device)
         w = torch.randn(co * kh * kw * ci, device=device) * 0.05
         b = torch.randn(co, device=device)
         geom = (n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad)
         tail = (ws.data_ptr(), ws.numel())
+        if name.endswith("_grouped"):
+            import ctypes
+            ws_ = [torch.randn(co * kh * kw * ci, device=device) for _ in range(groups)]
+            arr = (ctypes.c_void_p * groups)(*[t.data_ptr() for t in ws_])
+            args = (groups, y.data_ptr(), x.data_ptr(), arr, None) + geom + (0,) + tail
+            return args, (x, y, ws_, arr)
         if name.endswith("_fwd"):
             args = (x.data_ptr(), w.data_ptr(), b.data_ptr() if a[2] else 0, y.data_ptr()) + geom + (a[15], a[16]) + tail
         elif name.endswith("_dgrad"):
@@ -201,7 +221,7 @@ def measure_dominant_kernel(recorded, device, reps=20, live=False):
         finally:
             lib.movae_bench_main_kernel_only(0)
         rows.append(dict(call=name, kernel=kernel, shape=list(conv_call_key(name, a)[1:]), us=us, us_main=us_main,
-                         gflop=conv_call_flops(name, a) / 1e9))
+                         gflop=conv_call_flops(name, a) / 1e9, alg_bytes=conv_call_bytes(name, a)))
     return rows, other
 
 
@@ -298,10 +318,6 @@ def main():
         rows = [r for r in all_rows if r["call"] in CONV_CALLS]
         tot_us = sum(r["us"] for r in rows)
         tot_gf = sum(r["gflop"] for r in rows)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.config}.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         # group the main-kernel timings by kernel symbol (the way rocprofv3 --stats does) and report the one with
         # the largest time per step; the whole conv family (all kernels + their epilogue launches) is given beside it
         groups = {}
@@ -313,13 +329,20 @@ def main():
         mfma_groups = {k: v for k, v in groups.items() if k.startswith("igemm")} or groups
         dom = max(mfma_groups, key=lambda k: mfma_groups[k]["us"])
         d = groups[dom]
+        # memory-side bytes per launch of that kernel from the committed PMC passes (profiles/pmc_traffic_<cfg>.json)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.config}.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("kernels", {}).get(dom, {}).get("hbm_bytes_per_launch")
+        alg_bytes = sum(r["alg_bytes"] for r in rows if r["kernel"] == dom) / d["n"]
         achieved = d["gflop"] * 1e9 / (d["us"] * 1e-6) / 1e12 if d["us"] > 0 else 0.0
         fam = tot_gf * 1e9 / (tot_us * 1e-6) / 1e12 if tot_us > 0 else 0.0
         roofline = dict(bound="mfma", kernel=dom + " (implicit-GEMM conv, v_mfma_f32_32x32x2_f32)",
                         achieved=round(achieved, 3), peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                         frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
                         launches_per_step=d["n"], avg_launch_us=round(d["us"] / d["n"], 2),
-                        flop_per_launch=round(d["gflop"] * 1e9 / d["n"]), kernel_us_per_step=round(d["us"], 1),
+                        flop_per_launch=round(d["gflop"] * 1e9 / d["n"]), algorithmic_bytes_per_launch=round(alg_bytes),
+                        kernel_us_per_step=round(d["us"], 1),
                         per_kernel={k: dict(launches=v["n"], avg_us=round(v["us"] / v["n"], 2),
                                             tflops=round(v["gflop"] * 1e3 / v["us"], 2) if v["us"] > 0 else 0.0)
                                     for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["us"])},
