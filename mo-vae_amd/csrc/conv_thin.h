@@ -275,6 +275,101 @@ __global__ void thin_wgrad_tiled_k(const float* __restrict__ S, const float* __r
     }
 }
 
+// Sweep variant (preferred): a thread owns ONE wide channel and ALL taps.  Per wide-side pixel it reads its channel once
+// (conflict-free ds_read_b32) and, per tap, the matching thin-side pixel as one broadcast ds_read_b128 (thin pixels are
+// padded to 4 floats in LDS), i.e. (1 + taps) LDS reads per taps*TC FMAs -- the tiled kernel above issues 1 + TC reads per
+// TC FMAs and is LDS-issue bound.  Block = 32 channel lanes x 8 row groups over one TH x TW tile of wide-side pixels of one
+// image; the row groups fold through LDS and the block writes one slab row (deterministic reduce afterwards).
+//   REV = false: wide = S (small side), thin = Bg:  acc[tap][b] += S[p][a]  * Bg[p*s - pad + tap][b],  thread a
+//   REV = true : wide = Bg, thin = S, stride 1:      acc[tap][a] += Bg[q][b] * S[q + pad - tap][a],     thread b
+template <int TC, int KH, int KW, bool REV>
+__global__ __launch_bounds__(256) void thin_wgrad_sweep_k(const float* __restrict__ Wide, const float* __restrict__ Thin,
+                                                          float* __restrict__ slab, int Hw, int Ww, int Cw, int Ht, int Wt,
+                                                          int stride, int pad, int TH, int TW, int tiles_h, int tiles_w,
+                                                          int Cs, int Cb) {
+    constexpr int TAPS = KH * KW, NA = TAPS * TC;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int t = threadIdx.x, cw = t & 31, rg = t >> 5;
+    const int BH = REV ? TH + KH - 1 : (TH - 1) * stride + KH, BW = REV ? TW + KW - 1 : (TW - 1) * stride + KW;
+    float* wideT = lds;                                // [TH*TW][32]; reused as the row-group fold buffer
+    const int wide_floats = max(TH * TW * 32, 8 * 32 * ((NA + 1) / 2));
+    f32x4* thinT = reinterpret_cast<f32x4*>(lds + wide_floats);  // [BH*BW] pixels padded to 4 channels
+    int b = blockIdx.x;
+    const int tw = b % tiles_w;
+    b /= tiles_w;
+    const int th = b % tiles_h, img = b / tiles_h;
+    const int c0 = blockIdx.y * 32;
+    const int y0 = th * TH, x0 = tw * TW;
+    // stage the wide tile: 8 threads x 16 B cover one pixel's 32-channel slice
+    {
+        const float* Wb = Wide + (long)img * Hw * Ww * Cw + c0;
+        const int q = t & 7;
+        for (int pix = t >> 3; pix < TH * TW; pix += 32) {
+            const int py = pix / TW, px = pix - py * TW;
+            const int y = y0 + py, x = x0 + px;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (y < Hw && x < Ww) v = *reinterpret_cast<const f32x4*>(Wb + ((long)y * Ww + x) * Cw + q * 4);
+            *reinterpret_cast<f32x4*>(wideT + pix * 32 + q * 4) = v;
+        }
+        // thin tile with its halo, zero outside the image
+        const float* Tb = Thin + (long)img * Ht * Wt * TC;
+        const int ty0 = REV ? y0 + pad - (KH - 1) : y0 * stride - pad, tx0 = REV ? x0 + pad - (KW - 1) : x0 * stride - pad;
+        for (int pix = t; pix < BH * BW; pix += 256) {
+            const int r = pix / BW, c = pix - r * BW;
+            const int y = ty0 + r, x = tx0 + c;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (y >= 0 && y < Ht && x >= 0 && x < Wt) {
+                const float* src = Tb + ((long)y * Wt + x) * TC;
+#pragma unroll
+                for (int j = 0; j < TC; ++j) v[j] = src[j];
+            }
+            thinT[pix] = v;
+        }
+    }
+    __syncthreads();
+    float acc[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) acc[i] = 0.f;
+    for (int py = rg; py < TH; py += 8) {
+        const float* wrow = wideT + py * TW * 32 + cw;
+        const f32x4* trow = thinT + (REV ? py : py * stride) * BW;
+        for (int px = 0; px < TW; ++px) {
+            const float wv = wrow[px * 32];
+            const f32x4* tp = trow + (REV ? px : px * stride);
+#pragma unroll
+            for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < KW; ++kw) {
+                    const f32x4 tv = tp[(REV ? KH - 1 - kh : kh) * BW + (REV ? KW - 1 - kw : kw)];
+#pragma unroll
+                    for (int j = 0; j < TC; ++j) acc[(kh * KW + kw) * TC + j] += wv * tv[j];
+                }
+        }
+    }
+    // fold the 8 row groups through LDS (two passes keep the buffer inside the wide tile's footprint), then one slab row
+    const int N = TAPS * Cb;
+    float* out = slab + (long)blockIdx.x * Cs * N;
+    constexpr int HALF = (NA + 1) / 2;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < HALF; ++i)
+            if (pass * HALF + i < NA) wideT[(rg * HALF + i) * 32 + cw] = acc[pass * HALF + i];
+        __syncthreads();
+        for (int i = rg; i < HALF && pass * HALF + i < NA; i += 8) {
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v += wideT[(r * HALF + i) * 32 + cw];
+            const int ai = pass * HALF + i, tap = ai / TC, j = ai - tap * TC;
+            const int c = c0 + cw;
+            // dW[a][tap][b]: REV -> a = j (thin), b = c (wide);  else a = c (wide), b = j (thin)
+            const long o = REV ? ((long)j * TAPS + tap) * Cb + c : ((long)c * TAPS + tap) * Cb + j;
+            out[o] = v;
+        }
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------
 inline bool thin_in_ok(const Geom& g) { return g.Cr <= 4 && g.Nn >= 8 && g.KH * g.KW * g.Cr * 64 * 4 <= 48 * 1024; }
 
@@ -315,7 +410,50 @@ int launch_thin_wgrad(const float* S, const float* Bg, float* dW, const WGeom& g
     const int M = g.Cs, N = g.KH * g.KW * g.Cb;
     const bool thin_small = g.Cs <= 4;
     const int wide = thin_small ? g.Cb : g.Cs;
-    {   // preferred: LDS-tiled kernel (tile sized to <= 48 KiB of LDS)
+    {   // preferred: sweep kernel (3x3 / 4x4 taps, wide side a multiple of 32 channels; thin = S needs stride 1)
+        const int tc = thin_small ? g.Cs : g.Cb;
+        const bool k33 = g.KH == 3 && g.KW == 3, k44 = g.KH == 4 && g.KW == 4;
+        const bool aligned = (reinterpret_cast<uintptr_t>(thin_small ? Bg : S) & 15) == 0;
+        if ((k33 || k44) && wide % 32 == 0 && tc == 3 && aligned && (!thin_small || g.stride == 1) && ws) {
+            // wide side: REV (thin = S) sweeps the big-side image, else the small-side image
+            const int Hw = thin_small ? g.Hb : g.Hs, Ww = thin_small ? g.Wb : g.Ws;
+            const int Ht = thin_small ? g.Hs : g.Hb, Wt = thin_small ? g.Ws : g.Wb;
+            const int TW = Ww < 32 ? Ww : 32;
+            int TH = 256 / TW;
+            if (TH > Hw) TH = Hw;
+            const int taps = g.KH * g.KW, na = taps * 3;
+            auto lds_bytes = [&](int th, int tw) {
+                const int bh = thin_small ? th + g.KH - 1 : (th - 1) * g.stride + g.KH;
+                const int bw = thin_small ? tw + g.KW - 1 : (tw - 1) * g.stride + g.KW;
+                const long tile_f = (long)th * tw * 32, fold_f = 8L * 32 * ((na + 1) / 2);
+                const long wide_f = tile_f > fold_f ? tile_f : fold_f;
+                return (wide_f + (long)bh * bw * 4) * 4;
+            };
+            while (lds_bytes(TH, TW) > 60 * 1024 && TH > 1) TH = (TH + 1) / 2;
+            const int tiles_h = ceil_div(Hw, TH), tiles_w = ceil_div(Ww, TW);
+            const long nblk = (long)g.Nimg * tiles_h * tiles_w;
+            const size_t per1 = (size_t)M * N * sizeof(float);
+            if (lds_bytes(TH, TW) <= 60 * 1024 && nblk <= 0x7fffffffL && per1 * (size_t)nblk <= ws_bytes) {
+                float* slab = static_cast<float*>(ws);
+                const dim3 grid((unsigned)nblk, wide / 32);
+                const size_t shb = (size_t)lds_bytes(TH, TW);
+                const float* Wd = thin_small ? Bg : S;
+                const float* Tn = thin_small ? S : Bg;
+#define MOVAE_SW(K, REVV)                                                                                                      \
+    hipLaunchKernelGGL((thin_wgrad_sweep_k<3, K, K, REVV>), grid, dim3(256), shb, st, Wd, Tn, slab, Hw, Ww, wide, Ht, Wt, g.stride, \
+                       g.pad, TH, TW, tiles_h, tiles_w, g.Cs, g.Cb)
+                if (thin_small) {
+                    if (k33) MOVAE_SW(3, true); else MOVAE_SW(4, true);
+                } else {
+                    if (k33) MOVAE_SW(3, false); else MOVAE_SW(4, false);
+                }
+#undef MOVAE_SW
+                MOVAE_CHECK_LAUNCH("thin_wgrad_sweep");
+                return launch_reduce(slab, dW, (long)M * N, (int)nblk, N, nullptr, 0, 0.f, accumulate, st);
+            }
+        }
+    }
+    {   // LDS-tiled kernel (tile sized to <= 48 KiB of LDS)
         int TW = g.Ws < 32 ? g.Ws : 32, TH = g.Hs < 16 ? g.Hs : 16;
         auto lds_floats = [&](int th, int tw) {
             return (long)th * tw * g.Cs + (long)((th - 1) * g.stride + g.KH) * ((tw - 1) * g.stride + g.KW) * g.Cb;

@@ -55,6 +55,10 @@ CONV_CASES = [
     (2, 48, 6, 6, 32, 1, 1, 0),      # 1x1
     (5, 64, 2, 2, 128, 3, 2, 1),     # 2x2 -> 1x1 (CIFAR VAE tail), split-K path
     (2, 20, 5, 5, 12, 3, 2, 1),      # ci not multiple of 16 nor 4
+    (3, 3, 13, 11, 32, 3, 2, 1),     # 3-channel input, 32 outputs: thin wgrad sweep kernel (thin = big side), ragged tiles
+    (2, 3, 16, 16, 64, 4, 2, 1),     # ... with 4x4 taps and two 32-channel blocks
+    (2, 32, 9, 7, 3, 3, 1, 1),       # 3-channel output, stride 1: thin wgrad sweep kernel (thin = small side)
+    (2, 64, 40, 36, 3, 3, 1, 1),     # ... several tiles per image, two channel blocks
 ]
 
 
@@ -86,6 +90,8 @@ CONVT_CASES = [
     (2, 8, 5, 6, 12, 3, 2, 1, 1),     # generic path
     (2, 16, 8, 8, 3, 4, 2, 1, 0),     # k4 s2 p1 (VQ decoders), co = 3
     (2, 32, 4, 4, 32, 4, 2, 1, 0),
+    (2, 32, 9, 5, 3, 4, 2, 1, 0),     # co = 3 with 32 input channels: thin wgrad sweep kernel through the convT mapping
+    (2, 128, 20, 20, 3, 4, 2, 1, 0),  # ... four channel blocks, several tiles
 ]
 
 
