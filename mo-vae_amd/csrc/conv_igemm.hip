@@ -653,6 +653,11 @@ int launch_fwd(const float* X, const float* W, float* Y, const Geom& g, const Ep
     }
     const int M = (int)Ml, K = (int)Kl;
     if (thin::thin_in_ok(g)) return (g_last_kernel = "thin_in_k<fwd>", thin::launch_thin_in<false>(X, W, Y, g, ep, st));
+    if (g.Nn <= 4) {  // 3-channel output: LDS-tiled direct kernel
+        bool handled = false;
+        if (int rc = thin::launch_thin_out_tile<false>(X, W, Y, g, ep, st, &handled)) return rc;
+        if (handled) return (g_last_kernel = "thin_out_tile_k<fwd>", MOVAE_OK);
+    }
     if (thin::thin_out_ok(g, X)) return (g_last_kernel = "thin_out_fwd_k", thin::launch_thin_out_fwd(X, W, Y, g, ep, st));
     if (g.Cr % 4 == 0 && aligned16(X) && aligned16(W)) {  // fast path (igemm_v2.h)
         if (g.Nn <= 32) return (g_last_kernel = "igemm2_fwd<128,32>", v2::launch_fwd2<128, 32>(X, W, Y, g, ep, M, K, ws, ws_bytes, st));
@@ -700,6 +705,11 @@ int launch_bwd(const float* X, const float* W, float* Y, const Geom& g, const Ep
     }
     const long Mc = Ml / (g.stride * g.stride);
     if (thin::thin_in_ok(g)) return (g_last_kernel = "thin_in_k<bwd>", thin::launch_thin_in<true>(X, W, Y, g, ep, st));
+    if (g.Nn <= 4) {  // 3-channel output of a transposed conv: LDS-tiled direct kernel
+        bool handled = false;
+        if (int rc = thin::launch_thin_out_tile<true>(X, W, Y, g, ep, st, &handled)) return rc;
+        if (handled) return (g_last_kernel = "thin_out_tile_k<bwd>", MOVAE_OK);
+    }
     if (g.Cr % 4 == 0 && g.Nn % 4 == 0 && aligned16(X) && aligned16(W)) {  // fast path (igemm_v2.h)
         if (g.Nn <= 32) return (g_last_kernel = "igemm2_bwd<128,32>", v2::launch_bwd2<128, 32>(X, W, Y, g, ep, ws, ws_bytes, st));
         if (g.Nn >= 128 && (Mc / 128) * (g.Nn / 128) * g.stride * g.stride >= big_tile_min())
@@ -772,6 +782,8 @@ int launch_wgrad(const float* S, const float* Bg, float* const* dW, int G, long 
             return (g_last_kernel = "igemm2_wgrad<128,128>", v2::launch_wgrad2<128, 128>(S, Bg, dW, G, s_gs, b_gs, g, (int)Kl, accumulate, ws, ws_bytes, st));
         return (g_last_kernel = "igemm2_wgrad<64,64>", v2::launch_wgrad2<64, 64>(S, Bg, dW, G, s_gs, b_gs, g, (int)Kl, accumulate, ws, ws_bytes, st));
     }
+    if (thin::thin_wgrad_ok(g) && ws)
+        return (g_last_kernel = "thin_wgrad", thin::launch_thin_wgrad_grouped(S, Bg, dW, G, s_gs, b_gs, g, (int)Kl, accumulate, ws, ws_bytes, st));
     for (int i = 0; i < G; ++i)
         if (int rc = launch_wgrad1(S + i * s_gs, Bg + i * b_gs, dW[i], g, accumulate, ws, ws_bytes, st)) return rc;
     return MOVAE_OK;

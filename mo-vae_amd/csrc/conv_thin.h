@@ -136,6 +136,157 @@ __global__ __launch_bounds__(256) void thin_out_fwd_k(const float* __restrict__ 
         if (n < N) Y[(long)p * N + n] = apply_act(acc[n], act, slope);
 }
 
+// ---- thin output side, LDS-tiled (FWD and BWD gather) -----------------------------------------------------------
+// N <= 4 outputs per pixel from many reduction channels (last decoder layer: Conv2d -> 3 or ConvTranspose2d -> 3).  The
+// layer streams the step's largest activation once; one output pixel per thread reading its taps straight from global
+// memory (thin_out_fwd_k) re-fetches every input pixel KH*KW times through the L1 in 16-byte pieces.  Here a block owns a
+// TH x TW tile of output pixels of one image and walks the reduction channels in chunks of CC: the input region of the
+// tile (with halo, zero outside the image) and the chunk's weights are staged in LDS with coalesced 16-byte loads, then
+// every thread accumulates PPT pixels x 3..4 outputs from LDS (pixel stride CC + 4 floats => conflict-free ds_read_b128;
+// weight reads are wave-uniform broadcasts).  BWD (transposed conv, stride 2): wave w owns output-parity class w, so
+// the tap set -- and with it every weight address -- stays uniform inside a wave.
+template <bool BWD, int CC, int PPT>
+__global__ __launch_bounds__(256) void thin_out_tile_k(const float* __restrict__ X, const float* __restrict__ W,
+                                                       const float* __restrict__ bias, float* __restrict__ Y, Geom g, int TH,
+                                                       int TW, int tiles_h, int tiles_w, int IH, int IW, int act, float slope) {
+    constexpr int XS = CC + 4;  // LDS pixel stride
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* xT = lds;                    // [IH*IW][XS]
+    float* wT = lds + IH * IW * XS;     // [taps][4][CC]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int s = g.stride, taps = g.KH * g.KW, N = g.Nn;
+    int b = blockIdx.x;
+    const int tw = b % tiles_w;
+    b /= tiles_w;
+    const int th = b % tiles_h, img = b / tiles_h;
+    const int y0 = th * TH, x0 = tw * TW;
+    // input tile origin
+    int iy0, ix0;
+    if (BWD) {
+        const int ny = y0 + g.pad - g.KH + 1, nx = x0 + g.pad - g.KW + 1;
+        iy0 = ny >= 0 ? ny / s : -((-ny + s - 1) / s);
+        ix0 = nx >= 0 ? nx / s : -((-nx + s - 1) / s);
+    } else {
+        iy0 = y0 * s - g.pad;
+        ix0 = x0 * s - g.pad;
+    }
+    // this thread's pixels (tile-local) and, for BWD, its parity class
+    int py[PPT], px[PPT];
+    int kh0 = 0, kw0 = 0, nA = g.KH, nB = g.KW;
+    if (BWD && s == 2) {
+        const int ph = wave >> 1, pw = wave & 1;  // TH, TW even; class grid (TH/2) x (TW/2)
+        const int cw = TW / 2;
+#pragma unroll
+        for (int u = 0; u < PPT; ++u) {
+            const int j = lane + u * 64;
+            py[u] = (j / cw) * 2 + ph;
+            px[u] = (j % cw) * 2 + pw;
+        }
+        kh0 = (y0 + ph + g.pad) % 2;  // y0, x0 are even (tile sizes are even)
+        kw0 = (x0 + pw + g.pad) % 2;
+        nA = kh0 < g.KH ? (g.KH - kh0 + 1) / 2 : 0;
+        nB = kw0 < g.KW ? (g.KW - kw0 + 1) / 2 : 0;
+    } else {
+#pragma unroll
+        for (int u = 0; u < PPT; ++u) {
+            const int j = t + u * 256;
+            py[u] = j / TW;
+            px[u] = j % TW;
+        }
+    }
+    float acc[PPT][4];
+#pragma unroll
+    for (int u = 0; u < PPT; ++u)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[u][n] = 0.f;
+    const float* Xb = X + (long)img * g.Hi * g.Wi * g.Cr;
+    constexpr int QC = CC / 4;
+    for (int c0 = 0; c0 < g.Cr; c0 += CC) {
+        __syncthreads();
+        // 4 independent 16-byte loads in flight per thread before the first LDS store: a load-store loop with one
+        // load per trip pays the full memory latency every trip
+        for (int base = t; base < IH * IW * QC; base += 4 * 256) {
+            f32x4 v[4];
+            int dst[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * 256;
+                const int pix = idx / QC, q = idx - pix * QC;
+                const int r = pix / IW, c = pix - r * IW;
+                const int h = iy0 + r, w = ix0 + c, ch = c0 + q * 4;
+                const bool ok = idx < IH * IW * QC && h >= 0 && h < g.Hi && w >= 0 && w < g.Wi && ch < g.Cr;
+                dst[u] = idx < IH * IW * QC ? pix * XS + q * 4 : -1;
+                v[u] = ok ? *reinterpret_cast<const f32x4*>(Xb + ((long)h * g.Wi + w) * g.Cr + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (dst[u] >= 0) *reinterpret_cast<f32x4*>(xT + dst[u]) = v[u];
+        }
+        for (int base = t; base < taps * 4 * CC; base += 4 * 256) {  // same batching for the chunk's weights
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * 256;
+                const int tap = idx / (4 * CC), rem = idx - tap * 4 * CC;
+                const int n = rem / CC, cl = rem - n * CC, c = c0 + cl;
+                const bool ok = idx < taps * 4 * CC && n < N && c < g.Cr;
+                v[u] = ok ? (BWD ? W[((long)c * taps + tap) * N + n] : W[((long)n * taps + tap) * g.Cr + c]) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (base + u * 256 < taps * 4 * CC) wT[base + u * 256] = v[u];
+        }
+        __syncthreads();
+        for (int a = 0; a < nA; ++a)
+            for (int bb = 0; bb < nB; ++bb) {
+                const int kh = BWD ? kh0 + s * a : a, kw = BWD ? kw0 + s * bb : bb;
+                const float* wp = wT + (kh * g.KW + kw) * 4 * CC;
+                const float* xp[PPT];
+#pragma unroll
+                for (int u = 0; u < PPT; ++u) {
+                    int ih, iw;
+                    if (BWD) {
+                        ih = (y0 + py[u] + g.pad - kh) / s - iy0;  // exact division by construction of the class
+                        iw = (x0 + px[u] + g.pad - kw) / s - ix0;
+                    } else {
+                        ih = py[u] * s + kh;
+                        iw = px[u] * s + kw;
+                    }
+                    xp[u] = xT + (ih * IW + iw) * XS;
+                }
+#pragma unroll
+                for (int q = 0; q < QC; ++q) {
+                    f32x4 x4[PPT];
+#pragma unroll
+                    for (int u = 0; u < PPT; ++u) x4[u] = *reinterpret_cast<const f32x4*>(xp[u] + q * 4);
+#pragma unroll
+                    for (int n = 0; n < 3; ++n) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wp + n * CC + q * 4);
+#pragma unroll
+                        for (int u = 0; u < PPT; ++u)
+                            acc[u][n] += x4[u][0] * w4[0] + x4[u][1] * w4[1] + x4[u][2] * w4[2] + x4[u][3] * w4[3];
+                    }
+                    if (N == 4) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wp + 3 * CC + q * 4);
+#pragma unroll
+                        for (int u = 0; u < PPT; ++u)
+                            acc[u][3] += x4[u][0] * w4[0] + x4[u][1] * w4[1] + x4[u][2] * w4[2] + x4[u][3] * w4[3];
+                    }
+                }
+            }
+    }
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+        const int ho = y0 + py[u], wo = x0 + px[u];
+        if (py[u] < TH && ho < g.Ho && wo < g.Wo) {
+            float* yo = Y + (((long)img * g.Ho + ho) * g.Wo + wo) * N;
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                if (n < N) yo[n] = apply_act(acc[u][n] + (bias ? bias[n] : 0.f), act, slope);
+        }
+    }
+}
+
 // ---- thin weight gradient ----------------------------------------------------------------------------
 // dW[a][tap][b] = sum_p S[p][a] * Bg[p*s - pad + tap][b].  THIN_SMALL: Cs <= 4 (accumulators over a, lanes
 // over b); else Cb <= 4 (accumulators over b, lanes over a).  grid = (pixel chunks, taps); block = WL wide
@@ -286,8 +437,11 @@ template <int TC, int KH, int KW, bool REV>
 __global__ __launch_bounds__(256) void thin_wgrad_sweep_k(const float* __restrict__ Wide, const float* __restrict__ Thin,
                                                           float* __restrict__ slab, int Hw, int Ww, int Cw, int Ht, int Wt,
                                                           int stride, int pad, int TH, int TW, int tiles_h, int tiles_w,
-                                                          int Cs, int Cb) {
+                                                          int Cs, int Cb, long wide_gs, long thin_gs, long slab_gs) {
     constexpr int TAPS = KH * KW, NA = TAPS * TC;
+    Wide += blockIdx.z * wide_gs;  // cotangent group (batched pull-back): 0 for the operand the groups share
+    Thin += blockIdx.z * thin_gs;
+    slab += blockIdx.z * slab_gs;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int t = threadIdx.x, cw = t & 31, rg = t >> 5;
     const int BH = REV ? TH + KH - 1 : (TH - 1) * stride + KH, BW = REV ? TW + KW - 1 : (TW - 1) * stride + KW;
@@ -403,11 +557,73 @@ int launch_thin_out_fwd(const float* X, const float* W, float* Y, const Geom& g,
     return MOVAE_OK;
 }
 
+// tile geometry of thin_out_tile_k; returns false when the layer does not fit the kernel
+template <bool BWD>
+inline bool thin_out_tile_plan(const Geom& g, const float* X, int& TH, int& TW, int& IH, int& IW, int& CC, int& PPT) {
+    if (g.Nn > 4 || g.Cr % 4 != 0 || (reinterpret_cast<uintptr_t>(X) & 15) != 0) return false;
+    if (BWD && g.stride != 2) return false;  // stride-1 transposed convs take the generic path
+    if (g.KH * g.KW > 16) return false;
+    TW = g.Wo < 32 ? (BWD ? (g.Wo + 1) / 2 * 2 : g.Wo) : 32;
+    if (TW < 1) return false;
+    // two pixels per thread halve the weight reads per FMA but also the block count (measured: better from ~200k pixels)
+    const long px_total = (long)g.Nimg * g.Ho * g.Wo;
+    for (int ppt = px_total >= 200000L ? 2 : 1; ppt >= 1; --ppt) {
+        int th = 256 * ppt / TW;
+        if (BWD) th = th / 2 * 2;
+        if (th < (BWD ? 2 : 1)) continue;
+        if (BWD && (256 * ppt) % (TW * 2) != 0) continue;          // whole class rows per wave pass
+        if (!BWD && (256 * ppt) % TW != 0) continue;
+        for (int cc = 32; cc >= 16; cc -= 16) {
+            const int ih = BWD ? (th + g.KH - 2) / 2 + 2 : (th - 1) * g.stride + g.KH;
+            const int iw = BWD ? (TW + g.KW - 2) / 2 + 2 : (TW - 1) * g.stride + g.KW;
+            const long bytes = ((long)ih * iw * (cc + 4) + (long)g.KH * g.KW * 4 * cc) * 4;
+            if (bytes <= 62 * 1024) {
+                TH = th; IH = ih; IW = iw; CC = cc; PPT = ppt;
+                return true;
+            }
+        }
+    }
+    return false;
+}
+
+template <bool BWD>
+int launch_thin_out_tile(const float* X, const float* W, float* Y, const Geom& g, const Epilogue& ep, hipStream_t st, bool* handled) {
+    int TH, TW, IH, IW, CC, PPT;
+    *handled = thin_out_tile_plan<BWD>(g, X, TH, TW, IH, IW, CC, PPT);
+    if (!*handled) return MOVAE_OK;
+    const int tiles_h = ceil_div(g.Ho, TH), tiles_w = ceil_div(g.Wo, TW);
+    const long nblk = (long)g.Nimg * tiles_h * tiles_w;
+    if (nblk > 0x7fffffffL) {
+        *handled = false;
+        return MOVAE_OK;
+    }
+    const size_t shb = ((size_t)IH * IW * (CC + 4) + (size_t)g.KH * g.KW * 4 * CC) * sizeof(float);
+#define MOVAE_TO(CCV, PPTV)                                                                                                      \
+    hipLaunchKernelGGL((thin_out_tile_k<BWD, CCV, PPTV>), dim3((unsigned)nblk), dim3(256), shb, st, X, W, ep.bias, Y, g, TH, TW, tiles_h, \
+                       tiles_w, IH, IW, ep.act, ep.slope)
+    if (CC == 32) {
+        if (PPT == 2) MOVAE_TO(32, 2); else MOVAE_TO(32, 1);
+    } else {
+        if (PPT == 2) MOVAE_TO(16, 2); else MOVAE_TO(16, 1);
+    }
+#undef MOVAE_TO
+    MOVAE_CHECK_LAUNCH("thin_out_tile");
+    return MOVAE_OK;
+}
+
 inline bool thin_wgrad_ok(const WGeom& g) { return g.Cs <= 4 || g.Cb <= 4; }
 
 int launch_thin_wgrad(const float* S, const float* Bg, float* dW, const WGeom& g, int K, int accumulate, void* ws,
-                      size_t ws_bytes, hipStream_t st) {
+                      size_t ws_bytes, hipStream_t st);
+
+// G cotangent groups: one sweep launch (blockIdx.z = group) when the sweep kernel applies, else group by group
+int launch_thin_wgrad_grouped(const float* S, const float* Bg, float* const* dW, int G, long s_gs, long b_gs, const WGeom& g, int K,
+                              int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+
+int launch_thin_wgrad_impl(const float* S, const float* Bg, float* const* dW, int G, long s_gs, long b_gs, const WGeom& g, int K,
+                           int accumulate, void* ws, size_t ws_bytes, hipStream_t st, bool* handled) {
     const int M = g.Cs, N = g.KH * g.KW * g.Cb;
+    *handled = true;
     const bool thin_small = g.Cs <= 4;
     const int wide = thin_small ? g.Cb : g.Cs;
     {   // preferred: sweep kernel (3x3 / 4x4 taps, wide side a multiple of 32 channels; thin = S needs stride 1)
@@ -433,15 +649,17 @@ int launch_thin_wgrad(const float* S, const float* Bg, float* dW, const WGeom& g
             const int tiles_h = ceil_div(Hw, TH), tiles_w = ceil_div(Ww, TW);
             const long nblk = (long)g.Nimg * tiles_h * tiles_w;
             const size_t per1 = (size_t)M * N * sizeof(float);
-            if (lds_bytes(TH, TW) <= 60 * 1024 && nblk <= 0x7fffffffL && per1 * (size_t)nblk <= ws_bytes) {
+            if (lds_bytes(TH, TW) <= 60 * 1024 && nblk <= 0x7fffffffL && per1 * (size_t)nblk * G <= ws_bytes) {
                 float* slab = static_cast<float*>(ws);
-                const dim3 grid((unsigned)nblk, wide / 32);
+                const dim3 grid((unsigned)nblk, wide / 32, G);
+                const long slab_gs = (long)nblk * M * N;
+                const long wide_gs = thin_small ? b_gs : s_gs, thin_gs = thin_small ? s_gs : b_gs;
                 const size_t shb = (size_t)lds_bytes(TH, TW);
                 const float* Wd = thin_small ? Bg : S;
                 const float* Tn = thin_small ? S : Bg;
 #define MOVAE_SW(K, REVV)                                                                                                      \
     hipLaunchKernelGGL((thin_wgrad_sweep_k<3, K, K, REVV>), grid, dim3(256), shb, st, Wd, Tn, slab, Hw, Ww, wide, Ht, Wt, g.stride, \
-                       g.pad, TH, TW, tiles_h, tiles_w, g.Cs, g.Cb)
+                       g.pad, TH, TW, tiles_h, tiles_w, g.Cs, g.Cb, wide_gs, thin_gs, slab_gs)
                 if (thin_small) {
                     if (k33) MOVAE_SW(3, true); else MOVAE_SW(4, true);
                 } else {
@@ -449,9 +667,37 @@ int launch_thin_wgrad(const float* S, const float* Bg, float* dW, const WGeom& g
                 }
 #undef MOVAE_SW
                 MOVAE_CHECK_LAUNCH("thin_wgrad_sweep");
-                return launch_reduce(slab, dW, (long)M * N, (int)nblk, N, nullptr, 0, 0.f, accumulate, st);
+                for (int i = 0; i < G; ++i)
+                    if (int rc = launch_reduce(slab + i * slab_gs, dW[i], (long)M * N, (int)nblk, N, nullptr, 0, 0.f, accumulate, st))
+                        return rc;
+                return MOVAE_OK;
             }
         }
+    }
+    *handled = false;
+    return MOVAE_OK;
+}
+
+int launch_thin_wgrad_grouped(const float* S, const float* Bg, float* const* dW, int G, long s_gs, long b_gs, const WGeom& g, int K,
+                              int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+    bool handled = false;
+    if (int rc = launch_thin_wgrad_impl(S, Bg, dW, G, s_gs, b_gs, g, K, accumulate, ws, ws_bytes, st, &handled)) return rc;
+    if (handled) return MOVAE_OK;
+    for (int i = 0; i < G; ++i)
+        if (int rc = launch_thin_wgrad(S + i * s_gs, Bg + i * b_gs, dW[i], g, K, accumulate, ws, ws_bytes, st)) return rc;
+    return MOVAE_OK;
+}
+
+int launch_thin_wgrad(const float* S, const float* Bg, float* dW, const WGeom& g, int K, int accumulate, void* ws,
+                      size_t ws_bytes, hipStream_t st) {
+    const int M = g.Cs, N = g.KH * g.KW * g.Cb;
+    const bool thin_small = g.Cs <= 4;
+    const int wide = thin_small ? g.Cb : g.Cs;
+    {
+        float* one[1] = {dW};
+        bool handled = false;
+        if (int rc = launch_thin_wgrad_impl(S, Bg, one, 1, 0, 0, g, K, accumulate, ws, ws_bytes, st, &handled)) return rc;
+        if (handled) return MOVAE_OK;
     }
     {   // LDS-tiled kernel (tile sized to <= 48 KiB of LDS)
         int TW = g.Ws < 32 ? g.Ws : 32, TH = g.Hs < 16 ? g.Hs : 16;

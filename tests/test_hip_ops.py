@@ -91,7 +91,10 @@ CONVT_CASES = [
     (2, 16, 8, 8, 3, 4, 2, 1, 0),     # k4 s2 p1 (VQ decoders), co = 3
     (2, 32, 4, 4, 32, 4, 2, 1, 0),
     (2, 32, 9, 5, 3, 4, 2, 1, 0),     # co = 3 with 32 input channels: thin wgrad sweep kernel through the convT mapping
-    (2, 128, 20, 20, 3, 4, 2, 1, 0),  # ... four channel blocks, several tiles
+    (2, 128, 20, 20, 3, 4, 2, 1, 0),  # ... four channel blocks, several tiles; LDS-tiled thin-output kernel with ragged tiles
+    (2, 64, 16, 16, 3, 4, 2, 1, 0),   # thin-output kernel, exact tiles
+    (3, 32, 8, 8, 3, 3, 2, 1, 1),     # thin-output kernel, 3x3 taps with output padding
+    (2, 24, 16, 16, 2, 4, 2, 1, 0),   # thin-output kernel, 2 outputs, channels not a multiple of the chunk
 ]
 
 
