@@ -113,16 +113,28 @@ __global__ __launch_bounds__(256) void bn_apply(const float* __restrict__ y, con
                                                 const float* __restrict__ rstd, float* __restrict__ out, long total, int C,
                                                 int act, float slope) {
     const long stride = (long)gridDim.x * blockDim.x;
-    if (VEC) {
+    if (VEC) {  // 4 independent 16-byte loads in flight per thread; the per-channel parameters come as float4 too
         const long nv = total / 4;
-        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
-            const f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
-            const int c = (int)((i * 4) % C);
-            f32x4 o;
+        for (long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x; i0 < nv; i0 += 4 * stride) {
+            f32x4 v[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                o[j] = apply_act((v[j] - mean[c + j]) * rstd[c + j] * gamma[c + j] + beta[c + j], act, slope);
-            reinterpret_cast<f32x4*>(out)[i] = o;
+            for (int u = 0; u < 4; ++u) {
+                const long i = i0 + u * stride;
+                if (i < nv) v[u] = reinterpret_cast<const f32x4*>(y)[i];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long i = i0 + u * stride;
+                if (i < nv) {
+                    const int c = (int)((i * 4) % C);
+                    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
+                    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
+                    f32x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = apply_act((v[u][j] - mu[j]) * rs[j] * ga[j] + be[j], act, slope);
+                    reinterpret_cast<f32x4*>(out)[i] = o;
+                }
+            }
         }
     } else {
         for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -214,14 +226,19 @@ struct Split4 {
     int CQB, RG, rows_per_block, nblk;
 };
 
-inline Split4 make_split4(int rows, int c) {
+// max_parts = most partial blocks: measured best ~256 for the forward statistics and for grouped backward passes,
+// ~1024 for a single-cotangent backward (two input streams per thread)
+inline Split4 make_split4(int rows, int c, int parts = 256) {
     Split4 s;
     const int cq = c / 4;
     s.CQB = pow2_ge(cq) < 256 ? pow2_ge(cq) : 256;
     s.RG = 256 / s.CQB;
-    int rpb = ceil_div(rows, 256);  // <= 256 partial blocks: the in-launch fold by the last block stays short
+    static const int env_parts = getenv("MOVAE_BN_PARTS") ? atoi(getenv("MOVAE_BN_PARTS")) : 0;
+    static const int min_iter = getenv("MOVAE_BN_MINITER") ? atoi(getenv("MOVAE_BN_MINITER")) : 4;
+    const int max_parts = env_parts > 0 ? env_parts : parts;
+    int rpb = ceil_div(rows, max_parts);  // up to 4 partial blocks per CU keep enough 16-byte loads in flight
     rpb = ceil_div(rpb, s.RG) * s.RG;
-    if (rpb < s.RG * 8) rpb = s.RG * 8;
+    if (rpb < s.RG * min_iter) rpb = s.RG * min_iter;
     s.rows_per_block = rpb;
     s.nblk = ceil_div(rows, rpb);
     return s;
@@ -383,18 +400,34 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4(const float* __restrict__ d
     dy += (long)blockIdx.y * total;
     sums += (long)blockIdx.y * 2 * C;
     const long stride = (long)gridDim.x * blockDim.x, nv = total / 4;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
-        const int c = (int)((i * 4) % C);
-        const f32x4 yy = reinterpret_cast<const f32x4*>(y)[i], go = reinterpret_cast<const f32x4*>(dout)[i];
-        f32x4 o4;
+    for (long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x; i0 < nv; i0 += 4 * stride) {
+        f32x4 yy[4], go[4];  // 8 independent 16-byte loads in flight per thread
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float xh = (yy[j] - mean[c + j]) * rstd[c + j];
-            const float o = apply_act(xh * gamma[c + j] + beta[c + j], act, slope);
-            const float dz = go[j] * act_grad_from_out(o, act, slope);
-            o4[j] = gamma[c + j] * rstd[c + j] * (dz - sums[2 * (c + j)] - xh * sums[2 * (c + j) + 1]);
+        for (int u = 0; u < 4; ++u) {
+            const long i = i0 + u * stride;
+            if (i < nv) {
+                yy[u] = reinterpret_cast<const f32x4*>(y)[i];
+                go[u] = reinterpret_cast<const f32x4*>(dout)[i];
+            }
         }
-        reinterpret_cast<f32x4*>(dy)[i] = o4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long i = i0 + u * stride;
+            if (i < nv) {
+                const int c = (int)((i * 4) % C);
+                const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
+                const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
+                f32x4 o4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xh = (yy[u][j] - mu[j]) * rs[j];
+                    const float o = apply_act(xh * ga[j] + be[j], act, slope);
+                    const float dz = go[u][j] * act_grad_from_out(o, act, slope);
+                    o4[j] = ga[j] * rs[j] * (dz - sums[2 * (c + j)] - xh * sums[2 * (c + j) + 1]);
+                }
+                reinterpret_cast<f32x4*>(dy)[i] = o4;
+            }
+        }
     }
 }
 
@@ -555,7 +588,7 @@ extern "C" {
 
 size_t movae_bn_ws_bytes(int rows, int c) {
     if (rows <= 0 || c <= 0) return 0;
-    const int nblk = (c % 4 == 0) ? make_split4(rows, c).nblk : make_split(rows, c).nblk;
+    const int nblk = (c % 4 == 0) ? make_split4(rows, c, 1024).nblk : make_split(rows, c).nblk;
     return MOVAE_WS_HEADER_BYTES + (size_t)nblk * c * 2 * sizeof(double) + (size_t)c * 2 * sizeof(float) + 64;
 }
 
@@ -602,9 +635,9 @@ int movae_bn_act_fwd(const float* y, const float* gamma, const float* beta, floa
         MOVAE_CHECK_LAUNCH("bn_eval_prepare");
     }
     const long total = (long)rows * c;
-    const bool vec = (c % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    const bool vec = (c % 4 == 0) && al16(y, out) && al16(gamma, beta) && al16(save_mean, save_rstd);
     if (vec)
-        hipLaunchKernelGGL(bn_apply<true>, dim3(grid_for(total / 4)), dim3(256), 0, st, y, gamma, beta, save_mean, save_rstd,
+        hipLaunchKernelGGL(bn_apply<true>, dim3(grid_for(total / 16)), dim3(256), 0, st, y, gamma, beta, save_mean, save_rstd,
                            out, total, c, act, slope);
     else
         hipLaunchKernelGGL(bn_apply<false>, dim3(grid_for(total)), dim3(256), 0, st, y, gamma, beta, save_mean, save_rstd,
@@ -639,7 +672,7 @@ int movae_bn_act_bwd_grouped(int groups, const float* dout, const float* y, cons
     unsigned* counter = static_cast<unsigned*>(ws);
     double* part = reinterpret_cast<double*>(static_cast<char*>(ws) + MOVAE_WS_HEADER_BYTES);
     if (vec) {
-        const Split4 s = make_split4(rows, c);
+        const Split4 s = make_split4(rows, c, groups == 1 ? 1024 : 512);
         const bool fold = in_launch_final() && groups == 1;
         float* sums = reinterpret_cast<float*>(part + (size_t)groups * s.nblk * c * 2);
         hipLaunchKernelGGL(bn_bwd_partial4, dim3(s.nblk, groups), dim3(256), 0, st, dout, y, gamma, beta, save_mean, save_rstd, part,
@@ -649,7 +682,7 @@ int movae_bn_act_bwd_grouped(int groups, const float* dout, const float* y, cons
             hipLaunchKernelGGL(bn_bwd_final, dim3(c, groups), dim3(64), 0, st, part, s.nblk, rows, c, sums, tab, accumulate);
             MOVAE_CHECK_LAUNCH("bn_bwd_final");
         }
-        hipLaunchKernelGGL(bn_bwd_apply4, dim3(grid_for(total / 4), groups), dim3(256), 0, st, dout, y, gamma, beta, save_mean,
+        hipLaunchKernelGGL(bn_bwd_apply4, dim3(grid_for(total / 16), groups), dim3(256), 0, st, dout, y, gamma, beta, save_mean,
                            save_rstd, sums, dy, total, c, act, slope);
         MOVAE_CHECK_LAUNCH("bn_bwd_apply");
         return MOVAE_OK;
