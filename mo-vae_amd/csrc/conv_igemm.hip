@@ -778,6 +778,8 @@ int launch_wgrad(const float* S, const float* Bg, float* const* dW, int G, long 
     const int N = g.KH * g.KW * g.Cb;
     if (vec && !(thin::thin_wgrad_ok(g) && ws)) {  // fast path (igemm_v2.h)
         if (N <= 32) return (g_last_kernel = "igemm2_wgrad<128,32>", v2::launch_wgrad2<128, 32>(S, Bg, dW, G, s_gs, b_gs, g, (int)Kl, accumulate, ws, ws_bytes, st));
+        // <= 32 rows of dW (32-channel layers): a 64-row tile would multiply half a tile of padding
+        if (g.Cs <= 32 && N >= 128) return (g_last_kernel = "igemm2_wgrad<32,128>", v2::launch_wgrad2<32, 128>(S, Bg, dW, G, s_gs, b_gs, g, (int)Kl, accumulate, ws, ws_bytes, st));
         if (g.Cs >= 128 && (long)(g.Cs / 128) * (N / 128) * (Kl / 512) * G >= big_tile_min())
             return (g_last_kernel = "igemm2_wgrad<128,128>", v2::launch_wgrad2<128, 128>(S, Bg, dW, G, s_gs, b_gs, g, (int)Kl, accumulate, ws, ws_bytes, st));
         return (g_last_kernel = "igemm2_wgrad<64,64>", v2::launch_wgrad2<64, 64>(S, Bg, dW, G, s_gs, b_gs, g, (int)Kl, accumulate, ws, ws_bytes, st));

@@ -27,7 +27,7 @@ constexpr int RPP = 256 / CPR;        // rows staged per pass of the 256 threads
 
 template <int BM, int BN>
 struct T2 {
-    static constexpr int WN = BN >= 64 ? 2 : 1;  // waves along N
+    static constexpr int WN = BM == 32 ? 4 : (BN >= 64 ? 2 : 1);  // waves along N (32-row tile: all four side by side)
     static constexpr int WM = 4 / WN;            // waves along M
     static constexpr int TM = BM / (WM * 32);    // 32x32 accumulators per wave along M ...
     static constexpr int TN = BN / (WN * 32);    // ... and along N (2x2 = 64x64 per wave for the 128x128 tile)
