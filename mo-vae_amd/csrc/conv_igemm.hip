@@ -546,6 +546,28 @@ __global__ __launch_bounds__(256) void splitk_reduce_flat(const float* __restric
     }
 }
 
+// BWD form with per-class split factors: pixel (ho, wo) belongs to output-parity class (ho % s) * s + (wo % s) and only the
+// first scls[class] slabs hold its partial sums (the others were never written for that pixel).  One float4 per thread.
+struct ClsSplit {
+    int s[4];
+};
+__global__ __launch_bounds__(256) void splitk_reduce_cls(const float* __restrict__ slab, float* __restrict__ out, long total, int N,
+                                                         int Ho, int Wo, int stride, ClsSplit scls, const float* __restrict__ bias,
+                                                         int act, float slope) {
+    const long nv = total / 4, gstride = (long)gridDim.x * blockDim.x;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nv; q += gstride) {
+        const long i = q * 4, p = i / N;
+        const int n = (int)(i - p * N);
+        const int wo = (int)(p % Wo), ho = (int)((p / Wo) % Ho);
+        const int S = scls.s[(ho % stride) * stride + (wo % stride)];
+        f32x4 v = *reinterpret_cast<const f32x4*>(slab + i);
+        for (int z = 1; z < S; ++z) v += *reinterpret_cast<const f32x4*>(slab + (long)z * total + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j] + (bias ? bias[n + j] : 0.f), act, slope);
+        *reinterpret_cast<f32x4*>(out + i) = v;
+    }
+}
+
 const char* g_last_kernel = "";  // movae_bench_last_kernel(): main kernel chosen by the most recent conv-family dispatch
 int g_force_split = 0;           // movae_bench_force_split(): > 0 pins the split-K factor (tuning sweeps)
 bool g_bench_main_only = false;  // movae_bench_main_kernel_only(): time the MFMA kernel without its epilogue launches
@@ -710,7 +732,7 @@ int launch_bwd(const float* X, const float* W, float* Y, const Geom& g, const Ep
         if (int rc = thin::launch_thin_out_tile<true>(X, W, Y, g, ep, st, &handled)) return rc;
         if (handled) return (g_last_kernel = "thin_out_tile_k<bwd>", MOVAE_OK);
     }
-    if (g.Cr % 4 == 0 && g.Nn % 4 == 0 && aligned16(X) && aligned16(W)) {  // fast path (igemm_v2.h)
+    if (g.Cr % 4 == 0 && g.Nn % 4 == 0 && g.stride <= 2 && aligned16(X) && aligned16(W) && aligned16(Y)) {  // fast path (igemm_v2.h)
         if (g.Nn <= 32) return (g_last_kernel = "igemm2_bwd<128,32>", v2::launch_bwd2<128, 32>(X, W, Y, g, ep, ws, ws_bytes, st));
         if (g.Nn >= 128 && (Mc / 128) * (g.Nn / 128) * g.stride * g.stride >= big_tile_min())
             return (g_last_kernel = "igemm2_bwd<128,128>", v2::launch_bwd2<128, 128>(X, W, Y, g, ep, ws, ws_bytes, st));

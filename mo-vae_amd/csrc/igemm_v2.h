@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void igemm2_fwd(const float* __restrict__ X, c
 // ------------------------------------------------------------------------------------------------
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void igemm2_bwd(const float* __restrict__ X, const float* __restrict__ W,
-                                                  float* __restrict__ Y, Geom g, Epilogue ep, int S, int ktiles_per_split,
+                                                  float* __restrict__ Y, Geom g, Epilogue ep, ClsSplit scls, ClsSplit kps,
                                                   float* __restrict__ slab, long total) {
     using T = T2<BM, BN>;
     constexpr int ASZ = BM * LDR, BSZ = BK2 * T::LDKB;
@@ -242,7 +242,12 @@ __global__ __launch_bounds__(256) void igemm2_bwd(const float* __restrict__ X, c
     __shared__ __attribute__((aligned(16))) float Bs[(T::DB ? 2 : 1) * BSZ];
     const int t = threadIdx.x;
     const int s = g.stride;
-    const int cls = blockIdx.z / S, split = blockIdx.z - cls * S;
+    // blockIdx.z enumerates (class, split) pairs; class c owns scls.s[c] consecutive z values and kps.s[c] k-tiles per split
+    // (the s*s output-parity classes of a 3x3 stride-2 layer carry 1/2/2/4 taps: one split factor for all would let the
+    // 4-tap class set the kernel's duration)
+    int cls = 0, split = blockIdx.z;
+    while (cls < s * s - 1 && split >= scls.s[cls]) split -= scls.s[cls++];
+    const int ktiles_per_split = kps.s[cls];
     const int ph = cls / s, pw = cls % s;
     const int Hoc = (g.Ho - ph + s - 1) / s, Woc = (g.Wo - pw + s - 1) / s;
     const int M = g.Nimg * Hoc * Woc;
@@ -514,15 +519,66 @@ int launch_bwd2(const float* X, const float* W, float* Y, const Geom& g, const E
     const int s = g.stride;
     const long Mmax = (long)g.Nimg * ceil_div(g.Ho, s) * ceil_div(g.Wo, s);
     const int gx = ceil_div(Mmax, BM), gy = ceil_div(g.Nn, BN);
-    const int nk_max = ceil_div((long)ceil_div(g.KH, s) * ceil_div(g.KW, s) * g.Cr, BK2);
     const long total = (long)g.Nimg * g.Ho * g.Wo * g.Nn;
-    int S = choose_split(FORM_BWD, BM * BN, BK2, (long)gx * gy * s * s, nk_max, (size_t)total * sizeof(float), ws_bytes, ws != nullptr);
-    const int per_split = ceil_div(nk_max, S);
-    S = ceil_div(nk_max, per_split);
-    float* slab = S > 1 ? static_cast<float*>(ws) : nullptr;
-    hipLaunchKernelGGL((igemm2_bwd<BM, BN>), dim3(gx, gy, s * s * S), dim3(256), 0, st, X, W, Y, g, ep, S, per_split, slab, total);
+    // k-tiles of every output-parity class (same arithmetic as the kernel)
+    int nk_c[4] = {0, 0, 0, 0}, nk_max = 0;
+    long nk_sum = 0;
+    const int ncls = s * s <= 4 ? s * s : 0;
+    for (int c = 0; c < ncls; ++c) {
+        const int ph = c / s, pw = c % s;
+        const int kh0 = (ph + g.pad) % s, kw0 = (pw + g.pad) % s;
+        const int nA = kh0 < g.KH ? (g.KH - kh0 + s - 1) / s : 0, nB = kw0 < g.KW ? (g.KW - kw0 + s - 1) / s : 0;
+        nk_c[c] = ceil_div((long)nA * nB * g.Cr, BK2);
+        nk_max = nk_c[c] > nk_max ? nk_c[c] : nk_max;
+        nk_sum += nk_c[c];
+    }
+    if (ncls == 0 || nk_max == 0) {
+        movae_set_error("conv bwd-form: stride %d unsupported by the fast path", s);
+        return MOVAE_EUNSUPPORTED;
+    }
+    // split factor of the heaviest class from the cost model, on the block count the balanced grid will have
+    const long tiles_eff = ceil_div((long)gx * gy * nk_sum, nk_max);
+    int Smax = choose_split(FORM_BWD, BM * BN, BK2, tiles_eff, nk_max, (size_t)total * sizeof(float), ws_bytes, ws != nullptr);
+    // the cost model sees balanced blocks; unsplit but unbalanced (heaviest class >= 2x the lightest) it is better to split
+    int nk_min = nk_max;
+    for (int c = 0; c < ncls; ++c)
+        if (nk_c[c] > 0 && nk_c[c] < nk_min) nk_min = nk_c[c];
+    static const int balance = getenv("MOVAE_BWD_BALANCE") ? atoi(getenv("MOVAE_BWD_BALANCE")) : 1;
+    // (measured: pays while the output is below ~5 MB -- every extra slab writes and re-reads it once)
+    if (balance && Smax == 1 && ws && nk_max >= 2 * nk_min && nk_min >= 4 && (size_t)total * sizeof(float) <= (5u << 20) &&
+        (size_t)total * sizeof(float) * (nk_max / nk_min) <= ws_bytes && g.Nn % 4 == 0)
+        Smax = nk_max / nk_min;
+    ClsSplit scls, kps;
+    int zsum = 0, Sreal = 1;
+    for (int c = 0; c < 4; ++c) {
+        int Sc = 1, per = 1;
+        if (c < ncls && nk_c[c] > 0) {
+            Sc = balance ? (int)(((long)Smax * nk_c[c] + nk_max - 1) / nk_max) : Smax;
+            if (Sc < 1) Sc = 1;
+            per = ceil_div(nk_c[c], Sc);
+            Sc = ceil_div(nk_c[c], per);
+        }
+        scls.s[c] = c < ncls ? Sc : 0;
+        kps.s[c] = per;
+        if (c < ncls) {
+            zsum += Sc;
+            Sreal = Sc > Sreal ? Sc : Sreal;
+        }
+    }
+    float* slab = Sreal > 1 ? static_cast<float*>(ws) : nullptr;
+    if (slab && ((size_t)total * sizeof(float) * Sreal > ws_bytes || g.Nn % 4 != 0)) {
+        movae_set_error("conv bwd-form: workspace too small for %d slabs", Sreal);
+        return MOVAE_EINVAL;
+    }
+    hipLaunchKernelGGL((igemm2_bwd<BM, BN>), dim3(gx, gy, zsum), dim3(256), 0, st, X, W, Y, g, ep, scls, kps, slab, total);
     MOVAE_CHECK_LAUNCH("igemm2_bwd");
-    if (S > 1) return launch_reduce(slab, Y, total, S, g.Nn, ep.bias, ep.act, ep.slope, 0, st);
+    if (Sreal > 1 && !g_bench_main_only) {
+        long gq = (total / 4 + 255) / 256;
+        if (gq > 4096) gq = 4096;
+        hipLaunchKernelGGL(splitk_reduce_cls, dim3((unsigned)gq), dim3(256), 0, st, slab, Y, total, g.Nn, g.Ho, g.Wo, s, scls, ep.bias,
+                           ep.act, ep.slope);
+        MOVAE_CHECK_LAUNCH("splitk_reduce_cls");
+    }
     return MOVAE_OK;
 }
 
