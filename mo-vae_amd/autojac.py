@@ -109,6 +109,30 @@ def _accumulate_stacked(a, b, G):
     return a + b
 
 
+def _expected_shape(node, input_nr):
+    """Shape autograd expects for gradient `input_nr` flowing into `node` (None when unknown)."""
+    var = getattr(node, "variable", None)
+    if var is not None:
+        return tuple(var.shape)
+    meta = getattr(node, "_input_metadata", None)
+    if meta is not None and input_nr < len(meta):
+        return tuple(meta[input_nr].shape)
+    return None
+
+
+def _fit_groups(t, shape, G):
+    """torch.autograd reduces a node's output to the shape of the forward input it belongs to (broadcast operands);
+    calling nodes directly skips that step, so it is applied here, per group."""
+    if shape is None:
+        return t
+    if isinstance(t, (list, tuple)):
+        return [x if x is None or tuple(x.shape) == shape else x.sum_to_size(shape) for x in t]
+    if tuple(t.shape[1:]) == shape:
+        return t
+    return [t[g].sum_to_size(shape) for g in range(G)]
+
+
+@torch.no_grad()  # nodes are called directly; without this their formulas would be recorded as a new graph
 def _batched_pullback(features, feat_grads, rows, jb):
     """Pull G = len(rows) cotangents of `features` back through the shared graph in ONE traversal and write row
     rows[g] of the Jacobian arena for group g.
@@ -203,6 +227,7 @@ def _batched_pullback(features, feat_grads, rows, jb):
                     continue
                 o = outs[i] if outs is not None and i < len(outs) else None
                 if o is not None:
+                    o = _fit_groups(o, _expected_shape(nf, nr), G)  # the engine's validate_outputs: un-broadcast
                     slot = pending.setdefault(nf, {})
                     slot[nr] = _accumulate_stacked(slot.get(nr), o, G)
                 deps[nf] -= 1
