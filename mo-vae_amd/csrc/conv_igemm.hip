@@ -634,6 +634,11 @@ inline int choose_split(int form, int tile_area, int bk, long tiles, int nk, siz
 // ------------------------------------------------------------------------------------------------
 #include "igemm_v2.h"
 #include "conv_thin.h"
+#include "linear_small.h"
+
+inline bool is_linear(const Geom& g) {
+    return g.KH == 1 && g.KW == 1 && g.Hi == 1 && g.Wi == 1 && g.Ho == 1 && g.Wo == 1 && g.stride == 1 && g.pad == 0;
+}
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -674,6 +679,11 @@ int launch_fwd(const float* X, const float* W, float* Y, const Geom& g, const Ep
         return MOVAE_EINVAL;
     }
     const int M = (int)Ml, K = (int)Kl;
+    if (is_linear(g) && lin::linear_small_ok(Ml, g.Nn, Kl) && aligned16(X) && aligned16(W)) {
+        float* ys[1] = {Y};
+        return (g_last_kernel = "linear_small_k<NT>",
+                lin::launch_linear_small<0>(X, W, ys, nullptr, 1, 0, ep.bias, M, g.Nn, K, ep.act, ep.slope, 0, st));
+    }
     if (thin::thin_in_ok(g)) return (g_last_kernel = "thin_in_k<fwd>", thin::launch_thin_in<false>(X, W, Y, g, ep, st));
     if (g.Nn <= 4) {  // 3-channel output: LDS-tiled direct kernel
         bool handled = false;
@@ -726,6 +736,11 @@ int launch_bwd(const float* X, const float* W, float* Y, const Geom& g, const Ep
         return MOVAE_EINVAL;
     }
     const long Mc = Ml / (g.stride * g.stride);
+    if (is_linear(g) && lin::linear_small_ok(Ml, g.Nn, g.Cr) && g.Nn % 4 == 0 && aligned16(X) && aligned16(W)) {
+        float* ys[1] = {Y};
+        return (g_last_kernel = "linear_small_k<NN>",
+                lin::launch_linear_small<1>(X, W, ys, nullptr, 1, 0, ep.bias, (int)Ml, g.Nn, g.Cr, ep.act, ep.slope, 0, st));
+    }
     if (thin::thin_in_ok(g)) return (g_last_kernel = "thin_in_k<bwd>", thin::launch_thin_in<true>(X, W, Y, g, ep, st));
     if (g.Nn <= 4) {  // 3-channel output of a transposed conv: LDS-tiled direct kernel
         bool handled = false;
@@ -789,12 +804,21 @@ int launch_wgrad1(const float* S, const float* Bg, float* dW, const WGeom& g, in
 }
 
 // G cotangent groups of one layer: group i reads S + i * s_gs and Bg + i * b_gs (0 = shared operand), writes dW[i]
+// colsum_S (optional): per-group destinations of sum_p S[p][a] (the bias gradient when S is dy); *colsum_done reports whether
+// the chosen kernel produced it
 int launch_wgrad(const float* S, const float* Bg, float* const* dW, int G, long s_gs, long b_gs, const WGeom& g, int accumulate,
-                 void* ws, size_t ws_bytes, hipStream_t st) {
+                 void* ws, size_t ws_bytes, hipStream_t st, float* const* colsum_S = nullptr, bool* colsum_done = nullptr) {
     const long Kl = (long)g.Nimg * g.Hs * g.Ws;
     if (Kl <= 0 || Kl > 0x7fffffffL || g.Cs <= 0 || g.Cb <= 0) {
         movae_set_error("wgrad: bad shape K=%ld Cs=%d Cb=%d", Kl, g.Cs, g.Cb);
         return MOVAE_EINVAL;
+    }
+    if (colsum_done) *colsum_done = false;
+    if (g.KH == 1 && g.KW == 1 && g.Hs == 1 && g.Ws == 1 && g.Hb == 1 && g.Wb == 1 && b_gs == 0 &&
+        lin::linear_small_ok(g.Cs, g.Cb, (Kl + 3) / 4 * 4) && !g_bench_main_only) {  // reduction = batch rows, any count
+        if (colsum_done) *colsum_done = colsum_S != nullptr;
+        return (g_last_kernel = "linear_small_k<TN>",
+                lin::launch_linear_small<2>(S, Bg, dW, colsum_S, G, s_gs, nullptr, g.Cs, g.Cb, (int)Kl, 0, 0.f, accumulate, st));
     }
     const bool vec = g.Cs % 4 == 0 && g.Cb % 4 == 0 && aligned16(S) && aligned16(Bg) && s_gs % 4 == 0 && b_gs % 4 == 0;
     const int N = g.KH * g.KW * g.Cb;
@@ -886,8 +910,9 @@ int movae_conv2d_wgrad_grouped(int groups, const float* dy, const float* x, floa
     if (int rc = check_conv_shape("movae_conv2d_wgrad", n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, false)) return rc;
     WGeom g{n, ho, wo, co, hi, wi, ci, kh, kw, stride, pad};
     const long dy_gs = (long)n * ho * wo * co;  // dy is stacked [groups][n][ho][wo][co]; x is shared
-    if (int rc = launch_wgrad(dy, x, dw, groups, dy_gs, 0, g, accumulate, ws, ws_bytes, (hipStream_t)stream)) return rc;
-    if (dbias && !g_bench_main_only)
+    bool bias_done = false;
+    if (int rc = launch_wgrad(dy, x, dw, groups, dy_gs, 0, g, accumulate, ws, ws_bytes, (hipStream_t)stream, dbias, &bias_done)) return rc;
+    if (dbias && !bias_done && !g_bench_main_only)
         for (int i = 0; i < groups; ++i)
             if (dbias[i])
                 if (int rc = movae_colsum(dy + i * dy_gs, dbias[i], n * ho * wo, co, accumulate, ws_full, ws_full_bytes, stream)) return rc;

@@ -1,0 +1,130 @@
+// linear_small.h -- one-launch GEMMs for the fully connected layers of the hot path (included inside conv_igemm.hip's
+// anonymous namespace).
+//
+// fc_mu / fc_var / decoder_input are [batch x 512] x [512 x 128]-sized problems: 34 MFLOP, a few microseconds of MFMA
+// time, for which the tiled implicit-GEMM kernels need split-K plus a reduce launch (and a column-sum launch pair for the
+// bias gradient) -- 8-22 us per call, ~120 us of a 1.5 ms step.  Here a block owns ONE 32x32 output tile, its four waves
+// split the reduction four ways, operands go global -> registers directly in MFMA lane order (no LDS staging, the whole
+// k-slice of a wave is in flight at once), the four partial accumulators fold through LDS and the epilogue (bias,
+// activation, bias gradient) happens in the same launch.
+//   NT  (linear forward)  Y[m][n]  = sum_k A[m][k] * B[n][k]          A = x [M][K],  B = W [N][K]
+//   NN  (linear dgrad)    Y[m][n]  = sum_k A[m][k] * B[k][n]          A = dy [M][K], B = W [K][N]
+//   TN  (linear wgrad)    Y[m][n]  = sum_k A[k][m] * B[k][n]          A = dy [K][M], B = x [K][N];  colsum[m] = sum_k A[k][m]
+// MFMA k assignment: within a group of 8 reduction indices lane half h consumes k = 4h + j at step j (both operands
+// agree, so the contraction is unchanged).
+#pragma once
+
+namespace lin {
+
+constexpr int LU = 16;  // 8-wide reduction groups a wave keeps in flight (16 * 8 = 128 reduction indices)
+
+struct LinOut {
+    float* y[8];       // per cotangent group (blockIdx.z)
+    float* colsum[8];  // TN only: bias gradient per group (may be null)
+};
+
+template <int FORM>  // 0 = NT, 1 = NN, 2 = TN
+__global__ __launch_bounds__(256) void linear_small_k(const float* __restrict__ A, const float* __restrict__ B, LinOut out,
+                                                      const float* __restrict__ bias, int M, int N, int K, int act, float slope,
+                                                      long a_gs, int accumulate) {
+    __shared__ float red[4][16][64];
+    __shared__ float csum[4][32];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    A += blockIdx.z * a_gs;  // cotangent group: only the A operand (dy) is per group
+    // reduction slice of this wave, in groups of 8
+    const int groups = (K + 7) / 8, gper = (groups + 3) / 4;
+    const int g_begin = wave * gper, g_end = min(groups, g_begin + gper);
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float cs = 0.f;
+    const int am = m0 + r, bn = n0 + r;
+    for (int gb = g_begin; gb < g_end; gb += LU) {
+        f32x4 a4[LU], b4[LU];
+#pragma unroll
+        for (int u = 0; u < LU; ++u) {
+            const int k = (gb + u) * 8 + 4 * h;
+            const bool kv = gb + u < g_end && k < K;  // K % 4 == 0
+            if (FORM == 0) {
+                a4[u] = (kv && am < M) ? *reinterpret_cast<const f32x4*>(A + (long)am * K + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+                b4[u] = (kv && bn < N) ? *reinterpret_cast<const f32x4*>(B + (long)bn * K + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else if (FORM == 1) {
+                a4[u] = (kv && am < M) ? *reinterpret_cast<const f32x4*>(A + (long)am * K + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b4[u][j] = (kv && bn < N) ? B[(long)(k + j) * N + bn] : 0.f;
+            } else {  // the reduction index is the batch row here: any count, checked per row
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool kj = gb + u < g_end && k + j < K;
+                    a4[u][j] = (kj && am < M) ? A[(long)(k + j) * M + am] : 0.f;
+                    b4[u][j] = (kj && bn < N) ? B[(long)(k + j) * N + bn] : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < LU; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[u][j], b4[u][j], acc, 0, 0, 0);
+                if (FORM == 2) cs += a4[u][j];
+            }
+    }
+    // fold the four waves' partial tiles; thread t then owns 4 consecutive outputs of one row
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[wave][i][lane] = acc[i];
+    if (FORM == 2) {
+        cs += __shfl_xor(cs, 32, 64);
+        if (lane < 32) csum[wave][lane] = cs;
+    }
+    __syncthreads();
+    // accumulator register i of lane (r, h) is C[row = (i & 3) + 8 * (i >> 2) + 4 * h][col = r]
+    {
+        const int row = t >> 3, c4 = (t & 7) * 4;  // 32 rows x 8 column quads
+        const int i = (row & 3) + 4 * (row >> 3), hh = (row >> 2) & 1;
+        const int m = m0 + row;
+        float* Y = out.y[blockIdx.z];
+        if (m < M) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + c4 + j;
+                if (n < N) {
+                    const int ln = hh * 32 + c4 + j;
+                    float v = (red[0][i][ln] + red[1][i][ln]) + (red[2][i][ln] + red[3][i][ln]);
+                    if (FORM != 2) v = apply_act(v + (bias ? bias[n] : 0.f), act, slope);
+                    float* dst = Y + (long)m * N + n;
+                    *dst = accumulate ? *dst + v : v;
+                }
+            }
+        }
+    }
+    if (FORM == 2 && blockIdx.y == 0 && t < 32 && m0 + t < M) {
+        float* dbias = out.colsum[blockIdx.z];
+        if (dbias) {
+            const float v = (csum[0][t] + csum[1][t]) + (csum[2][t] + csum[3][t]);
+            dbias[m0 + t] = accumulate ? dbias[m0 + t] + v : v;
+        }
+    }
+}
+
+// shapes served: 1x1 spatial, reduction short enough for one in-flight slice chain, few enough tiles to be latency bound
+inline bool linear_small_ok(long M, long N, long K) {
+    static const bool off = getenv("MOVAE_NO_LINEAR_SMALL") != nullptr;
+    return !off && K % 4 == 0 && K <= 2048 && M * N <= 1024L * 1024 && M > 0 && N > 0;
+}
+
+template <int FORM>
+int launch_linear_small(const float* A, const float* B, float* const* Y, float* const* colsum, int G, long a_gs, const float* bias,
+                        int M, int N, int K, int act, float slope, int accumulate, hipStream_t st) {
+    LinOut out;
+    for (int i = 0; i < 8; ++i) {
+        out.y[i] = i < G ? Y[i] : nullptr;
+        out.colsum[i] = (i < G && colsum) ? colsum[i] : nullptr;
+    }
+    hipLaunchKernelGGL((linear_small_k<FORM>), dim3(ceil_div(M, 32), ceil_div(N, 32), G), dim3(256), 0, st, A, B, out, bias, M, N, K, act,
+                       slope, a_gs, accumulate);
+    MOVAE_CHECK_LAUNCH("linear_small");
+    return MOVAE_OK;
+}
+
+}  // namespace lin
