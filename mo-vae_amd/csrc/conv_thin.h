@@ -32,15 +32,16 @@ __global__ __launch_bounds__(256) void thin_in_k(const float* __restrict__ X, co
     }
     __syncthreads();
     const int p = blockIdx.x * 256 + t;
-    if (p >= M) return;
+    const bool live = p < M;
+    const int pp = live ? p : 0;
     const int hw = g.Ho * g.Wo;
-    const int img = p / hw, rem = p - img * hw;
+    const int img = pp / hw, rem = pp - img * hw;
     const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
     float acc[NN];
 #pragma unroll
     for (int n = 0; n < NN; ++n) acc[n] = (bias && n0 + n < N) ? bias[n0 + n] : 0.f;
     const float* xb = X + (long)img * g.Hi * g.Wi * g.Cr;
-    for (int kh = 0; kh < g.KH; ++kh) {
+    for (int kh = 0; live && kh < g.KH; ++kh) {
         int h;
         if (BWD) {
             const int hh = ho + g.pad - kh;
@@ -73,6 +74,26 @@ __global__ __launch_bounds__(256) void thin_in_k(const float* __restrict__ X, co
             }
         }
     }
+    if (NN == 32 && N == 32) {  // (launch_thin_in sizes the dynamic LDS for the 256 x 33 transpose tile in this case)
+        // the block's 256 pixels x 32 outputs are one contiguous 32 KiB run of Y: transpose through LDS (the weight tile is
+        // dead by now) so that every wave stores 1 KiB contiguous instead of 64 scattered 16-byte pieces
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < NN; ++n) Wl[t * 33 + n] = apply_act(acc[n], act, slope);
+        __syncthreads();
+        float* yb = Y + (long)blockIdx.x * 256 * 32;
+        const long rows_left = (long)M - (long)blockIdx.x * 256;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = i * 256 + t, px = idx >> 3, q = idx & 7;
+            if (px < rows_left) {
+                const float* src = Wl + px * 33 + q * 4;
+                *reinterpret_cast<f32x4*>(yb + px * 32 + q * 4) = f32x4{src[0], src[1], src[2], src[3]};
+            }
+        }
+        return;
+    }
+    if (!live) return;
     float* yo = Y + (long)p * N + n0;
     if (N % 4 == 0 && n0 + NN <= N) {
 #pragma unroll
@@ -537,7 +558,9 @@ int launch_thin_in(const float* X, const float* W, float* Y, const Geom& g, cons
                            ep.act, ep.slope);
     } else {
         dim3 grid(ceil_div(M, 256), 1);
-        hipLaunchKernelGGL((thin_in_k<32, BWD>), grid, dim3(256), (size_t)K * 32 * sizeof(float), st, X, W, ep.bias, Y, g, M,
+        size_t lds_floats = (size_t)K * 32;
+        if (g.Nn == 32 && lds_floats < 256 * 33) lds_floats = 256 * 33;  // room for the coalescing transpose of the outputs
+        hipLaunchKernelGGL((thin_in_k<32, BWD>), grid, dim3(256), lds_floats * sizeof(float), st, X, W, ep.bias, Y, g, M,
                            ep.act, ep.slope);
     }
     MOVAE_CHECK_LAUNCH("thin_in");
