@@ -33,6 +33,7 @@ typedef void* movae_stream_t; /* hipStream_t */
 enum movae_act { MOVAE_ACT_NONE = 0, MOVAE_ACT_LRELU = 1, MOVAE_ACT_RELU = 2, MOVAE_ACT_TANH = 3, MOVAE_ACT_SIGMOID = 4 };
 enum movae_recon { MOVAE_RECON_MSE = 0, MOVAE_RECON_BCE = 1, MOVAE_RECON_L1 = 2, MOVAE_RECON_SMOOTH_L1 = 3 };
 enum movae_mgda_norm { MOVAE_MGDA_NONE = 0, MOVAE_MGDA_L2 = 1, MOVAE_MGDA_LOSS = 2, MOVAE_MGDA_LOSS_PLUS = 3 };
+enum movae_upgrad_norm { MOVAE_UPGRAD_TRACE = 0, MOVAE_UPGRAD_MIN_L2 = 1, MOVAE_UPGRAD_COSINE = 2 };
 enum movae_amtl_scale { MOVAE_AMTL_MIN = 0, MOVAE_AMTL_MEDIAN = 1, MOVAE_AMTL_RMSE = 2 };
 
 int movae_version(void);
@@ -162,6 +163,11 @@ int movae_gram(const float* J, size_t ldj, int k, size_t m, float* G, void* ws, 
 /* UPGrad (torchjd; constructed main.py:1195): G/tr(G) (0 if tr<norm_eps) + reg_eps I; for each i solve
  * min 1/2 w'Gw s.t. w >= u_i e_i; sum rows.  pref may be NULL (u = 1/k).  Solved in fp64 on device. */
 int movae_weights_upgrad(const float* G, int k, float norm_eps, float reg_eps, const float* pref, float* w, movae_stream_t stream);
+/* the same projection on a differently normalised Gramian: MOVAE_UPGRAD_MIN_L2 = NUPGrad
+ * (utils/torchmoo/nupgrad.py:115-158, main.py:1226), MOVAE_UPGRAD_COSINE = the other branch of PNUPGrad's coin flip
+ * (utils/torchmoo/pnupgrad.py:13-24,127-134, main.py:1228); MOVAE_UPGRAD_TRACE is movae_weights_upgrad. */
+int movae_weights_upgrad_norm(const float* G, int k, int norm_mode, float norm_eps, float reg_eps, const float* pref, float* w,
+                              movae_stream_t stream);
 /* MGDA Frank-Wolfe (utils/torchmoo/mgda.py:221-367); losses may be NULL for norm NONE/L2. info[0]=iterations */
 int movae_weights_mgda(const float* G, int k, int norm, const float* losses, float epsilon, int max_iters,
                        float* w, int32_t* info, movae_stream_t stream);

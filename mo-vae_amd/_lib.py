@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(HERE, "libmovae_hip.so")
 
 ACT = {"none": 0, None: 0, "lrelu": 1, "relu": 2, "tanh": 3, "sigmoid": 4}
 RECON = {"mse": 0, "bce": 1, "l1": 2, "smooth_l1": 3}
+UPGRAD_NORM = {"trace": 0, "min_l2": 1, "cosine": 2}
 MGDA_NORM = {"none": 0, "l2": 1, "loss": 2, "loss+": 3}
 AMTL_SCALE = {"min": 0, "median": 1, "rmse": 2}
 MAX_K = 8
@@ -60,6 +61,7 @@ SIGNATURES = {
     "movae_gram_ws_bytes": ([_i, _z], _z),
     "movae_gram": ([_p, _z, _i, _z, _p, _p, _z, _p], _i),
     "movae_weights_upgrad": ([_p, _i, _f, _f, _p, _p, _p], _i),
+    "movae_weights_upgrad_norm": ([_p, _i, _i, _f, _f, _p, _p, _p], _i),
     "movae_weights_mgda": ([_p, _i, _i, _p, _f, _i, _p, _p, _p], _i),
     "movae_weights_amtl": ([_p, _i, _i, _p, _p, _p], _i),
     "movae_weights_const": ([_i, _f, _p, _p], _i),

@@ -81,7 +81,8 @@ class _FromJacobian(tnn.Module):
         self.gramian_weighting = gramian_weighting
 
     def forward(self, J):
-        return self.gramian_weighting(compute_gramian(J))
+        self.last_gramian = compute_gramian(J)  # kept for aggregators that derive a second weighting from it (COMFORT)
+        return self.gramian_weighting(self.last_gramian)
 
 
 class GramianWeightedAggregator(tnn.Module):
@@ -97,17 +98,36 @@ class GramianWeightedAggregator(tnn.Module):
 
 # ---- UPGrad --------------------------------------------------------------------------------------
 class UPGradWeighting(Weighting):
-    def __init__(self, pref_vector=None, norm_eps=1e-4, reg_eps=1e-4):
+    """Projection of every weighted row onto the dual cone of all rows.  `norm` selects the Gramian normalisation:
+    "trace" (torchjd UPGrad), "min_l2" (NUPGrad), "cosine" (PNUPGrad's second branch)."""
+
+    def __init__(self, pref_vector=None, norm_eps=1e-4, reg_eps=1e-4, norm="trace"):
         super().__init__()
-        self.pref_vector, self.norm_eps, self.reg_eps = pref_vector, norm_eps, reg_eps
+        self.pref_vector, self.norm_eps, self.reg_eps, self.norm = pref_vector, norm_eps, reg_eps, norm
+
+    def _mode(self):
+        return self.norm
 
     def forward(self, G):
         k = G.shape[0]
         w = torch.empty(k, dtype=torch.float32, device=G.device)
         pref = _pref_tensor(self.pref_vector, G.device)
-        L.call("movae_weights_upgrad", G.data_ptr(), k, float(self.norm_eps), float(self.reg_eps), L.ptr(pref),
-                                              w.data_ptr(), _st(G))
+        L.call("movae_weights_upgrad_norm", G.data_ptr(), k, L.UPGRAD_NORM[self._mode()], float(self.norm_eps),
+               float(self.reg_eps), L.ptr(pref), w.data_ptr(), _st(G))
         return w
+
+
+class _PNUPGradWeighting(UPGradWeighting):
+    """utils/torchmoo/pnupgrad.py:127-134: with probability `prob` the cosine-normalised Gramian, else the min-L2 one.
+    The coin is torch's CPU generator, as in the reference (`torch.rand(1).item()`), so a seeded run makes the same
+    sequence of choices; it is drawn on the host per call and therefore not replayable from a captured hipGraph."""
+
+    def __init__(self, pref_vector=None, prob=0.5, norm_eps=1e-4, reg_eps=1e-4):
+        super().__init__(pref_vector, norm_eps, reg_eps, norm="min_l2")
+        self.prob = prob
+
+    def _mode(self):
+        return "cosine" if torch.rand(1).item() < self.prob else "min_l2"
 
 
 class UPGrad(GramianWeightedAggregator):
@@ -121,6 +141,29 @@ class UPGrad(GramianWeightedAggregator):
         return f"UPGrad(pref_vector={self._pref_vector!r}, norm_eps={self._norm_eps}, reg_eps={self._reg_eps})"
 
 
+class NUPGrad(GramianWeightedAggregator):
+    """utils/torchmoo/nupgrad.py:37-89 as constructed at main.py:1226."""
+
+    def __init__(self, pref_vector=None, norm_eps=0.0001, reg_eps=0.0001, solver="quadprog"):
+        super().__init__(UPGradWeighting(pref_vector, norm_eps, reg_eps, norm="min_l2"))
+        self._pref_vector, self._norm_eps, self._reg_eps = pref_vector, norm_eps, reg_eps
+
+    def __repr__(self):
+        return f"NUPGrad(pref_vector={self._pref_vector!r}, norm_eps={self._norm_eps}, reg_eps={self._reg_eps}, solver='quadprog')"
+
+
+class PNUPGrad(GramianWeightedAggregator):
+    """utils/torchmoo/pnupgrad.py:36-95 as constructed at main.py:1228."""
+
+    def __init__(self, pref_vector=None, prob=0.5, norm_eps=0.0001, reg_eps=0.0001, solver="quadprog"):
+        super().__init__(_PNUPGradWeighting(pref_vector, prob, norm_eps, reg_eps))
+        self._pref_vector, self._prob, self._norm_eps, self._reg_eps = pref_vector, prob, norm_eps, reg_eps
+
+    def __repr__(self):
+        return (f"PNUPGrad(pref_vector={self._pref_vector!r}, prob={self._prob}, norm_eps={self._norm_eps}, "
+                f"reg_eps={self._reg_eps}, solver='quadprog')")
+
+
 # ---- MGDA (utils/torchmoo/mgda.py) -------------------------------------------------------------------
 class MGDAWeighting(Weighting):
     def __init__(self, norm_type="none", epsilon=1e-5, max_iters=250, stable=False, min_eigenvalue_eps=1e-10):
@@ -129,7 +172,7 @@ class MGDAWeighting(Weighting):
             raise ValueError("Parameter `norm_type` should be 'none', 'l2', 'loss', or 'loss+'. Found "
                              f"`norm_type = {norm_type!r}`.")
         if stable:
-            raise NotImplementedError("StableMGDA (eigen regularisation) is only reached through COMFORT, which is out of scope")
+            raise NotImplementedError("StableMGDA (eigen regularisation, --comfort_mgda_stable) is not implemented in this build")
         self.norm_type, self.epsilon, self.max_iters = norm_type, epsilon, max_iters
         self.stable, self.min_eigenvalue_eps = stable, min_eigenvalue_eps
         self._losses = None
@@ -229,7 +272,58 @@ class Sum(GramianWeightedAggregator):
         super().__init__(_ConstWeighting(False))
 
 
-OUT_OF_SCOPE = ("pcgrad", "imtlg", "cagrad", "nashmtl", "dualproj", "nupgrad", "pnupgrad", "comfort")
+def beta_schedule(epoch, total_epochs, k=1.0, a=1.0, l=0.01, u=1.0):
+    """utils/torchmoo/comfort.py:20-66."""
+    import math
+
+    if total_epochs <= 1:
+        return u
+    progress = (epoch - 1) / (total_epochs - 1)
+    progress = min(1.0, max(0.0, progress)) ** a
+    f = progress if k <= 0 else (1.0 - math.exp(-k * progress)) / (1.0 - math.exp(-k))
+    beta = l + (u - l) * f
+    return float(min(u, max(l, beta)))
+
+
+class COMFORT:
+    """utils/torchmoo/comfort.py:68-165: g = (1 - beta) g_MGDA + beta g_UPGrad with beta following `beta_schedule` per
+    epoch (`set_epoch`, main.py:1290-1291).  Both weight vectors come from ONE Gramian and the blend happens on the K
+    weights, so the Jacobian is read twice (Gram, combine) instead of four times; `weighting` is the MGDA weighting, as
+    in the reference (hooks see J and the MGDA weights)."""
+
+    def __init__(self, mgda_norm_type="none", mgda_stable=False, mgda_epsilon=1e-5, mgda_max_iters=250,
+                 mgda_min_eigenvalue_eps=1.0, beta_k=1.0, beta_a=1.0, beta_l=0.01, beta_u=1.0):
+        self._mgda = MGDA(norm_type=mgda_norm_type, epsilon=mgda_epsilon, max_iters=mgda_max_iters, stable=mgda_stable,
+                          min_eigenvalue_eps=mgda_min_eigenvalue_eps)
+        self._upgrad = UPGrad()
+        self._beta_k, self._beta_a, self._beta_l, self._beta_u = beta_k, beta_a, beta_l, beta_u
+        self._current_epoch, self._total_epochs = 1, 1
+        self._norm_type = mgda_norm_type
+        self.weighting = self._mgda.weighting
+
+    def set_epoch(self, epoch, total_epochs):
+        self._current_epoch, self._total_epochs = epoch, total_epochs
+
+    def set_losses(self, losses):
+        self._mgda.set_losses(losses)
+
+    def _get_beta(self):
+        return beta_schedule(self._current_epoch, self._total_epochs, k=self._beta_k, a=self._beta_a, l=self._beta_l, u=self._beta_u)
+
+    def __call__(self, J):
+        w_m = self.weighting(J)                                        # through the module: forward hooks fire
+        w_u = self._upgrad.gramian_weighting(self.weighting.last_gramian)
+        beta = self._get_beta()
+        w = torch.empty_like(w_m)
+        L.call("movae_axpby", 1.0 - beta, w_m.data_ptr(), beta, w_u.data_ptr(), w.data_ptr(), w.numel(), _st(w))
+        return combine(J, w)
+
+    def __repr__(self):
+        return (f"COMFORT(mgda_norm_type={self._norm_type!r}, mgda_stable={self._mgda._stable}, beta_k={self._beta_k}, "
+                f"beta_a={self._beta_a}, beta_l={self._beta_l}, beta_u={self._beta_u})")
+
+
+OUT_OF_SCOPE = ("pcgrad", "imtlg", "cagrad", "nashmtl", "dualproj")
 
 
 def make_aggregator(args):
@@ -256,9 +350,19 @@ def make_aggregator(args):
         return MGDA(epsilon=args.mgda_epsilon, max_iters=args.mgda_max_iters, norm_type=mg[name])
     if name == "jd_sum":
         return Sum()
+    if name == "nupgrad":
+        return NUPGrad(norm_eps=args.agg_norm_eps, reg_eps=args.agg_reg_eps)
+    if name == "pnupgrad":
+        return PNUPGrad(norm_eps=args.agg_norm_eps, reg_eps=args.agg_reg_eps)
+    if name == "comfort":
+        return COMFORT(mgda_norm_type=getattr(args, "comfort_mgda_norm_type", "none"),
+                       mgda_stable=getattr(args, "comfort_mgda_stable", False), mgda_epsilon=args.mgda_epsilon,
+                       mgda_max_iters=args.mgda_max_iters, mgda_min_eigenvalue_eps=getattr(args, "mgda_min_eigenvalue_eps", 1e-10),
+                       beta_k=getattr(args, "comfort_beta_k", 1.0), beta_a=getattr(args, "comfort_beta_a", 1.0),
+                       beta_l=getattr(args, "comfort_beta_l", 0.01), beta_u=getattr(args, "comfort_beta_u", 1.0))
     if name == "sum":
         return "sum"
     if name in OUT_OF_SCOPE:
         raise NotImplementedError(f"Aggregator {args.aggregator} exists in the reference but is outside this build's scope "
-                                  "(sum, upgrad, mgda*, aligned_mtl*, mean, jd_sum); see DESIGN.md")
+                                  "(sum, upgrad, nupgrad, pnupgrad, comfort, mgda*, aligned_mtl*, mean, jd_sum); see DESIGN.md")
     raise ValueError(f"Aggregator {args.aggregator} not supported")

@@ -157,15 +157,40 @@ __global__ void similarity_final(const double* __restrict__ part, int nblk, floa
 // One wave; lane s evaluates the active-set candidate whose free set is the bit mask s (s += 64
 // until 2^K), solves the free block by Cholesky in fp64 and scores the KKT violation; the wave
 // keeps the least-violating candidate (the unique KKT point of the strictly convex QP).
-__global__ __launch_bounds__(64) void upgrad_k(const float* __restrict__ Gin, int K, float norm_eps, float reg_eps,
+// norm_mode: how the Gramian is normalised before the projection --
+//   0 trace (torchjd UPGrad), 1 min-L2-norm scaling (NUPGrad, utils/torchmoo/nupgrad.py:122-158),
+//   2 cosine (PNUPGrad's `normalize`, utils/torchmoo/pnupgrad.py:13-24)
+__global__ __launch_bounds__(64) void upgrad_k(const float* __restrict__ Gin, int K, int norm_mode, float norm_eps, float reg_eps,
                                                const float* __restrict__ pref, float* __restrict__ wout) {
     const int lane = threadIdx.x;
     double G[MAXK][MAXK];
-    double tr = 0.0;
-    for (int i = 0; i < K; ++i) tr += (double)Gin[i * K + i];
-    const bool zero = tr < (double)norm_eps;
-    for (int i = 0; i < K; ++i)
-        for (int j = 0; j < K; ++j) G[i][j] = (zero ? 0.0 : (double)Gin[i * K + j] / tr) + (i == j ? (double)reg_eps : 0.0);
+    if (norm_mode == 0) {
+        double tr = 0.0;
+        for (int i = 0; i < K; ++i) tr += (double)Gin[i * K + i];
+        const bool zero = tr < (double)norm_eps;
+        for (int i = 0; i < K; ++i)
+            for (int j = 0; j < K; ++j) G[i][j] = zero ? 0.0 : (double)Gin[i * K + j] / tr;
+    } else {
+        // the reference normalises with float32 tensor ops and only then hands the matrix to the fp64 QP; the same
+        // roundings are kept here because the QP of a rank-deficient Gramian amplifies them by ~1 / reg_eps
+        float l2[MAXK], sf[MAXK];
+        float amin = 0.f;
+        bool any = false;
+        for (int i = 0; i < K; ++i) {
+            l2[i] = sqrtf(fmaxf(Gin[i * K + i], norm_eps));
+            if (l2[i] > norm_eps && (!any || l2[i] < amin)) {
+                amin = l2[i];
+                any = true;
+            }
+        }
+        for (int i = 0; i < K; ++i) sf[i] = (any && l2[i] > norm_eps) ? amin / l2[i] : 0.f;
+        for (int i = 0; i < K; ++i)
+            for (int j = 0; j < K; ++j) {
+                const float g = Gin[i * K + j];
+                G[i][j] = norm_mode == 1 ? (double)(g * (sf[i] * sf[j])) : (double)(g / (l2[i] * l2[j]));
+            }
+    }
+    for (int i = 0; i < K; ++i) G[i][i] += (double)reg_eps;
     double wsum[MAXK];
     for (int i = 0; i < K; ++i) wsum[i] = 0.0;
     const int nsub = 1 << K;
@@ -468,12 +493,18 @@ int movae_gd_similarity(const float* J, size_t ldj, int k, size_t m, const float
     return MOVAE_OK;
 }
 
-int movae_weights_upgrad(const float* G, int k, float norm_eps, float reg_eps, const float* pref, float* w, movae_stream_t stream) {
+int movae_weights_upgrad_norm(const float* G, int k, int norm_mode, float norm_eps, float reg_eps, const float* pref, float* w,
+                              movae_stream_t stream) {
     MOVAE_CHECK_ARG(G && w, "movae_weights_upgrad: null pointer");
     MOVAE_CHECK_ARG(k >= 1 && k <= MAXK, "movae_weights_upgrad: k=%d outside 1..%d", k, MAXK);
-    hipLaunchKernelGGL(upgrad_k, dim3(1), dim3(64), 0, (hipStream_t)stream, G, k, norm_eps, reg_eps, pref, w);
+    MOVAE_CHECK_ARG(norm_mode >= 0 && norm_mode <= 2, "movae_weights_upgrad: unknown normalisation %d", norm_mode);
+    hipLaunchKernelGGL(upgrad_k, dim3(1), dim3(64), 0, (hipStream_t)stream, G, k, norm_mode, norm_eps, reg_eps, pref, w);
     MOVAE_CHECK_LAUNCH("upgrad");
     return MOVAE_OK;
+}
+
+int movae_weights_upgrad(const float* G, int k, float norm_eps, float reg_eps, const float* pref, float* w, movae_stream_t stream) {
+    return movae_weights_upgrad_norm(G, k, MOVAE_UPGRAD_TRACE, norm_eps, reg_eps, pref, w, stream);
 }
 
 int movae_weights_mgda(const float* G, int k, int norm, const float* losses, float epsilon, int max_iters, float* w,

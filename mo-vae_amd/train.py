@@ -18,7 +18,7 @@ import torch.optim as optim
 
 from . import aggregation
 from . import autojac
-from .aggregation import MGDA
+from .aggregation import COMFORT, MGDA
 from .models import get_network
 from .optim import FusedAdam, FusedAdamW
 from .parallel import DataParallelGrads
@@ -74,7 +74,7 @@ def forward_backward(net, images, optimizer, aggregator):
     else:
         features = [outputs[f] for f in net.features] if net.features is not None else None
         component_losses = [v for k, v in loss_dict.items() if k != "total_loss"]  # main.py:184
-        if isinstance(aggregator, MGDA):
+        if isinstance(aggregator, (MGDA, COMFORT)):  # main.py:185
             aggregator.set_losses(torch.stack([c.detach() for c in component_losses]))
         if features is not None:
             autojac.mtl_backward(losses=component_losses, features=features, aggregator=aggregator, retain_graph=True)
@@ -438,6 +438,8 @@ def main(args):
     for epoch in range(1, args.epochs + 1):
         if sampler is not None:
             sampler.set_epoch(epoch)
+        if isinstance(aggregator, COMFORT):  # main.py:1290-1291
+            aggregator.set_epoch(epoch, args.epochs)
         t0 = time.time()
         meters, step = train_epoch(net, train_loader, optimizer, aggregator, step, device, args, dp, log)
         torch.cuda.synchronize()

@@ -46,14 +46,57 @@ def _qp_lower_bounded(G, u):
     return best
 
 
-def upgrad_weights(G, norm_eps=1e-4, reg_eps=1e-4, pref=None):
+def normalize_min_l2(G, eps):
+    """utils/torchmoo/nupgrad.py:122-158 (identical copy in pnupgrad.py:137-166): scale gradient k by a_min / a_k, a_k the
+    L2 norms sqrt(clamp(G_kk, eps)), a_min the smallest norm above eps (zero matrix when there is none).  float32 like the
+    reference.  Pinned by tests/golden/agg_variants.npz."""
+    G = np.asarray(G, dtype=np.float32)
+    l2 = np.sqrt(np.maximum(np.diagonal(G), np.float32(eps))).astype(np.float32)
+    mask = l2 > np.float32(eps)
+    if not mask.any():
+        return np.zeros_like(G)
+    amin = l2[mask].min()
+    sf = np.where(mask, amin / l2, np.float32(0.0)).astype(np.float32)
+    return (G * (sf[:, None] * sf[None, :])).astype(np.float32)
+
+
+def normalize_cosine(G, eps):
+    """utils/torchmoo/pnupgrad.py:13-24: G_ij / (||g_i|| ||g_j||) with ||g_k|| = sqrt(clamp(G_kk, eps)).  float32."""
+    G = np.asarray(G, dtype=np.float32)
+    gn = np.sqrt(np.maximum(np.diagonal(G), np.float32(eps))).astype(np.float32)
+    return (G / (gn[:, None] * gn[None, :])).astype(np.float32)
+
+
+def beta_schedule(epoch, total_epochs, k=1.0, a=1.0, l=0.01, u=1.0):
+    """utils/torchmoo/comfort.py:20-66."""
+    import math
+
+    if total_epochs <= 1:
+        return u
+    progress = (epoch - 1) / (total_epochs - 1)
+    progress = min(1.0, max(0.0, progress)) ** a
+    f = progress if k <= 0 else (1.0 - math.exp(-k * progress)) / (1.0 - math.exp(-k))
+    beta = l + (u - l) * f
+    return float(min(u, max(l, beta)))
+
+
+def upgrad_weights(G, norm_eps=1e-4, reg_eps=1e-4, pref=None, norm="trace"):
     """torchjd UPGrad weighting (constructed at main.py:1195): trace-normalise, regularise,
     project every row of U = diag(pref or 1/K) onto the dual cone, sum the rows.
-    Arithmetic in float64 on the host like torchjd's numpy path; result cast to G's dtype."""
+    Arithmetic in float64 on the host like torchjd's numpy path; result cast to G's dtype.
+    norm = "min_l2" is NUPGrad (nupgrad.py:115-120), "cosine" PNUPGrad's other branch (pnupgrad.py:127-134): the same
+    projection on a differently normalised Gramian."""
     Gd = np.asarray(G.detach().cpu().numpy() if isinstance(G, torch.Tensor) else G, dtype=np.float64)
     K = Gd.shape[0]
-    tr = np.trace(Gd)
-    Gn = np.zeros_like(Gd) if tr < norm_eps else Gd / tr
+    if norm == "trace":
+        tr = np.trace(Gd)
+        Gn = np.zeros_like(Gd) if tr < norm_eps else Gd / tr
+    elif norm == "min_l2":
+        Gn = normalize_min_l2(Gd, norm_eps).astype(np.float64)
+    elif norm == "cosine":
+        Gn = normalize_cosine(Gd, norm_eps).astype(np.float64)
+    else:
+        raise ValueError(norm)
     Gn = Gn + reg_eps * np.eye(K)
     u_diag = np.full(K, 1.0 / K) if pref is None else np.asarray(pref, dtype=np.float64)
     W = np.zeros((K, K))
@@ -147,6 +190,16 @@ def make_weighting(name, **kw):
     mg = {"mgda": "none", "mgda_ln": "l2", "mgda_gn": "loss", "mgda_lgn": "loss+"}
     if n in mg:
         return lambda G, losses=None: mgda_weights(G, mg[n], losses, kw.get("epsilon", 1e-5), kw.get("max_iters", 250))
+    if n == "nupgrad":
+        return lambda G, losses=None: upgrad_weights(G, kw.get("norm_eps", 1e-4), kw.get("reg_eps", 1e-4), norm="min_l2")
+    if n in ("pnupgrad_cosine", "pnupgrad_min_l2"):  # the two branches of PNUPGrad's coin flip (pnupgrad.py:129-132)
+        return lambda G, losses=None: upgrad_weights(G, kw.get("norm_eps", 1e-4), kw.get("reg_eps", 1e-4), norm=n.split("_", 1)[1])
+    if n == "comfort":  # (1 - beta) MGDA + beta UPGrad (comfort.py:146-157); UPGrad() with its default eps
+        beta = beta_schedule(kw.get("epoch", 1), kw.get("total_epochs", 1), kw.get("beta_k", 1.0), kw.get("beta_a", 1.0),
+                             kw.get("beta_l", 0.01), kw.get("beta_u", 1.0))
+        nt = kw.get("mgda_norm_type", "none")
+        return lambda G, losses=None: ((1.0 - beta) * np.asarray(mgda_weights(G, nt, losses, kw.get("epsilon", 1e-5), kw.get("max_iters", 250)),
+                                                                  dtype=np.float64) + beta * upgrad_weights(G))
     if n == "mean":
         return lambda G, losses=None: np.full(len(G), 1.0 / len(G))
     if n == "jd_sum":

@@ -207,6 +207,37 @@ def weightings_fixture():
     print("weightings.npz", len(out))
 
 
+def agg_variants_fixture():
+    """In-tree pieces of NUPGrad / PNUPGrad / COMFORT: the two Gramian normalisations, the
+    regulariser and COMFORT's beta schedule.  Their QP (torchjd `project_weights`) and torchjd's UPGrad are
+    third-party and absent, so the aggregators as a whole stay "parity unpinned" like UPGrad."""
+    from utils.torchmoo import nupgrad as NU
+    from utils.torchmoo import pnupgrad as PN
+    from utils.torchmoo.comfort import beta_schedule
+
+    fx = np.load(os.path.join(HERE, "weightings.npz"))
+    out = {}
+    names = sorted({k.split(".")[0] for k in fx.files if k.endswith(".G")})
+    out["cases"] = np.array(names)
+    for name in names:
+        G = torch.from_numpy(fx[f"{name}.G"])
+        for eps in (1e-4, 1e-2):
+            out[f"{name}.min_l2.{eps}"] = _np(NU.normalize_by_min_l2_norm(G, eps))
+            out[f"{name}.min_l2_p.{eps}"] = _np(PN.normalize_by_min_l2_norm(G, eps))
+            out[f"{name}.cosine.{eps}"] = _np(PN.normalize(G, eps))
+            out[f"{name}.reg.{eps}"] = _np(NU.regularize(NU.normalize_by_min_l2_norm(G, eps), eps))
+    zero = torch.zeros(3, 3)
+    out["zero.min_l2"] = _np(NU.normalize_by_min_l2_norm(zero, 1e-4))
+    grid = []
+    for total in (1, 2, 10, 50):
+        for epoch in (1, 2, 5, 10, 50, 60):
+            for (k, a, l, u) in ((1.0, 1.0, 0.01, 1.0), (0.0, 1.0, 0.1, 0.9), (5.0, 2.0, 0.0, 1.0), (-1.0, 0.5, 0.2, 0.7)):
+                grid.append((epoch, total, k, a, l, u, beta_schedule(epoch, total, k=k, a=a, l=l, u=u)))
+    out["beta_schedule"] = np.array(grid, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "agg_variants.npz"), **out)
+    print("agg_variants.npz", len(out))
+
+
 def _model_fixture(tag, arch, seed, B, input_size, args_kw, objective="mse"):
     from models import get_network
     from models.betatc_vae import BetaTCVAE
@@ -354,12 +385,17 @@ def full_fixture():
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
+    ap.add_argument("--only-agg-variants", action="store_true", help="regenerate agg_variants.npz only")
     a = ap.parse_args()
     _install_placeholders()
     sys.path.insert(0, REF)
     torch.set_num_threads(8)
+    if a.only_agg_variants:
+        agg_variants_fixture()
+        sys.exit(0)
     objectives_fixture()
     weightings_fixture()
+    agg_variants_fixture()
     model_fixtures()
     if a.full:
         full_fixture()

@@ -123,6 +123,14 @@ def test_aggregator_factory_names(pkg):
         assert mk(n).mgda_weighting.norm_type == nt
     for n, sm in [("aligned_mtl", "min"), ("amtl", "min"), ("aligned_mtl_median", "median"), ("aligned_mtl_rmse", "rmse")]:
         assert mk(n)._scale_mode == sm
+    assert isinstance(mk("nupgrad"), A.NUPGrad) and mk("nupgrad").gramian_weighting.norm == "min_l2"
+    assert isinstance(mk("pnupgrad"), A.PNUPGrad) and mk("pnupgrad").gramian_weighting.prob == 0.5
+    c = mk("comfort")
+    assert isinstance(c, A.COMFORT) and c.weighting is c._mgda.weighting and c._get_beta() == 1.0  # total_epochs <= 1 -> u
+    c.set_epoch(1, 10)
+    assert abs(c._get_beta() - 0.01) < 1e-12
+    c.set_epoch(10, 10)
+    assert abs(c._get_beta() - 1.0) < 1e-12
     with pytest.raises(NotImplementedError):
         mk("pcgrad")
     with pytest.raises(ValueError):

@@ -365,6 +365,52 @@ def test_upgrad_weights_vs_oracle(M, case):
     np.testing.assert_allclose(w.cpu().numpy(), OA.upgrad_weights(G), rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("norm", ["min_l2", "cosine"])
+def test_nupgrad_pnupgrad_weights_vs_oracle(M, case, norm):
+    """NUPGrad / both PNUPGrad branches (movae_weights_upgrad_norm) vs the oracle, whose normalisations are
+    pinned by tests/golden/agg_variants.npz."""
+    _, agg = M
+    from oracle import aggregation as OA
+
+    G = load_golden("weightings")[f"{case}.G"]
+    w = agg.UPGradWeighting(norm=norm)(torch.from_numpy(G).cuda())
+    want = OA.upgrad_weights(G, norm=norm)
+    np.testing.assert_allclose(w.cpu().numpy(), want, rtol=2e-4, atol=1e-6 * max(1.0, np.abs(want).max()))
+
+
+def test_nupgrad_pnupgrad_comfort_aggregators(M):
+    _, agg = M
+    from oracle import aggregation as OA
+
+    fx = load_golden("weightings")
+    J = torch.from_numpy(fx["k4_conflict.J"])
+    G = fx["k4_conflict.G"]
+    g = agg.NUPGrad()(J.cuda())
+    close(g, torch.as_tensor(OA.upgrad_weights(G, norm="min_l2"), dtype=torch.float32) @ J, "nupgrad", rtol=2e-4)
+    # PNUPGrad draws torch's CPU generator exactly like the reference: seed -> same branch sequence
+    P = agg.PNUPGrad(prob=0.5)
+    torch.manual_seed(123)
+    coins = [torch.rand(1).item() < 0.5 for _ in range(6)]
+    torch.manual_seed(123)
+    for c in coins:
+        want = torch.as_tensor(OA.upgrad_weights(G, norm="cosine" if c else "min_l2"), dtype=torch.float32) @ J
+        close(P(J.cuda()), want, "pnupgrad", rtol=2e-4)
+    assert any(coins) and not all(coins)
+    # COMFORT = (1 - beta) MGDA + beta UPGrad, beta from the epoch schedule; hooks see the MGDA weighting
+    C = agg.COMFORT(mgda_norm_type="l2")
+    seen = {}
+    C.weighting.register_forward_hook(lambda m, i, o: seen.update(w=o.clone()))
+    for epoch, total in [(1, 10), (4, 10), (10, 10)]:
+        C.set_epoch(epoch, total)
+        beta = OA.beta_schedule(epoch, total)
+        w = (1 - beta) * np.asarray(OA.mgda_weights(G, "l2"), dtype=np.float64) + beta * OA.upgrad_weights(G)
+        close(C(J.cuda()), torch.as_tensor(w, dtype=torch.float32) @ J, f"comfort epoch {epoch}", rtol=5e-4)
+        np.testing.assert_allclose(seen["w"].cpu().numpy(), OA.mgda_weights(G, "l2"), rtol=2e-4, atol=2e-6)
+    with pytest.raises(NotImplementedError):
+        agg.COMFORT(mgda_stable=True)
+
+
 def test_aggregator_docstring_kats(M):
     """utils/torchmoo/mgda.py:54-86 and nupgrad.py:58-62."""
     _, agg = M

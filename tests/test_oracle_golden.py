@@ -113,6 +113,43 @@ def test_upgrad_against_scipy(case):
     np.testing.assert_allclose(A.upgrad_weights(fx[f"{case}.G"]), total, rtol=2e-4, atol=2e-5)
 
 
+def test_nupgrad_pnupgrad_normalisations_and_comfort_schedule_match_reference_code():
+    """the in-tree pieces of NUPGrad / PNUPGrad / COMFORT against vectors generated from
+    utils/torchmoo/{nupgrad,pnupgrad,comfort}.py (tests/golden/agg_variants.npz).  The projection itself is torchjd's."""
+    fx, wx = load_golden("agg_variants"), load_golden("weightings")
+    for name in fx["cases"]:
+        G = wx[f"{name}.G"]
+        for eps in (1e-4, 1e-2):
+            np.testing.assert_allclose(A.normalize_min_l2(G, eps), fx[f"{name}.min_l2.{eps}"], rtol=1e-6, atol=1e-7)
+            np.testing.assert_array_equal(fx[f"{name}.min_l2.{eps}"], fx[f"{name}.min_l2_p.{eps}"])  # the two in-tree copies agree
+            np.testing.assert_allclose(A.normalize_cosine(G, eps), fx[f"{name}.cosine.{eps}"], rtol=1e-6, atol=1e-7)
+            np.testing.assert_allclose(A.normalize_min_l2(G, eps) + eps * np.eye(len(G), dtype=np.float32), fx[f"{name}.reg.{eps}"],
+                                       rtol=1e-6, atol=1e-7)
+    assert not A.normalize_min_l2(np.zeros((3, 3), np.float32), 1e-4).any() and not fx["zero.min_l2"].any()
+    for e, t, k, a, l, u, b in fx["beta_schedule"]:
+        assert abs(A.beta_schedule(int(e), int(t), k, a, l, u) - b) < 1e-12
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("norm", ["min_l2", "cosine"])
+def test_nupgrad_projection_against_scipy(case, norm):
+    """Independent check of the projection on the NUPGrad / PNUPGrad Gramians with a generic constrained solver."""
+    from scipy.optimize import minimize
+
+    fx = load_golden("weightings")
+    G = fx[f"{case}.G"]
+    K = len(G)
+    Gn = (A.normalize_min_l2(G, 1e-4) if norm == "min_l2" else A.normalize_cosine(G, 1e-4)).astype(np.float64) + 1e-4 * np.eye(K)
+    total = np.zeros(K)
+    for i in range(K):
+        u = np.zeros(K)
+        u[i] = 1.0 / K
+        r = minimize(lambda w: 0.5 * w @ Gn @ w, u + 0.1, jac=lambda w: Gn @ w, method="SLSQP",
+                     bounds=[(u[j], None) for j in range(K)], options=dict(ftol=1e-15, maxiter=500))
+        total += r.x
+    np.testing.assert_allclose(A.upgrad_weights(G, norm=norm), total, rtol=5e-4, atol=5e-5)
+
+
 # ---------------------------------------------------------------- models
 def _trainer(fx, agg="sum"):
     m = meta_of(fx)
