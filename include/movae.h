@@ -193,6 +193,11 @@ int movae_adam_step(float* p, const float* g, float* m, float* v, size_t n, floa
 int movae_adam_multi(int n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v,
                      const size_t* numel, float lr, float beta1, float beta2, float eps, float weight_decay,
                      int decoupled_wd, int step, float* hyper_dev, movae_stream_t stream);
+/* torch.nn.utils.clip_grad_norm_(parameters, max_norm) (main.py:211-212) over a LIST of gradient tensors in three
+ * launches per 64 tensors: total_sumsq_dev[0] receives the squared total L2 norm (its sqrt is the value torch
+ * returns), every gradient is scaled in place by min(max_norm / (norm + 1e-6), 1).  g / numel are HOST arrays. */
+int movae_clip_grad_norm_multi(int n_tensors, float* const* g, const size_t* numel, float max_norm, float* total_sumsq_dev,
+                               void* ws, size_t ws_bytes, movae_stream_t stream);
 /* sumsq of a flat arena into out[0] (clip_grad_norm_, main.py:211-212) */
 int movae_sumsq(const float* x, size_t n, float* out, void* ws, size_t ws_bytes, movae_stream_t stream);
 int movae_scale_by_clip(float* g, size_t n, const float* sumsq_dev, float max_norm, movae_stream_t stream);

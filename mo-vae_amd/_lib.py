@@ -69,6 +69,7 @@ SIGNATURES = {
     "movae_gd_similarity": ([_p, _z, _i, _z, _p, _p, _p, _z, _p], _i),
     "movae_adam_step": ([_p, _p, _p, _p, _z, _f, _f, _f, _f, _f, _i, _i, _p], _i),
     "movae_adam_multi": ([_i, _p, _p, _p, _p, _p, _f, _f, _f, _f, _f, _i, _i, _p, _p], _i),
+    "movae_clip_grad_norm_multi": ([_i, _p, _p, _f, _p, _p, _z, _p], _i),
     "movae_sumsq": ([_p, _z, _p, _p, _z, _p], _i),
     "movae_scale_by_clip": ([_p, _z, _p, _f, _p], _i),
     "movae_bench_main_kernel_only": ([_i], _i),

@@ -121,6 +121,41 @@ __global__ void clip_scale_k(float* __restrict__ g, long n, const float* __restr
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] *= coef;
 }
 
+// ---- clip_grad_norm_ over a tensor list: 3 launches (partials, final, scale) whatever the list length ------------------
+struct ClipTable {
+    float* g[ADAM_MT];
+    unsigned n[ADAM_MT];
+};
+
+// grid = (blocks per tensor, tensors); part[tensor * gridDim.x + block] = sum of squares of that block's slice (fp64)
+__global__ __launch_bounds__(256) void sumsq_multi_k(ClipTable tab, double* __restrict__ part) {
+    __shared__ double sh[4];
+    const float* __restrict__ g = tab.g[blockIdx.y];
+    const unsigned n = tab.n[blockIdx.y];
+    double s = 0.0;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) s += (double)g[i] * g[i];
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) part[blockIdx.y * gridDim.x + blockIdx.x] = s;
+}
+
+// sumsq_acc (+)= sum of the partials; then, once every chunk of the list has been added, norm = sqrt
+__global__ __launch_bounds__(256) void sumsq_multi_final(const double* __restrict__ part, int nparts, float* __restrict__ sumsq,
+                                                         int accumulate) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) sumsq[0] = accumulate ? sumsq[0] + (float)s : (float)s;
+}
+
+__global__ __launch_bounds__(256) void clip_multi_k(ClipTable tab, const float* __restrict__ sumsq, float max_norm) {
+    const float coef = fminf(max_norm / (sqrtf(sumsq[0]) + 1e-6f), 1.f);  // torch.nn.utils.clip_grad_norm_
+    if (coef >= 1.f) return;                                                // torch multiplies by 1.0: same values
+    float* __restrict__ g = tab.g[blockIdx.y];
+    const unsigned n = tab.n[blockIdx.y];
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) g[i] *= coef;
+}
+
 inline int blocks_for(size_t n) {
     size_t b = (n + 1023) / 1024;
     return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
@@ -171,6 +206,36 @@ int movae_adam_multi(int n_tensors, float* const* p, const float* const* g, floa
                            eps, weight_decay, decoupled_wd, bc1, bc2_sqrt, (const float*)hyper_dev);
         MOVAE_CHECK_LAUNCH("adam_multi");
     }
+    return MOVAE_OK;
+}
+
+int movae_clip_grad_norm_multi(int n_tensors, float* const* g, const size_t* numel, float max_norm, float* total_sumsq_dev, void* ws,
+                               size_t ws_bytes, movae_stream_t stream) {
+    MOVAE_WS_SCRATCH(ws, ws_bytes);
+    MOVAE_CHECK_ARG(n_tensors >= 1 && g && numel && total_sumsq_dev && max_norm > 0.f, "movae_clip_grad_norm_multi: bad argument");
+    constexpr int BX = 32;  // blocks per tensor
+    MOVAE_CHECK_ARG(ws && ws_bytes >= (size_t)ADAM_MT * BX * sizeof(double), "movae_clip_grad_norm_multi: workspace too small");
+    double* part = static_cast<double*>(ws);
+    hipStream_t st = (hipStream_t)stream;
+    for (int pass = 0; pass < 2; ++pass)  // pass 0: total norm over all chunks; pass 1: scale
+        for (int t0 = 0; t0 < n_tensors; t0 += ADAM_MT) {
+            ClipTable tab;
+            const int cnt = n_tensors - t0 < ADAM_MT ? n_tensors - t0 : ADAM_MT;
+            for (int i = 0; i < ADAM_MT; ++i) {
+                tab.g[i] = i < cnt ? g[t0 + i] : nullptr;
+                tab.n[i] = i < cnt ? (unsigned)numel[t0 + i] : 0;
+                if (i < cnt) MOVAE_CHECK_ARG(g[t0 + i] && numel[t0 + i] < 0xffffffffUL, "movae_clip_grad_norm_multi: bad tensor");
+            }
+            if (pass == 0) {
+                hipLaunchKernelGGL(sumsq_multi_k, dim3(BX, cnt), dim3(256), 0, st, tab, part);
+                MOVAE_CHECK_LAUNCH("sumsq_multi");
+                hipLaunchKernelGGL(sumsq_multi_final, dim3(1), dim3(256), 0, st, part, BX * cnt, total_sumsq_dev, t0 > 0 ? 1 : 0);
+                MOVAE_CHECK_LAUNCH("sumsq_multi_final");
+            } else {
+                hipLaunchKernelGGL(clip_multi_k, dim3(BX, cnt), dim3(256), 0, st, tab, total_sumsq_dev, max_norm);
+                MOVAE_CHECK_LAUNCH("clip_multi");
+            }
+        }
     return MOVAE_OK;
 }
 

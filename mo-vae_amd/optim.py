@@ -122,3 +122,28 @@ class FusedAdamW(FusedAdam):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, device_step=False):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, decoupled_weight_decay=True,
                          device_step=device_step)
+
+
+def clip_grad_norm_(parameters, max_norm, norm_type=2.0):
+    """torch.nn.utils.clip_grad_norm_(parameters, max_norm) as called at main.py:211-212, in three launches for the
+    whole parameter list and without a host sync (so it can sit inside a captured hipGraph).  Returns the total norm
+    as a 0-dim device tensor, like torch."""
+    if float(norm_type) != 2.0:
+        raise NotImplementedError("clip_grad_norm_: only the L2 norm of the reference's call is implemented")
+    if isinstance(parameters, torch.Tensor):
+        parameters = [parameters]
+    grads = [p.grad for p in parameters if p.grad is not None]
+    if not grads:
+        return torch.tensor(0.0)
+    for g in grads:
+        L.require_gpu(g)
+        if g.dtype != torch.float32 or not _dense(g):
+            raise NotImplementedError("clip_grad_norm_: gradients must be dense fp32 tensors")
+    dev = grads[0].device
+    n = len(grads)
+    sumsq = torch.empty((), dtype=torch.float32, device=dev)
+    ws = L.workspace(dev)
+    L.call("movae_clip_grad_norm_multi", n, (C.c_void_p * n)(*[g.data_ptr() for g in grads]),
+           (C.c_size_t * n)(*[g.numel() for g in grads]), float(max_norm), sumsq.data_ptr(), ws.data_ptr(), ws.numel(),
+           L.stream_ptr(dev))
+    return sumsq.sqrt()

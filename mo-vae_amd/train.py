@@ -20,7 +20,7 @@ from . import aggregation
 from . import autojac
 from .aggregation import COMFORT, MGDA
 from .models import get_network
-from .optim import FusedAdam, FusedAdamW
+from .optim import FusedAdam, FusedAdamW, clip_grad_norm_
 from .parallel import DataParallelGrads
 
 _current_step = 0
@@ -89,7 +89,7 @@ def train_step(net, images, optimizer, aggregator, args, dp=None):
     if dp is not None:
         dp.all_reduce_grads()
     if getattr(args, "max_grad_norm", None) is not None:
-        torch.nn.utils.clip_grad_norm_(net.parameters(), max_norm=args.max_grad_norm)
+        clip_grad_norm_(net.parameters(), max_norm=args.max_grad_norm)  # optim.py: 3 launches, no host sync
     optimizer.step()
     return loss_dict, outputs
 
@@ -112,8 +112,6 @@ class GraphedTrainStep:
         if type(net).__name__ not in GRAPH_SAFE_ARCHS:
             raise NotImplementedError(f"{type(net).__name__}: forward syncs with the host (codebook usage / anneal counter); "
                                       "use the eager train_step")
-        if getattr(args, "max_grad_norm", None) is not None:
-            raise NotImplementedError("clip_grad_norm_ reads the norm on the host; use the eager train_step")
         self.net, self.opt, self.agg, self.args, self.dp = net, optimizer, aggregator, args, dp
         self.static_x = example.clone()
         from . import _lib as L

@@ -520,6 +520,32 @@ def test_fused_adam_matches_torch_adam(M, mode):
         close(b, a, f"{mode} after reload, param {i}", rtol=2e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("max_norm", [0.5, 1e6])
+def test_fused_clip_grad_norm_matches_torch(M, max_norm):
+    """optim.clip_grad_norm_ (movae_clip_grad_norm_multi: 3 launches for the whole list, no host sync) vs
+    torch.nn.utils.clip_grad_norm_ (main.py:211-212): clipping and the no-op case, 70 tensors (two kernel-argument
+    chunks), a channels_last gradient, a parameter without gradient."""
+    from movae_amd.optim import clip_grad_norm_
+
+    shapes = [(5,), (16, 8, 3, 3), (1,), (1000,)] + [(i + 2, 3) for i in range(66)]
+    ref = [torch.nn.Parameter(rnd(*s, seed=20 + i)) for i, s in enumerate(shapes)]
+    gpu = [torch.nn.Parameter(t.detach().clone().cuda()) for t in ref]
+    for i, (a, b) in enumerate(zip(ref, gpu)):
+        if i == 2:
+            continue  # no gradient
+        g = rnd(*shapes[i], seed=300 + i) * 0.3
+        if i == 1:
+            g = g.contiguous(memory_format=torch.channels_last)
+        a.grad, b.grad = g.clone(), g.cuda()
+    want = torch.nn.utils.clip_grad_norm_(ref, max_norm)
+    got = clip_grad_norm_(gpu, max_norm)
+    np.testing.assert_allclose(got.item(), want.item(), rtol=1e-6)
+    for i, (a, b) in enumerate(zip(ref, gpu)):
+        if i != 2:
+            close(b.grad, a.grad, f"clipped grad {i}", rtol=1e-6, atol=1e-7)
+    assert gpu[2].grad is None
+
+
 def test_invalid_arguments_raise(M):
     ops, agg = M
     with pytest.raises(RuntimeError):
