@@ -145,6 +145,25 @@ int movae_tc_decomp_bwd(const float* z, const float* mu, const float* log_var, c
                         const float* lse_joint, const float* lse_marg, const float* g,
                         float* dz, float* dmu, float* dlog_var, int b, int d, movae_stream_t stream);
 
+/* ---- Sobel edge losses of the gradient-guided VAE --------------------------------------------
+ * models/gg_vae.py:42-53 (depthwise Sobel x / y, zero padding 1), EPS = 1e-8 (gg_vae.py:8); images NHWC [n][h][w][c].
+ * edge weights (gg_vae.py:125-132): w_raw[n*h*w] = max_c sqrt(gx^2 + gy^2 + EPS) of `inputs`, wmax[0] = global max;
+ * edge-weighted pixel loss (gg_vae.py:134-137): out = scale * mean( w_raw / (wmax + EPS) * (recons - inputs)^2 );
+ * edge matching loss v1 (gg_vae.py:139-156): out = scale * smooth_l1( |sobel recons|, |sobel inputs| ), mean reduction.
+ * The backward passes take the upstream gradient as a device scalar (gscale_dev, may be NULL = 1). */
+int movae_edge_weights(const float* inputs, float* w_raw, float* wmax, int n, int h, int w, int c,
+                       void* ws, size_t ws_bytes, movae_stream_t stream);
+int movae_edge_weighted_mse_fwd(const float* recons, const float* inputs, const float* w_raw, const float* wmax, float* out,
+                                int n, int h, int w, int c, float scale, void* ws, size_t ws_bytes, movae_stream_t stream);
+int movae_edge_weighted_mse_bwd(const float* recons, const float* inputs, const float* w_raw, const float* wmax,
+                                const float* gscale_dev, float* drecons, int n, int h, int w, int c, float scale,
+                                movae_stream_t stream);
+int movae_edge_match_fwd(const float* recons, const float* inputs, float* out, int n, int h, int w, int c, float scale,
+                         void* ws, size_t ws_bytes, movae_stream_t stream);
+/* tmp_a / tmp_b: two scratch tensors of the images' size (d loss / d Sobel-x and -y responses) */
+int movae_edge_match_bwd(const float* recons, const float* inputs, const float* gscale_dev, float* drecons, float* tmp_a,
+                         float* tmp_b, int n, int h, int w, int c, float scale, movae_stream_t stream);
+
 /* ---- vector quantiser ------------------------------------------------------------------------------
  * models/vq_vae.py:27-64: nearest code under ||x||^2 + ||e||^2 - 2 x.e (first index on ties), gather, and
  * sse[0] = sum (q - x)^2 (commitment and embedding losses are both sse/numel).  x,q: [rows][d], e: [k][d]. */

@@ -56,6 +56,11 @@ SIGNATURES = {
     "movae_kl_bwd": ([_p, _p, _p, _p, _p, _i, _i, _f, _p], _i),
     "movae_tc_decomp_fwd": ([_p] * 7 + [_i, _i, _p, _z, _p], _i),
     "movae_tc_decomp_bwd": ([_p] * 10 + [_i, _i, _p], _i),
+    "movae_edge_weights": ([_p, _p, _p, _i, _i, _i, _i, _p, _z, _p], _i),
+    "movae_edge_weighted_mse_fwd": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _z, _p], _i),
+    "movae_edge_weighted_mse_bwd": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p], _i),
+    "movae_edge_match_fwd": ([_p, _p, _p, _i, _i, _i, _i, _f, _p, _z, _p], _i),
+    "movae_edge_match_bwd": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p], _i),
     "movae_vq_nearest_fwd": ([_p] * 6 + [_i, _i, _i, _p, _z, _p], _i),
     "movae_vq_bwd": ([_p] * 8 + [_i, _i, _i, _p], _i),
     "movae_gram_ws_bytes": ([_i, _z], _z),

@@ -1,12 +1,13 @@
 """Model factory -- drop-in for the reference's models/__init__.py:18-211 for the four hot-path
-architectures (vae, vq_vae, vq_vae2, betatc_vae / btc_vae)."""
+architectures (vae, vq_vae, vq_vae2, betatc_vae / btc_vae) and the SURVEY 8f.3 widening gg_vae."""
 from .betatc_vae import BetaTCVAE
+from .gg_vae import GGVAE
 from .vae import VAE
 from .vq_vae import VQVAE, VectorQuantizer
 from .vq_vae2 import VQVAE2
 
 OUT_OF_SCOPE_ARCHS = {
-    "gg_vae", "gg_vae_v2", "gg_vae_v3", "gg_vae_v5", "gg_vae_v6", "recursive_kl_vae", "cycle_vae", "recursive_cyclic_vae",
+    "gg_vae_v2", "gg_vae_v3", "gg_vae_v5", "gg_vae_v6", "recursive_kl_vae", "cycle_vae", "recursive_cyclic_vae",
     "rc_vae", "sphere_encoder", "sphere_encoder_vit", "gg_vq_vae", "gg_vq_vae_v1", "gg_vq_vae_v2", "gg_vq_vae_v3",
     "gg_vq_vae_v4", "gg_vq_vae_v5", "gg_vq_vae_v6", "gg_vq_vae_v7", "gg_vq_vae_v8", "gg_vq_vae2",
 }
@@ -42,6 +43,13 @@ def get_network(input_size, num_channels=3, args=None, device=None):
         else:
             lambda_weights = [lambda_weights[0], ratio]
         return VAE(latent_dim=latent_dim, hidden_dims=hidden_dims, lambda_weights=lambda_weights, **common)
+    if arch == "gg_vae":  # models/__init__.py:147-154 (edge_matching_version=1)
+        ratio = args.batch_size / args.dataset_size
+        if lambda_weights is None:
+            lambda_weights = {"reconstruction_loss": 1.0, "kld_loss": ratio, "gradient_guided_loss": 1.0, "edge_matching_loss": 1.0}
+        elif isinstance(lambda_weights, dict):
+            lambda_weights = dict(lambda_weights, kld_loss=ratio)
+        return GGVAE(latent_dim=latent_dim, hidden_dims=hidden_dims, lambda_weights=lambda_weights, edge_matching_version=1, **common)
     if arch == "vq_vae":
         if lambda_weights is None:
             lambda_weights = {"reconstruction_loss": 1.0, "embedding_loss": 1.0, "commitment_loss": 0.25}

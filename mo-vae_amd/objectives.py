@@ -27,6 +27,18 @@ laplacian_per_pixel_mean = _make("l1")       # utils/objectives.py:129-131
 smooth_l1_per_pixel_mean = _make("smooth_l1")  # utils/objectives.py:134-136
 
 
+def edge_weighted_pixel_loss(inputs, recons, scale=1.0):
+    """models/gg_vae.py:125-137 (GGVAE.edge_weighted_pixel_loss)."""
+    x, r = _pair(inputs, recons)
+    return ops.edge_weighted_pixel_loss(r, x, scale)
+
+
+def edge_matching_loss(inputs, recons, scale=1.0):
+    """models/gg_vae.py:139-156 (GGVAE.edge_matching_loss, version 1)."""
+    x, r = _pair(inputs, recons)
+    return ops.edge_matching_loss(r, x, scale)
+
+
 def kl_divergence(mu, log_var, scale=1.0):
     """utils/objectives.py:141-144."""
     return ops.kl_divergence(mu, log_var, scale)

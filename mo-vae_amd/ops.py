@@ -504,6 +504,75 @@ class ReconLoss(Function):
         return dr, None, None, None
 
 
+class EdgeWeightedPixelLoss(Function):
+    """models/gg_vae.py:125-137: scale * mean(w * (recons - inputs)^2), w = Sobel magnitude of `inputs` (max over channels,
+    normalised by the batch maximum).  NHWC operands; no gradient flows into `inputs`."""
+
+    @staticmethod
+    def forward(ctx, recons, inputs, scale):
+        L.require_gpu(recons)
+        recons, inputs = _c(recons), _c(inputs)
+        assert recons.shape == inputs.shape and recons.dim() == 4, (recons.shape, inputs.shape)
+        n, h, w, c = recons.shape
+        w_raw = torch.empty((n, h, w), dtype=recons.dtype, device=recons.device)
+        wmax = torch.empty((), dtype=recons.dtype, device=recons.device)
+        out = torch.empty((), dtype=recons.dtype, device=recons.device)
+        wsp, wsb = _ws(recons)
+        st = _st(recons)
+        _call("movae_edge_weights", inputs.data_ptr(), w_raw.data_ptr(), wmax.data_ptr(), n, h, w, c, wsp, wsb, st)
+        _call("movae_edge_weighted_mse_fwd", recons.data_ptr(), inputs.data_ptr(), w_raw.data_ptr(), wmax.data_ptr(), out.data_ptr(),
+              n, h, w, c, float(scale), wsp, wsb, st)
+        ctx.scale = scale
+        ctx.save_for_backward(recons, inputs, w_raw, wmax)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        recons, inputs, w_raw, wmax = ctx.saved_tensors
+        g = _c(g)
+        n, h, w, c = recons.shape
+        dr = torch.empty_like(recons)
+        _call("movae_edge_weighted_mse_bwd", recons.data_ptr(), inputs.data_ptr(), w_raw.data_ptr(), wmax.data_ptr(), g.data_ptr(),
+              dr.data_ptr(), n, h, w, c, float(ctx.scale), _st(recons))
+        return dr, None, None
+
+
+class EdgeMatchingLoss(Function):
+    """models/gg_vae.py:139-156 (edge_matching_version 1): scale * smooth_l1(|sobel recons|, |sobel inputs|).  NHWC."""
+
+    @staticmethod
+    def forward(ctx, recons, inputs, scale):
+        L.require_gpu(recons)
+        recons, inputs = _c(recons), _c(inputs)
+        assert recons.shape == inputs.shape and recons.dim() == 4, (recons.shape, inputs.shape)
+        n, h, w, c = recons.shape
+        out = torch.empty((), dtype=recons.dtype, device=recons.device)
+        wsp, wsb = _ws(recons)
+        _call("movae_edge_match_fwd", recons.data_ptr(), inputs.data_ptr(), out.data_ptr(), n, h, w, c, float(scale), wsp, wsb,
+              _st(recons))
+        ctx.scale = scale
+        ctx.save_for_backward(recons, inputs)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        recons, inputs = ctx.saved_tensors
+        g = _c(g)
+        n, h, w, c = recons.shape
+        dr, ta, tb = torch.empty_like(recons), torch.empty_like(recons), torch.empty_like(recons)
+        _call("movae_edge_match_bwd", recons.data_ptr(), inputs.data_ptr(), g.data_ptr(), dr.data_ptr(), ta.data_ptr(), tb.data_ptr(),
+              n, h, w, c, float(ctx.scale), _st(recons))
+        return dr, None, None
+
+
+def edge_weighted_pixel_loss(recons, inputs, scale=1.0):
+    return EdgeWeightedPixelLoss.apply(recons, inputs, scale)
+
+
+def edge_matching_loss(recons, inputs, scale=1.0):
+    return EdgeMatchingLoss.apply(recons, inputs, scale)
+
+
 def recon_loss(recons, inputs, kind, scale=1.0):
     return ReconLoss.apply(recons, inputs, kind, scale)
 

@@ -94,7 +94,7 @@ def train_step(net, images, optimizer, aggregator, args, dp=None):
     return loss_dict, outputs
 
 
-GRAPH_SAFE_ARCHS = {"VAE"}  # forward/loss free of host syncs and of Python-side per-step scalars
+GRAPH_SAFE_ARCHS = {"VAE", "GGVAE"}  # forward/loss free of host syncs and of Python-side per-step scalars
 
 
 class GraphedTrainStep:

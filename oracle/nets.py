@@ -60,7 +60,7 @@ BUFFER_SUFFIXES = (".running_mean", ".running_var", ".num_batches_tracked")
 
 
 def is_buffer(key):
-    return key.endswith(BUFFER_SUFFIXES)
+    return key.endswith(BUFFER_SUFFIXES) or key in ("sobel_x", "sobel_y")
 
 
 def parameter_names(sd, arch=None):
@@ -157,6 +157,56 @@ def losses_vae(x, out, cfg):
     r = lw["reconstruction_loss"] * fn(x, out["recons"])
     k = lw["kld_loss"] * O.kl_divergence(out["mu"], out["log_var"])
     return OrderedDict(reconstruction_loss=r, kld_loss=k, total_loss=r + k)
+
+
+# ---------------------------------------------------------------------------------------
+# Gradient-guided VAE (models/gg_vae.py) -- the VAE plus two Sobel edge losses
+# ---------------------------------------------------------------------------------------
+GG_EPS = 1e-8  # models/gg_vae.py:8
+
+
+def _sobel():
+    """models/gg_vae.py:44-53 -- (3,1,3,3) depthwise filters, registered as buffers BEFORE the sub-modules in state_dict order."""
+    sx = torch.tensor([[-1.0, 0.0, 1.0], [-2.0, 0.0, 2.0], [-1.0, 0.0, 1.0]])
+    sy = torch.tensor([[-1.0, -2.0, -1.0], [0.0, 0.0, 0.0], [1.0, 2.0, 1.0]])
+    return sx.expand(3, 1, 3, 3).clone(), sy.expand(3, 1, 3, 3).clone()
+
+
+def init_gg_vae(cfg):
+    sd = OrderedDict()
+    sd["sobel_x"], sd["sobel_y"] = _sobel()
+    sd.update(init_vae(cfg))  # the Sobel tensors draw nothing from the RNG
+    return sd
+
+
+def edge_weighted_pixel_loss(x, recons):
+    """models/gg_vae.py:125-137."""
+    sx, sy = _sobel()
+    gx = F.conv2d(x, sx, padding=1, groups=x.size(1))
+    gy = F.conv2d(x, sy, padding=1, groups=x.size(1))
+    w = torch.sqrt(gx ** 2 + gy ** 2 + GG_EPS).max(dim=1)[0]
+    w = w / (w.max() + GG_EPS)
+    return (w.unsqueeze(1) * F.mse_loss(recons, x, reduction="none")).mean()
+
+
+def edge_matching_loss(x, recons):
+    """models/gg_vae.py:139-156 (edge_matching_version 1)."""
+    sx, sy = _sobel()
+    g = x.size(1)
+    gp = torch.sqrt(F.conv2d(recons, sx, padding=1, groups=g) ** 2 + F.conv2d(recons, sy, padding=1, groups=g) ** 2 + GG_EPS)
+    gt = torch.sqrt(F.conv2d(x, sx, padding=1, groups=g) ** 2 + F.conv2d(x, sy, padding=1, groups=g) ** 2 + GG_EPS)
+    return F.smooth_l1_loss(gp, gt)
+
+
+def losses_gg_vae(x, out, cfg):
+    """models/gg_vae.py:222-251 -- order reconstruction, gradient_guided, edge_matching, kld."""
+    fn, _ = O.resolve_objective(cfg.get("recons_objective", "mse"), cfg.get("recons_activation"))
+    lw = cfg["lambda_weights"]
+    r = lw["reconstruction_loss"] * fn(x, out["recons"])
+    gg = lw["gradient_guided_loss"] * edge_weighted_pixel_loss(x, out["recons"])
+    em = lw["edge_matching_loss"] * edge_matching_loss(x, out["recons"])
+    k = lw["kld_loss"] * O.kl_divergence(out["mu"], out["log_var"])
+    return OrderedDict(reconstruction_loss=r, gradient_guided_loss=gg, edge_matching_loss=em, kld_loss=k, total_loss=r + gg + em + k)
 
 
 # ---------------------------------------------------------------------------------------
@@ -516,6 +566,8 @@ def losses_betatc_vae(x, out, cfg, train=True):
 ARCHS = {
     "vae": dict(init=init_vae, forward=forward_vae, losses=losses_vae, features=["mu", "log_var"],
                 needs_eps=True, eps_dim="latent_dim"),
+    "gg_vae": dict(init=init_gg_vae, forward=forward_vae, losses=losses_gg_vae, features=["mu", "log_var"],
+                   needs_eps=True, eps_dim="latent_dim"),
     "vq_vae": dict(init=init_vq_vae, forward=forward_vq_vae, losses=losses_vq_vae, features=["encoding"],
                    needs_eps=False),
     "vq_vae2": dict(init=init_vq_vae2, forward=forward_vq_vae2, losses=losses_vq_vae2,
@@ -529,6 +581,7 @@ def default_lambda_weights(arch, batch_size, dataset_size):
     r = batch_size / dataset_size
     return {
         "vae": {"reconstruction_loss": 1.0, "kld_loss": r},
+        "gg_vae": {"reconstruction_loss": 1.0, "kld_loss": r, "gradient_guided_loss": 1.0, "edge_matching_loss": 1.0},
         "vq_vae": {"reconstruction_loss": 1.0, "embedding_loss": 1.0, "commitment_loss": 0.25},
         "vq_vae2": {"reconstruction_loss": 1.0, "commitment_loss": 1.0, "embedding_loss": 0.25},
         "betatc_vae": {"reconstruction_loss": 1.0, "mi_loss": 1.0, "tc_loss": 1.0, "kld": r},

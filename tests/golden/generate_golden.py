@@ -324,6 +324,12 @@ def model_fixtures():
                    dict(embedding_dim=8, num_embeddings=16, hidden_dims=[16, 32], num_residual_layers=2))
     _model_fixture("betatc_vae_tiny", "betatc_vae", 42, 5, 16,
                    dict(latent_dim=6, hidden_dims=[8, 16], anneal_steps=200), objective="mse")
+    gg_vae_fixture()
+
+
+def gg_vae_fixture():
+    """the gradient-guided VAE (models/gg_vae.py), edge matching version 1."""
+    _model_fixture("gg_vae_tiny", "gg_vae", 31, 4, 16, dict(latent_dim=8, hidden_dims=[8, 16]))
 
 
 # --------------------------------------------------------------------------------------
@@ -386,12 +392,16 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--only-agg-variants", action="store_true", help="regenerate agg_variants.npz only")
+    ap.add_argument("--only-gg-vae", action="store_true", help="regenerate gg_vae_tiny.npz only")
     a = ap.parse_args()
     _install_placeholders()
     sys.path.insert(0, REF)
     torch.set_num_threads(8)
     if a.only_agg_variants:
         agg_variants_fixture()
+        sys.exit(0)
+    if a.only_gg_vae:
+        gg_vae_fixture()
         sys.exit(0)
     objectives_fixture()
     weightings_fixture()

@@ -546,6 +546,29 @@ def test_fused_clip_grad_norm_matches_torch(M, max_norm):
     assert gpu[2].grad is None
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 7, 5), (3, 3, 16, 16), (1, 3, 1, 9), (2, 1, 4, 4)])
+def test_sobel_edge_losses(M, shape):
+    """csrc/edge.hip vs the oracle's restatement of models/gg_vae.py:125-156 (depthwise F.conv2d Sobel, max over channels,
+    batch-max normalisation, smooth-L1 on gradient magnitudes), forward and backward, ragged shapes."""
+    ops, _ = M
+    from oracle import nets as ON
+
+    n, c, h, w = shape
+    x, r = rnd(n, c, h, w, seed=31) * 0.5, rnd(n, c, h, w, seed=32) * 0.5
+    if c != 3:
+        pytest.skip("the reference's Sobel buffers are built for 3 channels (gg_vae.py:52-53)")
+    for name, fn, ofn in (("edge_weighted", ops.edge_weighted_pixel_loss, ON.edge_weighted_pixel_loss),
+                          ("edge_matching", ops.edge_matching_loss, ON.edge_matching_loss)):
+        rr = r.clone().requires_grad_(True)
+        want = 1.7 * ofn(x, rr)
+        want.backward()
+        rg = nhwc(r)
+        got = fn(rg, x.permute(0, 2, 3, 1).contiguous().cuda(), 1.7)
+        got.backward()
+        np.testing.assert_allclose(got.item(), want.item(), rtol=2e-5, atol=1e-7, err_msg=name)
+        close(back(rg.grad), rr.grad, name + " grad", rtol=2e-4, atol=2e-6)
+
+
 def test_invalid_arguments_raise(M):
     ops, agg = M
     with pytest.raises(RuntimeError):
