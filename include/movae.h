@@ -190,6 +190,10 @@ int movae_weights_upgrad_norm(const float* G, int k, int norm_mode, float norm_e
 /* MGDA Frank-Wolfe (utils/torchmoo/mgda.py:221-367); losses may be NULL for norm NONE/L2. info[0]=iterations */
 int movae_weights_mgda(const float* G, int k, int norm, const float* losses, float epsilon, int max_iters,
                        float* w, int32_t* info, movae_stream_t stream);
+/* StableMGDA (utils/torchmoo/mgda.py:139-153,286-317; COMFORT's --comfort_mgda_stable): the (normalised) Gramian's
+ * eigenvalues are clamped to >= min_eigenvalue and the matrix reconstructed before the Frank-Wolfe iteration. */
+int movae_weights_mgda_stable(const float* G, int k, int norm, const float* losses, float epsilon, int max_iters,
+                              float min_eigenvalue, float* w, int32_t* info, movae_stream_t stream);
 /* Aligned-MTL (utils/torchmoo/aligned_mtl.py:97-133) */
 int movae_weights_amtl(const float* G, int k, int scale_mode, const float* pref, float* w, movae_stream_t stream);
 /* constant weightings (torchjd Sum / Mean) */

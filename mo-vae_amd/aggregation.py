@@ -171,8 +171,6 @@ class MGDAWeighting(Weighting):
         if norm_type not in ("none", "l2", "loss", "loss+"):
             raise ValueError("Parameter `norm_type` should be 'none', 'l2', 'loss', or 'loss+'. Found "
                              f"`norm_type = {norm_type!r}`.")
-        if stable:
-            raise NotImplementedError("StableMGDA (eigen regularisation, --comfort_mgda_stable) is not implemented in this build")
         self.norm_type, self.epsilon, self.max_iters = norm_type, epsilon, max_iters
         self.stable, self.min_eigenvalue_eps = stable, min_eigenvalue_eps
         self._losses = None
@@ -200,9 +198,29 @@ class MGDAWeighting(Weighting):
             losses = self._losses.to(device=G.device, dtype=torch.float32).contiguous()
         w = torch.empty(k, dtype=torch.float32, device=G.device)
         self._info = torch.empty(1, dtype=torch.int32, device=G.device)
-        L.call("movae_weights_mgda", G.data_ptr(), k, L.MGDA_NORM[self.norm_type], L.ptr(losses), float(self.epsilon),
-                                            int(self.max_iters), w.data_ptr(), self._info.data_ptr(), _st(G))
+        if self.stable:  # StableMGDA: eigenvalues clamped from below before the Frank-Wolfe iteration (mgda.py:286-317)
+            L.call("movae_weights_mgda_stable", G.data_ptr(), k, L.MGDA_NORM[self.norm_type], L.ptr(losses), float(self.epsilon),
+                   int(self.max_iters), float(self.min_eigenvalue_eps), w.data_ptr(), self._info.data_ptr(), _st(G))
+        else:
+            L.call("movae_weights_mgda", G.data_ptr(), k, L.MGDA_NORM[self.norm_type], L.ptr(losses), float(self.epsilon),
+                   int(self.max_iters), w.data_ptr(), self._info.data_ptr(), _st(G))
         return w
+
+
+class StableMGDA(GramianWeightedAggregator):
+    """utils/torchmoo/mgda.py:139-153: MGDA with eigen regularisation always on."""
+
+    def __init__(self, norm_type="none", epsilon=1e-5, max_iters=250, min_eigenvalue_eps=1e-10):
+        w = MGDAWeighting(norm_type, epsilon, max_iters, True, min_eigenvalue_eps)
+        super().__init__(w)
+        self._mgda_weighting = w
+
+    @property
+    def mgda_weighting(self):
+        return self._mgda_weighting
+
+    def set_losses(self, losses):
+        self._mgda_weighting.set_losses(losses)
 
 
 class MGDA(GramianWeightedAggregator):

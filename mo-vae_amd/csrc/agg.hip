@@ -269,8 +269,41 @@ __global__ __launch_bounds__(64) void upgrad_k(const float* __restrict__ Gin, in
 }
 
 // ---- MGDA Frank-Wolfe (fp32, op order of utils/torchmoo/mgda.py:241-265) ------------------------------
+// cyclic Jacobi eigen-decomposition of a symmetric K x K matrix in fp64: on return A is (numerically) diagonal with the
+// eigenvalues and the columns of V are the eigenvectors (V must enter as the identity)
+__device__ void jacobi_eigh(double (&A)[MAXK][MAXK], double (&V)[MAXK][MAXK], int K) {
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int i = 0; i < K; ++i)
+            for (int j = 0; j < K; ++j) (i == j ? diag : off) += A[i][j] * A[i][j];
+        if (off <= 1e-30 * (diag + 1e-300)) break;
+        for (int p = 0; p < K - 1; ++p)
+            for (int q = p + 1; q < K; ++q) {
+                if (A[p][q] == 0.0) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / sqrt(tt * tt + 1.0), sn = tt * cs;
+                for (int k = 0; k < K; ++k) {
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = cs * akp - sn * akq;
+                    A[k][q] = sn * akp + cs * akq;
+                }
+                for (int k = 0; k < K; ++k) {
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = cs * apk - sn * aqk;
+                    A[q][k] = sn * apk + cs * aqk;
+                }
+                for (int k = 0; k < K; ++k) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = cs * vkp - sn * vkq;
+                    V[k][q] = sn * vkp + cs * vkq;
+                }
+            }
+    }
+}
+
 __global__ void mgda_k(const float* __restrict__ Gin, int K, int norm, const float* __restrict__ losses, float epsilon,
-                       int max_iters, float* __restrict__ wout, int* __restrict__ info) {
+                       int max_iters, float* __restrict__ wout, int* __restrict__ info, int stable, float min_eig) {
     if (threadIdx.x != 0) return;
     float G[MAXK][MAXK], nrm[MAXK], ls[MAXK];
     for (int i = 0; i < K; ++i) {
@@ -285,6 +318,21 @@ __global__ void mgda_k(const float* __restrict__ Gin, int K, int norm, const flo
             else if (norm == MOVAE_MGDA_LOSS_PLUS) d = (ls[i] * nrm[i]) * (ls[j] * nrm[j]);
             G[i][j] = Gin[i * K + j] / d;
         }
+    if (stable) {  // StableMGDA (utils/torchmoo/mgda.py:286-317): clamp the eigenvalues from below, reconstruct
+        double A[MAXK][MAXK], V[MAXK][MAXK];
+        for (int i = 0; i < K; ++i)
+            for (int j = 0; j < K; ++j) {
+                A[i][j] = (double)(i <= j ? G[i][j] : G[j][i]);  // eigh reads one triangle
+                V[i][j] = i == j ? 1.0 : 0.0;
+            }
+        jacobi_eigh(A, V, K);
+        for (int i = 0; i < K; ++i)
+            for (int j = 0; j < K; ++j) {
+                double sacc = 0.0;
+                for (int e = 0; e < K; ++e) sacc += V[i][e] * fmax(A[e][e], (double)min_eig) * V[j][e];
+                G[i][j] = (float)sacc;
+            }
+    }
     float alpha[MAXK], Ga[MAXK];
     for (int i = 0; i < K; ++i) alpha[i] = 1.f / K;
     int it = 0;
@@ -325,34 +373,7 @@ __global__ void amtl_k(const float* __restrict__ Gin, int K, int scale_mode, con
             A[i][j] = (double)(i <= j ? Gin[i * K + j] : Gin[j * K + i]);
             V[i][j] = i == j ? 1.0 : 0.0;
         }
-    for (int sweep = 0; sweep < 30; ++sweep) {
-        double off = 0.0, diag = 0.0;
-        for (int i = 0; i < K; ++i)
-            for (int j = 0; j < K; ++j) (i == j ? diag : off) += A[i][j] * A[i][j];
-        if (off <= 1e-30 * (diag + 1e-300)) break;
-        for (int p = 0; p < K - 1; ++p)
-            for (int q = p + 1; q < K; ++q) {
-                if (A[p][q] == 0.0) continue;
-                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
-                const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double cs = 1.0 / sqrt(tt * tt + 1.0), sn = tt * cs;
-                for (int k = 0; k < K; ++k) {
-                    const double akp = A[k][p], akq = A[k][q];
-                    A[k][p] = cs * akp - sn * akq;
-                    A[k][q] = sn * akp + cs * akq;
-                }
-                for (int k = 0; k < K; ++k) {
-                    const double apk = A[p][k], aqk = A[q][k];
-                    A[p][k] = cs * apk - sn * aqk;
-                    A[q][k] = sn * apk + cs * aqk;
-                }
-                for (int k = 0; k < K; ++k) {
-                    const double vkp = V[k][p], vkq = V[k][q];
-                    V[k][p] = cs * vkp - sn * vkq;
-                    V[k][q] = sn * vkp + cs * vkq;
-                }
-            }
-    }
+    jacobi_eigh(A, V, K);
     double lam[MAXK];
     int order[MAXK];
     double lmax = -1e300;
@@ -507,6 +528,19 @@ int movae_weights_upgrad(const float* G, int k, float norm_eps, float reg_eps, c
     return movae_weights_upgrad_norm(G, k, MOVAE_UPGRAD_TRACE, norm_eps, reg_eps, pref, w, stream);
 }
 
+int movae_weights_mgda_stable(const float* G, int k, int norm, const float* losses, float epsilon, int max_iters, float min_eigenvalue,
+                              float* w, int32_t* info, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(G && w, "movae_weights_mgda: null pointer");
+    MOVAE_CHECK_ARG(k >= 1 && k <= MAXK, "movae_weights_mgda: k=%d outside 1..%d", k, MAXK);
+    MOVAE_CHECK_ARG(norm >= 0 && norm <= 3, "movae_weights_mgda: unknown norm %d", norm);
+    MOVAE_CHECK_ARG(!(norm >= MOVAE_MGDA_LOSS && !losses),
+                    "Losses must be set before calling forward() when using norm_type='loss'/'loss+'");
+    hipLaunchKernelGGL(mgda_k, dim3(1), dim3(64), 0, (hipStream_t)stream, G, k, norm, losses, epsilon, max_iters, w, info, 1,
+                       min_eigenvalue);
+    MOVAE_CHECK_LAUNCH("mgda");
+    return MOVAE_OK;
+}
+
 int movae_weights_mgda(const float* G, int k, int norm, const float* losses, float epsilon, int max_iters, float* w,
                        int32_t* info, movae_stream_t stream) {
     MOVAE_CHECK_ARG(G && w, "movae_weights_mgda: null pointer");
@@ -514,7 +548,7 @@ int movae_weights_mgda(const float* G, int k, int norm, const float* losses, flo
     MOVAE_CHECK_ARG(norm >= 0 && norm <= 3, "movae_weights_mgda: unknown norm %d", norm);
     MOVAE_CHECK_ARG(!(norm >= MOVAE_MGDA_LOSS && !losses),
                     "Losses must be set before calling forward() when using norm_type='loss'/'loss+'");
-    hipLaunchKernelGGL(mgda_k, dim3(1), dim3(64), 0, (hipStream_t)stream, G, k, norm, losses, epsilon, max_iters, w, info);
+    hipLaunchKernelGGL(mgda_k, dim3(1), dim3(64), 0, (hipStream_t)stream, G, k, norm, losses, epsilon, max_iters, w, info, 0, 0.f);
     MOVAE_CHECK_LAUNCH("mgda");
     return MOVAE_OK;
 }

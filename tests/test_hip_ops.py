@@ -345,6 +345,15 @@ def test_mgda_weights_match_reference_code(M, case, nt):
 
 
 @pytest.mark.parametrize("case", CASES)
+def test_stable_mgda_weights_match_reference_code(M, case):
+    """StableMGDA (eigen regularisation, utils/torchmoo/mgda.py:286-317) vs vectors from the reference's MGDAWeighting."""
+    _, agg = M
+    fx = load_golden("weightings")
+    w = agg.MGDAWeighting(norm_type="none", stable=True)(torch.from_numpy(fx[f"{case}.G"]).cuda())
+    np.testing.assert_allclose(w.cpu().numpy(), fx[f"{case}.mgda.stable"], rtol=5e-4, atol=5e-6)
+
+
+@pytest.mark.parametrize("case", CASES)
 @pytest.mark.parametrize("sm", ["min", "median", "rmse"])
 def test_aligned_mtl_weights_match_reference_code(M, case, sm):
     _, agg = M
@@ -407,8 +416,11 @@ def test_nupgrad_pnupgrad_comfort_aggregators(M):
         w = (1 - beta) * np.asarray(OA.mgda_weights(G, "l2"), dtype=np.float64) + beta * OA.upgrad_weights(G)
         close(C(J.cuda()), torch.as_tensor(w, dtype=torch.float32) @ J, f"comfort epoch {epoch}", rtol=5e-4)
         np.testing.assert_allclose(seen["w"].cpu().numpy(), OA.mgda_weights(G, "l2"), rtol=2e-4, atol=2e-6)
-    with pytest.raises(NotImplementedError):
-        agg.COMFORT(mgda_stable=True)
+    Cs = agg.COMFORT(mgda_stable=True, mgda_min_eigenvalue_eps=1e-10)  # StableMGDA branch (comfort.py:100-106)
+    Cs.set_epoch(1, 10)
+    beta = OA.beta_schedule(1, 10)
+    w = (1 - beta) * np.asarray(OA.mgda_weights(G, "none", stable=True), dtype=np.float64) + beta * OA.upgrad_weights(G)
+    close(Cs(J.cuda()), torch.as_tensor(w, dtype=torch.float32) @ J, "comfort stable", rtol=5e-4)
 
 
 def test_aggregator_docstring_kats(M):

@@ -63,6 +63,13 @@ def test_mgda_weights(case, nt):
 
 
 @pytest.mark.parametrize("case", CASES)
+def test_stable_mgda_weights(case):
+    """StableMGDA's eigen regularisation (utils/torchmoo/mgda.py:286-317) against the reference's own weights."""
+    fx = load_golden("weightings")
+    np.testing.assert_allclose(A.mgda_weights(fx[f"{case}.G"], "none", stable=True), fx[f"{case}.mgda.stable"], rtol=5e-4, atol=5e-6)
+
+
+@pytest.mark.parametrize("case", CASES)
 @pytest.mark.parametrize("sm", ["min", "median", "rmse"])
 def test_aligned_mtl_weights(case, sm):
     fx = load_golden("weightings")
