@@ -172,6 +172,13 @@ def _sobel():
     return sx.expand(3, 1, 3, 3).clone(), sy.expand(3, 1, 3, 3).clone()
 
 
+def _with_sobel(sd):
+    out = OrderedDict()
+    out["sobel_x"], out["sobel_y"] = _sobel()
+    out.update(sd)
+    return out
+
+
 def init_gg_vae(cfg):
     sd = OrderedDict()
     sd["sobel_x"], sd["sobel_y"] = _sobel()
@@ -207,6 +214,18 @@ def losses_gg_vae(x, out, cfg):
     em = lw["edge_matching_loss"] * edge_matching_loss(x, out["recons"])
     k = lw["kld_loss"] * O.kl_divergence(out["mu"], out["log_var"])
     return OrderedDict(reconstruction_loss=r, gradient_guided_loss=gg, edge_matching_loss=em, kld_loss=k, total_loss=r + gg + em + k)
+
+
+def losses_gg_vq_vae(x, out, cfg):
+    """models/gg_vq_vae.py (version v1) through VQVAE.loss_function (models/vq_vae.py:367-391): objectives order
+    reconstruction, embedding, commitment, gradient_guided."""
+    fn, _ = O.resolve_objective(cfg.get("recons_objective", "mse"), cfg.get("recons_activation"))
+    lw = cfg["lambda_weights"]
+    r = lw["reconstruction_loss"] * fn(x, out["recons"])
+    e = lw["embedding_loss"] * out["embedding_loss"]
+    c = lw["commitment_loss"] * out["commitment_loss"]
+    gg = lw["gradient_guided_loss"] * edge_weighted_pixel_loss(x, out["recons"])
+    return OrderedDict(reconstruction_loss=r, embedding_loss=e, commitment_loss=c, gradient_guided_loss=gg, total_loss=r + e + c + gg)
 
 
 # ---------------------------------------------------------------------------------------
@@ -570,6 +589,8 @@ ARCHS = {
                    needs_eps=True, eps_dim="latent_dim"),
     "vq_vae": dict(init=init_vq_vae, forward=forward_vq_vae, losses=losses_vq_vae, features=["encoding"],
                    needs_eps=False),
+    "gg_vq_vae": dict(init=lambda cfg: _with_sobel(init_vq_vae(cfg)), forward=lambda *a, **k: forward_vq_vae(*a, **k),
+                      losses=losses_gg_vq_vae, features=["encoding"], needs_eps=False),
     "vq_vae2": dict(init=init_vq_vae2, forward=forward_vq_vae2, losses=losses_vq_vae2,
                     features=["encoding_top", "encoding_bottom"], needs_eps=False),
     "betatc_vae": dict(init=init_betatc_vae, forward=forward_betatc_vae, losses=losses_betatc_vae,
@@ -583,6 +604,7 @@ def default_lambda_weights(arch, batch_size, dataset_size):
         "vae": {"reconstruction_loss": 1.0, "kld_loss": r},
         "gg_vae": {"reconstruction_loss": 1.0, "kld_loss": r, "gradient_guided_loss": 1.0, "edge_matching_loss": 1.0},
         "vq_vae": {"reconstruction_loss": 1.0, "embedding_loss": 1.0, "commitment_loss": 0.25},
+        "gg_vq_vae": {"reconstruction_loss": 1.0, "gradient_guided_loss": 1.0, "embedding_loss": 1.0, "commitment_loss": 0.25},
         "vq_vae2": {"reconstruction_loss": 1.0, "commitment_loss": 1.0, "embedding_loss": 0.25},
         "betatc_vae": {"reconstruction_loss": 1.0, "mi_loss": 1.0, "tc_loss": 1.0, "kld": r},
     }[arch]

@@ -330,6 +330,8 @@ def model_fixtures():
 def gg_vae_fixture():
     """the gradient-guided VAE (models/gg_vae.py), edge matching version 1."""
     _model_fixture("gg_vae_tiny", "gg_vae", 31, 4, 16, dict(latent_dim=8, hidden_dims=[8, 16]))
+    _model_fixture("gg_vq_vae_tiny", "gg_vq_vae", 57, 3, 16,
+                   dict(embedding_dim=8, num_embeddings=16, hidden_dims=[8, 16], num_residual_layers=2))
 
 
 # --------------------------------------------------------------------------------------

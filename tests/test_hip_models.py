@@ -8,7 +8,7 @@ from conftest import cfg_from_meta, load_golden, meta_of
 
 pytestmark = pytest.mark.gpu
 
-TINY = ["vae_tiny", "vae_tiny_bce", "vae_1x1", "vq_vae_tiny", "vq_vae2_tiny", "betatc_vae_tiny", "gg_vae_tiny"]
+TINY = ["vae_tiny", "vae_tiny_bce", "vae_1x1", "vq_vae_tiny", "vq_vae2_tiny", "betatc_vae_tiny", "gg_vae_tiny", "gg_vq_vae_tiny"]
 
 
 class Args:
@@ -97,7 +97,7 @@ def test_forward_losses_sum_backward_and_adam(tag, gpu_device):
     assert_close(oe["recons"], fx["eval.recons"], "eval recons", rtol=2e-3, atol=5e-3 if tag.startswith(("vae", "gg_vae")) else 1e-4)
 
 
-@pytest.mark.parametrize("tag", ["vae_tiny", "vq_vae_tiny", "betatc_vae_tiny", "vq_vae2_tiny", "gg_vae_tiny"])
+@pytest.mark.parametrize("tag", ["vae_tiny", "vq_vae_tiny", "betatc_vae_tiny", "vq_vae2_tiny", "gg_vae_tiny", "gg_vq_vae_tiny"])
 @pytest.mark.parametrize("agg", ["upgrad", "mgda", "mgda_ln", "mgda_gn", "aligned_mtl", "aligned_mtl_rmse", "jd_sum", "mean"])
 def test_mtl_backward_matches_oracle(tag, agg, gpu_device):
     import movae_amd  # noqa: F401
@@ -141,7 +141,7 @@ def test_mtl_backward_matches_oracle(tag, agg, gpu_device):
         assert_close(got, want, f"{agg} grad {n}", rtol=3e-2 if cond else 2e-3, atol=1e-4 if cond else 1e-5)
 
 
-@pytest.mark.parametrize("tag", ["vae_tiny", "vq_vae_tiny", "betatc_vae_tiny", "gg_vae_tiny"])
+@pytest.mark.parametrize("tag", ["vae_tiny", "vq_vae_tiny", "betatc_vae_tiny", "gg_vae_tiny", "gg_vq_vae_tiny"])
 def test_unit_weights_equal_total_backward(tag, gpu_device):
     """Invariant: with w = 1 mtl_backward reproduces total_loss.backward() for
     non-nested features."""
@@ -162,7 +162,7 @@ def test_unit_weights_equal_total_backward(tag, gpu_device):
         assert_close(p.grad if p.grad is not None else torch.zeros_like(p), fx["gsum." + n], n)
 
 
-@pytest.mark.parametrize("tag", ["vae_tiny", "betatc_vae_tiny", "vq_vae2_tiny", "gg_vae_tiny"])
+@pytest.mark.parametrize("tag", ["vae_tiny", "betatc_vae_tiny", "vq_vae2_tiny", "gg_vae_tiny", "gg_vq_vae_tiny"])
 def test_batched_pullback_matches_sequential_passes(tag, gpu_device, monkeypatch):
     """autojac._batched_pullback (all loss cotangents through the shared graph at once: dgrad over K*n images,
     grouped wgrad / BatchNorm backward) fills the same Jacobian as one torch.autograd pass per loss."""
