@@ -33,7 +33,7 @@ struct T2 {
     static constexpr int TN = BN / (WN * 32);    // ... and along N (2x2 = 64x64 per wave for the 128x128 tile)
     static constexpr int LDKA = BM + 4;          // k-major leading dims
     static constexpr int LDKB = BN + 4;
-    static constexpr bool DB = (BM + BN) <= 192; // double-buffered LDS stages while they fit in 64 KiB
+    static constexpr bool DB = true;             // double-buffered LDS stages (128x128: 74 KiB of the CU's 160 KiB, two blocks resident)
     static_assert(TM >= 1 && TN >= 1, "tile");
 };
 
