@@ -236,7 +236,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
-                    help="replay the step as one captured hipGraph (auto: single-GPU VAE configs)")
+                    help="replay the step as one captured hipGraph (auto = on)")
     ap.add_argument("--kernel-table", type=str, default=None, help="write the per-launch conv table (JSON) here")
     args = ap.parse_args()
 
@@ -258,10 +258,10 @@ def main():
     from movae_amd.parallel import DataParallelGrads
     from movae_amd.train import train_step
 
-    from movae_amd.train import GRAPH_SAFE_ARCHS, GraphedTrainStep
+    from movae_amd.train import GraphedTrainStep
 
     dp = DataParallelGrads.from_env() if (world > 1 or os.environ.get("MOVAE_FORCE_DP")) else None
-    use_graph = args.graph == "on" or (args.graph == "auto" and cfg["arch"] == "vae")
+    use_graph = args.graph != "off"  # every hot-path model is capturable (no host reads inside the step)
     net, opt, agg, a, pool = build_workload(cfg, device, capturable=use_graph)
     if dp is not None:
         dp.attach(net)

@@ -31,6 +31,72 @@ def resolve_lambda_weights(owner, objectives, lambda_weights, defaults, list_ord
     raise TypeError(f"lambda_weights must be dict or list, got {type(lambda_weights)}")
 
 
+class LazyScalar:
+    """A number that lives on the device until somebody needs it on the host.
+
+    The reference's VQ models return `codebook_usage_percentage` as a Python float computed with `.item()` inside
+    forward (models/vq_vae.py:110-124,353), which parks the host in the middle of every step until the encoder has
+    finished; the backward launches can only be queued afterwards.  The models here return this object instead: it
+    converts (one device read) when it is formatted, compared or used in arithmetic -- e.g. by the meter update at the
+    end of the step (main.py:220) -- and it is what lets the whole step be captured into a hipGraph."""
+
+    __slots__ = ("_terms", "_scale")
+
+    def __init__(self, tensors, scale):
+        self._terms, self._scale = list(tensors), float(scale)
+
+    def __float__(self):
+        return float(sum(float(t.item()) for t in self._terms) * self._scale)
+
+    def item(self):
+        return float(self)
+
+    def __format__(self, spec):
+        return format(float(self), spec)
+
+    def __repr__(self):
+        return repr(float(self))
+
+    def __mul__(self, o):
+        return float(self) * o
+
+    __rmul__ = __mul__
+
+    def __add__(self, o):
+        return float(self) + o
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        return float(self) - o
+
+    def __rsub__(self, o):
+        return o - float(self)
+
+    def __truediv__(self, o):
+        return float(self) / o
+
+    def __rtruediv__(self, o):
+        return o / float(self)
+
+    def __eq__(self, o):
+        return float(self) == o
+
+    def __lt__(self, o):
+        return float(self) < o
+
+    def __le__(self, o):
+        return float(self) <= o
+
+    def __gt__(self, o):
+        return float(self) > o
+
+    def __ge__(self, o):
+        return float(self) >= o
+
+    __hash__ = None
+
+
 def activation_module(name):
     if name not in mnn.ACTIVATIONS:
         raise ValueError(f"recons_activation {name} not supported")
@@ -40,6 +106,13 @@ def activation_module(name):
 class HotPathModel(tnn.Module):
     """Protocol consumed by the training loop (main.py:148,159-160,168,180-181): `.objectives`,
     `.features`, `.lambda_weights`, forward -> dict, loss_function -> dict ending in total_loss."""
+
+    #: True when forward / loss_function neither read device values on the host nor bake per-step Python scalars into
+    #: their launches, i.e. the step can be captured into a hipGraph (train.GraphedTrainStep)
+    graph_safe = False
+
+    def prepare_for_graph(self):
+        """Hook called once before capture; models with per-step host state move it to the device here."""
 
     #: set to a tensor to replace torch.randn_like in reparameterize (seed-parity tests: the CPU and
     #: HIP generators draw different streams, SURVEY section 7 "hard parts")

@@ -54,6 +54,14 @@ class BetaTCVAE(HotPathModel):
         h = ops.unflatten_nchw(self.decoder_input(z), self.hidden_dims[-1], self._sp, self._sp)
         return nchw_view(self.final_layer(self.decoder(h)))
 
+    graph_safe = True
+    _iter_dev = None
+
+    def prepare_for_graph(self):
+        """Moves the annealing counter (models/betatc_vae.py:13,301-305) to the device, starting from its current value."""
+        if self._iter_dev is None:
+            self._iter_dev = torch.tensor(float(self.num_iter), dtype=torch.float32, device=next(self.parameters()).device)
+
     def reparameterize(self, mu, logvar):
         return ops.reparameterize(mu, logvar, self._noise_like(mu))
 
@@ -82,7 +90,11 @@ class BetaTCVAE(HotPathModel):
         z = args["z"]
         rec = self.objectives["reconstruction_loss"](inputs, args["recons"], lw["reconstruction_loss"])
         terms = ops.tc_decomposition(z, args["mu"], args["log_var"], self._log_importance_weights(z.shape[0], z.device))
-        if self.training:
+        if self.training and self._iter_dev is not None:
+            # graph mode (prepare_for_graph): the iteration counter lives on the device, so a replayed capture anneals
+            self._iter_dev.add_(1.0)
+            anneal = torch.clamp(self._iter_dev / float(self.anneal_steps), max=1.0)
+        elif self.training:
             self.num_iter += 1
             anneal = min(0 + 1 * self.num_iter / self.anneal_steps, 1)
         else:

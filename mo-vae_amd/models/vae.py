@@ -32,6 +32,8 @@ class _Unflatten(torch.nn.Module):
 
 
 class VAE(HotPathModel):
+    graph_safe = True
+
     def __init__(self, latent_dim=2, input_size=32, in_channels=3, hidden_dims=None, layer_norm="batch",
                  recons_activation="tanh", recons_objective="mse", lambda_weights=None, device=None, **kwargs):
         super().__init__()

@@ -5,7 +5,7 @@ import torch
 from .. import nn as mnn
 from .. import objectives as O
 from .. import ops
-from ._base import HotPathModel, activation_module, nchw_view, resolve_lambda_weights
+from ._base import HotPathModel, LazyScalar, activation_module, nchw_view, resolve_lambda_weights
 
 
 class VectorQuantizer(torch.nn.Module):
@@ -35,7 +35,7 @@ class VectorQuantizer(torch.nn.Module):
         """models/vq_vae.py:110-124.  The distinct-code count was produced by the lookup kernel, so the
         host reads one int32 instead of running torch.unique."""
         if self.last_used_count is not None:
-            return float(self.last_used_count.item() / self.K * 100.0)
+            return LazyScalar([self.last_used_count], 100.0 / self.K)  # read on the host only when somebody needs the number
         return float(torch.unique(encoding_inds).size(0) / self.K * 100.0)
 
     def get_used_embeddings(self, latents):
@@ -62,6 +62,8 @@ def _conv_lrelu(cin, cout, k, stride, padding):
 
 
 class VQVAE(HotPathModel):
+    graph_safe = True  # codebook usage stays on the device (LazyScalar)
+
     def __init__(self, in_channels, embedding_dim, num_embeddings, hidden_dims=(128, 256), num_residual_layers=6,
                  input_size=64, layer_norm="none", recons_activation="tanh", recons_objective="mse", lambda_weights=None,
                  device=None, **kwargs):

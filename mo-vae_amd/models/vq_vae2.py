@@ -5,7 +5,7 @@ import torch
 from .. import nn as mnn
 from .. import objectives as O
 from .. import ops
-from ._base import HotPathModel, nchw_view, resolve_lambda_weights
+from ._base import LazyScalar, HotPathModel, nchw_view, resolve_lambda_weights
 from .vq_vae import VectorQuantizer
 
 N_RES_CHANNEL = 32  # hard-coded at models/vq_vae2.py:190-212
@@ -65,6 +65,8 @@ class Decoder(torch.nn.Module):
 
 
 class VQVAE2(HotPathModel):
+    graph_safe = True  # codebook usage stays on the device (LazyScalar)
+
     def __init__(self, in_channels, embedding_dim, num_embeddings, hidden_dims=(128, 256), num_residual_layers=2,
                  input_size=64, layer_norm="none", recons_activation="tanh", recons_objective="mse", lambda_weights=None,
                  device=None, **kwargs):
@@ -124,7 +126,7 @@ class VQVAE2(HotPathModel):
         recons = self.decode(quant_t, quant_b)
         K = self.num_embeddings
         used_t, used_b = self._used
-        usage = (float(used_t.item() / K * 100.0) + float(used_b.item() / K * 100.0)) / 2.0
+        usage = LazyScalar([used_t, used_b], 100.0 / K / 2.0)  # mean of the two codebooks' usage, read lazily
         out = {"recons": recons, "encoding_top": enc_t, "encoding_bottom": enc_b, "quantized_top": quant_t,
                "quantized_bottom": quant_b, "commitment_loss": c_t + c_b, "embedding_loss": e_t + e_b,
                "codebook_usage_percentage": usage, "encoding_inds_top": i_t, "encoding_inds_bottom": i_b}

@@ -94,7 +94,6 @@ def train_step(net, images, optimizer, aggregator, args, dp=None):
     return loss_dict, outputs
 
 
-GRAPH_SAFE_ARCHS = {"VAE", "GGVAE"}  # forward/loss free of host syncs and of Python-side per-step scalars
 
 
 class GraphedTrainStep:
@@ -109,9 +108,9 @@ class GraphedTrainStep:
     `all_reduce(bucket)` over RCCL, then graph 2 = 1/N scaling + optimizer step on views of the bucket."""
 
     def __init__(self, net, optimizer, aggregator, args, example, warmup=3, dp=None, record_calls=False):
-        if type(net).__name__ not in GRAPH_SAFE_ARCHS:
-            raise NotImplementedError(f"{type(net).__name__}: forward syncs with the host (codebook usage / anneal counter); "
-                                      "use the eager train_step")
+        if not getattr(net, "graph_safe", False):
+            raise NotImplementedError(f"{type(net).__name__}: forward syncs with the host; use the eager train_step")
+        net.prepare_for_graph()
         self.net, self.opt, self.agg, self.args, self.dp = net, optimizer, aggregator, args, dp
         self.static_x = example.clone()
         from . import _lib as L
@@ -209,7 +208,7 @@ def train_epoch(net, train_loader, optimizer, aggregator, step, device, args, dp
         if host["total_loss"] > 1e15:
             print(f"Step {step}: EXPLODING: Total loss: {host['total_loss']:.6e}")
         if "codebook_usage_percentage" in outputs:
-            usage.update(outputs["codebook_usage_percentage"], n=images.size(0))
+            usage.update(float(outputs["codebook_usage_percentage"]), n=images.size(0))  # LazyScalar: one device read
         for k in meters:
             meters[k].update(host[k])
         step += 1

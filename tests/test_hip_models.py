@@ -63,7 +63,7 @@ def test_forward_losses_sum_backward_and_adam(tag, gpu_device):
         elif isinstance(got, torch.Tensor):
             assert_close(got, fx["out." + k], k, rtol=2e-4, atol=2e-5)
         else:
-            np.testing.assert_allclose(got, fx["out." + k], rtol=1e-6, err_msg=k)
+            np.testing.assert_allclose(float(got), fx["out." + k], rtol=1e-6, err_msg=k)  # floats and LazyScalar
     assert idx_ok, "codebook indices differ from the reference on the tiny fixture"
     assert list(ld.keys()) == [f[5:] for f in fx.files if f.startswith("loss.")]
     for k, v in ld.items():
@@ -284,22 +284,41 @@ def test_full_size_configs_step0(tag, gpu_device):
     assert not bad, bad
 
 
-def test_hipgraph_replay_matches_eager_steps(gpu_device):
+GRAPH_CASES = {
+    "vae": dict(latent_dim=16, hidden_dims=[16, 32, 64], aggregator="upgrad", max_grad_norm=None),
+    "vae_clip": dict(arch="vae", latent_dim=16, hidden_dims=[16, 32, 64], aggregator="upgrad", max_grad_norm=0.5),
+    "gg_vae": dict(latent_dim=16, hidden_dims=[16, 32, 64], aggregator="mgda_ln", max_grad_norm=None),
+    "vq_vae": dict(embedding_dim=8, num_embeddings=32, hidden_dims=[16, 32], num_residual_layers=2, aggregator="aligned_mtl",
+                   max_grad_norm=None),
+    "vq_vae2": dict(embedding_dim=8, num_embeddings=32, hidden_dims=[16, 32], num_residual_layers=2, aggregator="mgda_ln",
+                    max_grad_norm=None),
+    "betatc_vae": dict(latent_dim=8, hidden_dims=[16, 32], anneal_steps=5, aggregator="upgrad", max_grad_norm=None),
+}
+
+
+@pytest.mark.parametrize("case", sorted(GRAPH_CASES))
+def test_hipgraph_replay_matches_eager_steps(case, gpu_device):
     """GraphedTrainStep (one captured hipGraph per step) must reproduce the eager loop: same losses and the
-    same parameters after several Adam steps on changing batches."""
+    same parameters after several Adam steps on changing batches -- for every hot-path architecture (codebook usage
+    stays on the device as a LazyScalar, BetaTC's annealing counter moves to the device) and with gradient clipping."""
     import movae_amd  # noqa: F401
     from movae_amd import aggregation
     from movae_amd.models import get_network
+    from movae_amd.models.betatc_vae import BetaTCVAE
     from movae_amd.train import GraphedTrainStep, make_optimizer, train_step
 
+    kw = dict(GRAPH_CASES[case])
+    arch = kw.pop("arch", case)
+
     def make():
-        a = Args(arch="vae", batch_size=16, dataset_size=1000, latent_dim=16, hidden_dims=[16, 32, 64], recons_objective="mse",
-                 recons_activation=None, loss_weights=None, aggregator="upgrad", agg_norm_eps=1e-4, agg_reg_eps=1e-4,
-                 mgda_epsilon=1e-5, mgda_max_iters=250, pref_weights=None, optimizer="adam", lr=1e-3, wd=0, momentum=0.9,
-                 max_grad_norm=None)
+        a = Args(arch=arch, batch_size=16, dataset_size=1000, recons_objective="mse",
+                 recons_activation=None, loss_weights=None, agg_norm_eps=1e-4, agg_reg_eps=1e-4,
+                 mgda_epsilon=1e-5, mgda_max_iters=250, pref_weights=None, optimizer="adam", lr=1e-3, wd=0, momentum=0.9, **kw)
         torch.manual_seed(3)
+        BetaTCVAE.num_iter = 0
         net = get_network(32, 3, a, gpu_device).to(gpu_device).train()
-        net.eps_override = torch.randn(16, 16, generator=torch.Generator().manual_seed(5)).to(gpu_device)
+        if hasattr(net, "latent_dim"):
+            net.eps_override = torch.randn(16, net.latent_dim, generator=torch.Generator().manual_seed(5)).to(gpu_device)
         return net, a
 
     g = torch.Generator().manual_seed(11)
@@ -322,6 +341,11 @@ def test_hipgraph_replay_matches_eager_steps(gpu_device):
     for b in batches:
         ld, _ = gs.step(b)
         graph_losses.append(ld["total_loss"].item())
-    np.testing.assert_allclose(graph_losses, eager_losses, rtol=1e-5)
+    np.testing.assert_allclose(graph_losses, eager_losses, rtol=2e-5)
+    # BetaTC: the graph computes the annealing factor in fp32 on the device, the eager loop in Python doubles; the 1e-7
+    # difference in the kld weight reaches Adam through near-zero gradients, hence the looser bound there
+    tol = dict(rtol=2e-3, atol=2e-5) if case == "betatc_vae" else dict(rtol=1e-4, atol=2e-6)
     for (n, p), (_, q) in zip(net_e.named_parameters(), net_g.named_parameters()):
-        np.testing.assert_allclose(q.detach().cpu().numpy(), p.detach().cpu().numpy(), rtol=1e-4, atol=1e-6, err_msg=n)
+        np.testing.assert_allclose(q.detach().cpu().numpy(), p.detach().cpu().numpy(), err_msg=n, **tol)
+    if "codebook_usage_percentage" in gs.outputs:  # a live LazyScalar over the graph's static counter
+        assert 0.0 < float(gs.outputs["codebook_usage_percentage"]) <= 100.0
