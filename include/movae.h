@@ -169,9 +169,12 @@ int movae_edge_match_bwd(const float* recons, const float* inputs, const float* 
  * sse[0] = sum (q - x)^2 (commitment and embedding losses are both sse/numel).  x,q: [rows][d], e: [k][d]. */
 int movae_vq_nearest_fwd(const float* x, const float* e, float* q, int64_t* idx, float* sse, int32_t* used_count,
                          int rows, int k, int d, void* ws, size_t ws_bytes, movae_stream_t stream);
-/* dx = dq + gc * 2 (x - q)/numel ; de[idx] += ge * 2 (q - x)/numel   (gc, ge: device scalars, may be NULL = 0) */
+/* dx = dq + gc * 2 (x - q)/numel ; de[k] = ge * 2/numel * sum_{idx[r]==k} (q[r] - x[r])   (gc, ge: device scalars, may be
+ * NULL = 0; dx / de may be NULL).  The codebook gradient is a sorted segmented sum (no float atomics, bit-reproducible);
+ * `ws` must hold movae_vq_bwd_ws_bytes(rows, k, d) bytes when de and ge are given. */
+size_t movae_vq_bwd_ws_bytes(int rows, int k, int d);
 int movae_vq_bwd(const float* x, const float* q, const int64_t* idx, const float* dq, const float* gc, const float* ge,
-                 float* dx, float* de, int rows, int k, int d, movae_stream_t stream);
+                 float* dx, float* de, int rows, int k, int d, void* ws, size_t ws_bytes, movae_stream_t stream);
 
 /* ---- K-loss gradient aggregation ---------------------------------------------------------------------
  * torchjd GramianWeightedAggregator (base of utils/torchmoo/mgda.py:12, aligned_mtl.py:39): G = J J^T,

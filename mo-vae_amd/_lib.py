@@ -62,7 +62,8 @@ SIGNATURES = {
     "movae_edge_match_fwd": ([_p, _p, _p, _i, _i, _i, _i, _f, _p, _z, _p], _i),
     "movae_edge_match_bwd": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p], _i),
     "movae_vq_nearest_fwd": ([_p] * 6 + [_i, _i, _i, _p, _z, _p], _i),
-    "movae_vq_bwd": ([_p] * 8 + [_i, _i, _i, _p], _i),
+    "movae_vq_bwd_ws_bytes": ([_i, _i, _i], _z),
+    "movae_vq_bwd": ([_p] * 8 + [_i, _i, _i, _p, _z, _p], _i),
     "movae_gram_ws_bytes": ([_i, _z], _z),
     "movae_gram": ([_p, _z, _i, _z, _p, _p, _z, _p], _i),
     "movae_weights_upgrad": ([_p, _i, _f, _f, _p, _p, _p], _i),

@@ -5,6 +5,7 @@
 // matrix and no one-hot GEMM ever touch HBM (the reference materialises two [rows x K] fp32
 // temporaries).  The codebook chunk is staged once per block in LDS with a +1 padded row.
 #include "common.h"
+#include <hipcub/hipcub.hpp>
 
 namespace {
 
@@ -154,22 +155,81 @@ __global__ __launch_bounds__(256) void vq_finalize(const double* __restrict__ pa
     }
 }
 
-__global__ void vq_bwd_k(const float* __restrict__ x, const float* __restrict__ q, const int64_t* __restrict__ idx,
-                         const float* __restrict__ dq, const float* __restrict__ gc, const float* __restrict__ ge,
-                         float* __restrict__ dx, float* __restrict__ de, long rows, int D, float inv_numel) {
+// dx = dq + gc * 2 (x - q) / numel   (straight-through estimator + commitment term)
+__global__ void vq_bwd_dx_k(const float* __restrict__ x, const float* __restrict__ q, const float* __restrict__ dq,
+                            const float* __restrict__ gc, float* __restrict__ dx, long total, float inv_numel) {
     const float fc = gc ? gc[0] * 2.f * inv_numel : 0.f;
-    const float fe = ge ? ge[0] * 2.f * inv_numel : 0.f;
-    const long total = rows * D;
     const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const float df = x[i] - q[i];
-        if (dx) dx[i] = (dq ? dq[i] : 0.f) + fc * df;
-        if (de && fe != 0.f) {
-            const long r = i / D;
-            const int d = (int)(i - r * D);
-            atomicAdd(&de[idx[r] * D + d], -fe * df);
-        }
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride)
+        dx[i] = (dq ? dq[i] : 0.f) + fc * (x[i] - q[i]);
+}
+
+// ---- codebook gradient: de[k] = ge * 2 / numel * sum_{rows r with idx[r] == k} (q[r] - x[r]) -------------------------------
+// A scatter-add with float atomics (what ATen's index_add / embedding backward does) is neither deterministic nor fast
+// when few codes are in use (every row hits the same 64 addresses).  Here the rows are sorted by (code, row) with one
+// radix sort of 64-bit keys, each code's contiguous segment is summed in ascending row order by VQ_SPLITS blocks and
+// the partial sums are folded in fixed order: bit-reproducible, no atomics, no memset.
+constexpr int VQ_SPLITS = 8;
+
+__global__ void vq_keys_k(const int64_t* __restrict__ idx, unsigned long long* __restrict__ keys, int rows) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < rows) keys[r] = ((unsigned long long)idx[r] << 32) | (unsigned)r;
+}
+
+__device__ __forceinline__ int lower_bound_key(const unsigned long long* __restrict__ keys, int n, unsigned long long key) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (keys[mid] < key) lo = mid + 1;
+        else hi = mid;
     }
+    return lo;
+}
+
+// grid = (K, VQ_SPLITS): block (k, s) sums slice s of code k's segment; part[s][k][d]
+__global__ __launch_bounds__(256) void vq_embed_part_k(const float* __restrict__ x, const float* __restrict__ q,
+                                                       const unsigned long long* __restrict__ sorted, float* __restrict__ part,
+                                                       int rows, int K, int D) {
+    __shared__ float sh[256];
+    __shared__ int seg[2];
+    const int k = blockIdx.x, t = threadIdx.x;
+    if (t < 2) seg[t] = lower_bound_key(sorted, rows, (unsigned long long)(k + t) << 32);
+    __syncthreads();
+    const int lo0 = seg[0], n = seg[1] - seg[0];
+    const int per = (n + VQ_SPLITS - 1) / VQ_SPLITS;
+    const int lo = lo0 + blockIdx.y * per, hi = min(lo0 + n, lo + per);
+    // DL lanes cover the D columns (power of two <= 256), the other 256 / DL row slots stride over the slice
+    int DL = 1;
+    while (DL < D && DL < 256) DL <<= 1;
+    const int slots = 256 / DL, dl = t % DL, slot = t / DL;
+    for (int d0 = 0; d0 < D; d0 += DL) {
+        const int d = d0 + dl;
+        float acc = 0.f;
+        if (d < D)
+            for (int i = lo + slot; i < hi; i += slots) {
+                const long r = (long)(sorted[i] & 0xffffffffu);
+                acc += q[r * D + d] - x[r * D + d];
+            }
+        sh[t] = acc;
+        __syncthreads();
+        if (slot == 0 && d < D) {
+            float s = 0.f;
+            for (int j = 0; j < slots; ++j) s += sh[j * DL + dl];  // fixed order
+            part[((long)blockIdx.y * K + k) * D + d] = s;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void vq_embed_final_k(const float* __restrict__ part, const float* __restrict__ ge, float* __restrict__ de, long kd,
+                                 float inv_numel) {
+    const float fe = ge[0] * 2.f * inv_numel;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= kd) return;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < VQ_SPLITS; ++j) s += part[j * kd + i];
+    de[i] = fe * s;
 }
 
 template <int D>
@@ -213,21 +273,55 @@ int movae_vq_nearest_fwd(const float* x, const float* e, float* q, int64_t* idx,
     return MOVAE_OK;
 }
 
+size_t movae_vq_bwd_ws_bytes(int rows, int k, int d) {
+    if (rows <= 0 || k <= 0 || d <= 0) return 0;
+    size_t temp = 0;
+    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, temp, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, rows, 0, 64);
+    return MOVAE_WS_HEADER_BYTES + 2 * (size_t)rows * sizeof(unsigned long long) + (size_t)VQ_SPLITS * k * d * sizeof(float) + temp + 512;
+}
+
 int movae_vq_bwd(const float* x, const float* q, const int64_t* idx, const float* dq, const float* gc, const float* ge,
-                 float* dx, float* de, int rows, int k, int d, movae_stream_t stream) {
+                 float* dx, float* de, int rows, int k, int d, void* ws, size_t ws_bytes, movae_stream_t stream) {
+    MOVAE_WS_SCRATCH(ws, ws_bytes);
     MOVAE_CHECK_ARG(x && q && idx, "movae_vq_bwd: null pointer");
     MOVAE_CHECK_ARG(rows > 0 && k > 0 && d > 0, "movae_vq_bwd: bad shape");
     hipStream_t st = (hipStream_t)stream;
-    if (de && hipMemsetAsync(de, 0, (size_t)k * d * sizeof(float), st) != hipSuccess) {
-        movae_set_error("movae_vq_bwd: memset failed");
-        return MOVAE_ELAUNCH;
-    }
     const long total = (long)rows * d;
-    long gq = (total + 255) / 256;
-    if (gq > 4096) gq = 4096;
-    hipLaunchKernelGGL(vq_bwd_k, dim3((int)gq), dim3(256), 0, st, x, q, idx, dq, gc, ge, dx, de, (long)rows, d,
-                       1.f / (float)total);
-    MOVAE_CHECK_LAUNCH("vq_bwd");
+    if (dx) {
+        long gq = (total + 255) / 256;
+        if (gq > 4096) gq = 4096;
+        hipLaunchKernelGGL(vq_bwd_dx_k, dim3((int)gq), dim3(256), 0, st, x, q, dq, gc, dx, total, 1.f / (float)total);
+        MOVAE_CHECK_LAUNCH("vq_bwd_dx");
+    }
+    if (de && ge) {
+        MOVAE_CHECK_ARG(ws && ws_bytes + MOVAE_WS_HEADER_BYTES >= movae_vq_bwd_ws_bytes(rows, k, d), "movae_vq_bwd: workspace too small");
+        char* base = static_cast<char*>(ws);
+        unsigned long long* keys = reinterpret_cast<unsigned long long*>(base);
+        unsigned long long* sorted = keys + rows;
+        float* part = reinterpret_cast<float*>(sorted + rows);
+        void* temp = reinterpret_cast<char*>(part + (size_t)VQ_SPLITS * k * d);
+        temp = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(temp) + 255) & ~(uintptr_t)255);
+        size_t temp_bytes = 0;
+        (void)hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, keys, sorted, rows, 0, 64);
+        hipLaunchKernelGGL(vq_keys_k, dim3(ceil_div(rows, 256)), dim3(256), 0, st, idx, keys, rows);
+        MOVAE_CHECK_LAUNCH("vq_keys");
+        int kbits = 1;
+        while ((1 << kbits) < k) ++kbits;
+        if (hipcub::DeviceRadixSort::SortKeys(temp, temp_bytes, keys, sorted, rows, 0, 32 + kbits, st) != hipSuccess) {
+            movae_set_error("movae_vq_bwd: radix sort failed");
+            return MOVAE_ELAUNCH;
+        }
+        hipLaunchKernelGGL(vq_embed_part_k, dim3(k, VQ_SPLITS), dim3(256), 0, st, x, q, sorted, part, rows, k, d);
+        MOVAE_CHECK_LAUNCH("vq_embed_part");
+        const long kd = (long)k * d;
+        hipLaunchKernelGGL(vq_embed_final_k, dim3(ceil_div(kd, 256)), dim3(256), 0, st, part, ge, de, kd, 1.f / (float)total);
+        MOVAE_CHECK_LAUNCH("vq_embed_final");
+    } else if (de) {
+        if (hipMemsetAsync(de, 0, (size_t)k * d * sizeof(float), st) != hipSuccess) {
+            movae_set_error("movae_vq_bwd: memset failed");
+            return MOVAE_ELAUNCH;
+        }
+    }
     return MOVAE_OK;
 }
 

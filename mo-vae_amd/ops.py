@@ -662,6 +662,7 @@ class VectorQuantize(Function):
         ctx.save_for_backward(x, q, idx)
         ctx.kd = (k, d)
         ctx.mark_non_differentiable(idx, used)
+        ctx.set_materialize_grads(False)  # a loss that does not reach an output hands None (not zeros): that part is skipped
         return q, commitment, embedding, idx, used
 
     @staticmethod
@@ -673,8 +674,9 @@ class VectorQuantize(Function):
         need_x, need_e = ctx.needs_input_grad
         dx = torch.empty_like(x) if need_x else None
         de = torch.empty((k, d), dtype=x.dtype, device=x.device) if (need_e and ge is not None) else None
+        wsp, wsb = _ws(x)
         _call("movae_vq_bwd", x.data_ptr(), q.data_ptr(), idx.data_ptr(), L.ptr(dq), L.ptr(_c(gc) if gc is not None else None),
-              L.ptr(_c(ge) if ge is not None else None), L.ptr(dx), L.ptr(de), rows, k, d, _st(x))
+              L.ptr(_c(ge) if ge is not None else None), L.ptr(dx), L.ptr(de), rows, k, d, wsp, wsb, _st(x))
         if need_e and de is None:
             de = torch.zeros((k, d), dtype=x.dtype, device=x.device)
         return dx, de

@@ -294,6 +294,29 @@ def test_vector_quantize_vs_oracle(M, rows, K, D):
         close(Eg.grad, Er.grad, "dE", rtol=1e-3, atol=1e-5)
 
 
+def test_vq_codebook_gradient_skewed_usage_and_bit_reproducible(M):
+    """Few codes in use (the early-training regime): the sorted segmented sum must match a float64 scatter-add and give
+    the same bits on every run (there are no float atomics)."""
+    ops, _ = M
+    rows, K, D = 20000, 64, 16
+    E = torch.randn(K, D, generator=torch.Generator().manual_seed(5)) * 4.0
+    pick = torch.tensor([3, 3, 3, 41, 3, 17])[torch.randint(0, 6, (rows,), generator=torch.Generator().manual_seed(6))]
+    x = (E[pick] + 0.05 * torch.randn(rows, D, generator=torch.Generator().manual_seed(7))).reshape(1, rows, 1, D)
+    outs = []
+    for _ in range(3):
+        xg, Eg = x.cuda().requires_grad_(True), E.cuda().requires_grad_(True)
+        q, c, e, idx, used = ops.vector_quantize(xg, Eg)
+        (0.25 * c + 2.0 * e).backward()
+        outs.append(Eg.grad.cpu().clone())
+    assert torch.equal(idx.cpu().reshape(-1), pick) and int(used.item()) == 3
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    want = torch.zeros(K, D, dtype=torch.float64)
+    want.index_add_(0, pick, (E[pick].double() - x.reshape(rows, D).double()))
+    want *= 2.0 * 2.0 / (rows * D)
+    close(outs[0], want.float(), "dE", rtol=2e-4, atol=1e-6)
+    assert not outs[0][0].any() and not outs[0][63].any()  # unused codes get exact zeros without a memset
+
+
 def test_vq_first_index_on_ties(M):
     ops, _ = M
     E = torch.zeros(40, 8)
