@@ -111,6 +111,13 @@ int movae_bn_act_bwd_grouped(int groups, const float* dout, const float* y, cons
 int movae_act_fwd(const float* x, float* y, size_t n, int act, float slope, movae_stream_t stream);
 /* dx = dy * act'(.) evaluated from the activation OUTPUT `out` (valid for all five kinds) */
 int movae_act_bwd(const float* dy, const float* out, float* dx, size_t n, int act, float slope, movae_stream_t stream);
+/* dpre = dy * act'(out) for `groups` (<= 8) stacked cotangents [groups][rows][c] of one forward (out is shared) AND, in the
+ * same pass, dbias[g][c] (+)= sum_rows dpre -- the bias gradient of the conv whose epilogue applied the activation
+ * (models/betatc_vae.py:104-110, vq_vae2.py:36-47: Conv2d(bias) -> LeakyReLU / ReLU).  c %% 4 == 0; dbias: HOST array
+ * of device pointers. */
+int movae_act_bwd_bias_grouped(int groups, const float* dy, const float* out, float* dpre, float* const* dbias,
+                               int rows, int c, int act, float slope, int accumulate,
+                               void* ws, size_t ws_bytes, movae_stream_t stream);
 int movae_add(const float* a, const float* b, float* y, size_t n, movae_stream_t stream);
 int movae_axpby(float alpha, const float* a, float beta, const float* b, float* y, size_t n, movae_stream_t stream);
 /* channel concat / split of NHWC tensors: dst[rows][c_dst], src[rows][c_src] placed at channel offset */

@@ -43,6 +43,7 @@ SIGNATURES = {
     "movae_bn_act_bwd_grouped": ([_i] + [_p] * 9 + [_i, _i, _i, _f, _i, _p, _z, _p], _i),
     "movae_act_fwd": ([_p, _p, _z, _i, _f, _p], _i),
     "movae_act_bwd": ([_p, _p, _p, _z, _i, _f, _p], _i),
+    "movae_act_bwd_bias_grouped": ([_i, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p, _z, _p], _i),
     "movae_add": ([_p, _p, _p, _z, _p], _i),
     "movae_axpby": ([_f, _p, _f, _p, _p, _z, _p], _i),
     "movae_copy_channels": ([_p, _p, _i, _i, _i, _i, _i, _i, _p], _i),

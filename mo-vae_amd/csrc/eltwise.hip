@@ -163,6 +163,77 @@ __global__ __launch_bounds__(256) void colsum_partial4(const float* __restrict__
     }
 }
 
+// ---- activation backward fused with the bias gradient --------------------------------------------------------------
+// dpre = dy * act'(y) and, in the same pass, the per-channel sums of dpre (the bias gradient of the conv that produced y).
+// Without the fusion the column-sum kernel re-reads dpre: on the bias + LeakyReLU stacks (BetaTC-VAE, VQ-VAE-2) that
+// pass and its launch pair were ~5 % of the step.  grid = (row blocks, cotangent groups); y is shared by the groups.
+struct BiasOut {
+    float* p[8];
+};
+
+__global__ __launch_bounds__(256) void act_bwd_colsum4(const float* __restrict__ dy, const float* __restrict__ y,
+                                                       float* __restrict__ dpre, double* __restrict__ part, int rows, int C, int CQB,
+                                                       int rows_per_block, int act, float slope) {
+    __shared__ double sh[4 * 256];
+    const long gs = (long)rows * C;
+    dy += blockIdx.y * gs;
+    dpre += blockIdx.y * gs;
+    part += (long)blockIdx.y * gridDim.x * C;
+    const int t = threadIdx.x, RG = 256 / CQB, cl = t % CQB, rg = t / CQB, CQ = C / 4;
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min((long)rows, r0 + rows_per_block);
+    for (int cb = 0; cb < CQ; cb += CQB) {
+        const int cq = cb + cl;
+        double v[4] = {0, 0, 0, 0};
+        if (cq < CQ)
+            for (long r = r0 + rg; r < r1; r += 4 * RG) {
+                f32x4 g4[4], y4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long rr = r + (long)u * RG;
+                    if (rr < r1) {
+                        g4[u] = *reinterpret_cast<const f32x4*>(dy + rr * C + cq * 4);
+                        y4[u] = *reinterpret_cast<const f32x4*>(y + rr * C + cq * 4);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long rr = r + (long)u * RG;
+                    if (rr < r1) {
+                        f32x4 o;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            o[j] = g4[u][j] * act_grad_from_out(y4[u][j], act, slope);
+                            v[j] += (double)o[j];
+                        }
+                        *reinterpret_cast<f32x4*>(dpre + rr * C + cq * 4) = o;
+                    }
+                }
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sh[j * 256 + t] = v[j];
+        __syncthreads();
+        if (rg == 0 && cq < CQ) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                double s = v[j];
+                for (int i = 1; i < RG; ++i) s += sh[j * 256 + i * CQB + cl];
+                part[(long)blockIdx.x * C + cq * 4 + j] = s;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(64) void colsum_final_grouped(const double* __restrict__ part, int nblk, int C, BiasOut out, int accumulate) {
+    const int c = blockIdx.x;
+    part += (long)blockIdx.y * nblk * C;
+    float* __restrict__ dst = out.p[blockIdx.y];
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 64) s += part[(long)b * C + c];
+    s = wave_sum(s);
+    if (threadIdx.x == 0 && dst) dst[c] = accumulate ? dst[c] + (float)s : (float)s;
+}
+
 __global__ __launch_bounds__(64) void colsum_final(const double* __restrict__ part, int nblk, int C, float* __restrict__ out,
                                                    int accumulate) {
     const int c = blockIdx.x;
@@ -258,6 +329,30 @@ int movae_copy_channels(const float* src, float* dst, int rows, int c_src, int c
     hipLaunchKernelGGL(copy_channels_k, dim3(grid_for((long)rows * c_copy)), dim3(256), 0, (hipStream_t)stream, src, dst,
                        (long)rows, c_src, c_dst, src_off, dst_off, c_copy);
     MOVAE_CHECK_LAUNCH("copy_channels");
+    return MOVAE_OK;
+}
+
+int movae_act_bwd_bias_grouped(int groups, const float* dy, const float* out, float* dpre, float* const* dbias, int rows, int c,
+                               int act, float slope, int accumulate, void* ws, size_t ws_bytes, movae_stream_t stream) {
+    MOVAE_WS_SCRATCH(ws, ws_bytes);
+    MOVAE_CHECK_ARG(dy && out && dpre && dbias && rows > 0 && c > 0 && groups >= 1 && groups <= 8, "movae_act_bwd_bias: bad argument");
+    MOVAE_CHECK_ARG(c % 4 == 0 && al16(dy, out, dpre), "movae_act_bwd_bias: needs c %% 4 == 0 and 16-byte aligned tensors");
+    const int cq = c / 4;
+    const int CQB = pow2_ge(cq) < 256 ? pow2_ge(cq) : 256;
+    const int RG4 = 256 / CQB;
+    int rpb4 = ceil_div(rows, 512);
+    rpb4 = ceil_div(rpb4, RG4) * RG4;
+    if (rpb4 < RG4 * 4) rpb4 = RG4 * 4;
+    const int nblk = ceil_div(rows, rpb4);
+    MOVAE_CHECK_ARG(ws && ws_bytes >= (size_t)groups * nblk * c * sizeof(double), "movae_act_bwd_bias: workspace too small");
+    double* part = static_cast<double*>(ws);
+    hipLaunchKernelGGL(act_bwd_colsum4, dim3(nblk, groups), dim3(256), 0, (hipStream_t)stream, dy, out, dpre, part, rows, c, CQB, rpb4,
+                       act, slope);
+    MOVAE_CHECK_LAUNCH("act_bwd_colsum4");
+    BiasOut tab;
+    for (int i = 0; i < 8; ++i) tab.p[i] = i < groups ? dbias[i] : nullptr;
+    hipLaunchKernelGGL(colsum_final_grouped, dim3(c, groups), dim3(64), 0, (hipStream_t)stream, part, nblk, c, tab, accumulate);
+    MOVAE_CHECK_LAUNCH("colsum_final_grouped");
     return MOVAE_OK;
 }
 

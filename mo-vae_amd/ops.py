@@ -204,9 +204,16 @@ class Conv(Function):
         n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad = ctx.geom
         st = _st(dy)
         wsp, wsb = _ws(dy)
+        db_done = None
         if L.ACT[ctx.act]:
             dpre = torch.empty_like(dy)
-            _call("movae_act_bwd", dy.data_ptr(), y.data_ptr(), dpre.data_ptr(), dy.numel(), L.ACT[ctx.act], float(ctx.slope), st)
+            if _fuse_bias_grad(ctx, dy, y, co):
+                # activation backward and the bias gradient (column sums of dpre) in one pass over dy
+                db_done = _sink(b, (co,))
+                _call("movae_act_bwd_bias_grouped", 1, dy.data_ptr(), y.data_ptr(), dpre.data_ptr(), (C.c_void_p * 1)(db_done.data_ptr()),
+                      dy.numel() // co, co, L.ACT[ctx.act], float(ctx.slope), 0, wsp, wsb, st)
+            else:
+                _call("movae_act_bwd", dy.data_ptr(), y.data_ptr(), dpre.data_ptr(), dy.numel(), L.ACT[ctx.act], float(ctx.slope), st)
             dy = dpre
         pre = "movae_convT2d_" if ctx.transposed else "movae_conv2d_"
         dx = dw = db = None
@@ -230,7 +237,9 @@ class Conv(Function):
             wm_shape = (ci, kh, kw, co) if ctx.transposed else (co, kh, kw, ci)
             dwm = _sink(w, wm_shape)
             db_k = None
-            if ctx.has_bias and ctx.needs_input_grad[2]:
+            if db_done is not None:
+                db = db_done
+            elif ctx.has_bias and ctx.needs_input_grad[2]:
                 if ctx.bias_grad_is_zero:
                     # the bias feeds a training-mode BatchNorm, which subtracts the batch mean: d(loss)/d(bias) == 0
                     # identically (the reference's value is rounding noise of order 1e-9); no column-sum pass
@@ -255,11 +264,18 @@ class Conv(Function):
         n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad = ctx.geom
         st = _st(dy)
         wsp, wsb = _ws(dy)
+        db_done = None
         if L.ACT[ctx.act]:
             dpre = torch.empty_like(dy)
-            for g in range(G):
-                _call("movae_act_bwd", dy[g].data_ptr(), y.data_ptr(), dpre[g].data_ptr(), y.numel(), L.ACT[ctx.act],
-                      float(ctx.slope), st)
+            if _fuse_bias_grad(ctx, dy, y, co):
+                db_done = [_sink_row(g, b, (co,)) for g in range(G)]
+                _call("movae_act_bwd_bias_grouped", G, dy.data_ptr(), y.data_ptr(), dpre.data_ptr(),
+                      (C.c_void_p * G)(*[t.data_ptr() for t in db_done]), y.numel() // co, co, L.ACT[ctx.act], float(ctx.slope), 0,
+                      wsp, wsb, st)
+            else:
+                for g in range(G):
+                    _call("movae_act_bwd", dy[g].data_ptr(), y.data_ptr(), dpre[g].data_ptr(), y.numel(), L.ACT[ctx.act],
+                          float(ctx.slope), st)
             dy = dpre
         pre = "movae_convT2d_" if ctx.transposed else "movae_conv2d_"
         dx = dw = db = None
@@ -272,14 +288,23 @@ class Conv(Function):
         if ctx.needs_input_grad[1] or need_b:
             wm_shape = (ci, kh, kw, co) if ctx.transposed else (co, kh, kw, ci)
             dwm = [_sink_row(g, w, wm_shape) for g in range(G)]
-            db = [_sink_row(g, b, (co,), zeros=ctx.bias_grad_is_zero) for g in range(G)] if need_b else None
             arr = C.c_void_p * G
-            dbp = arr(*[t.data_ptr() for t in db]) if (need_b and not ctx.bias_grad_is_zero) else None
+            if db_done is not None:
+                db, dbp = db_done, None  # already produced by the fused activation-backward pass
+            else:
+                db = [_sink_row(g, b, (co,), zeros=ctx.bias_grad_is_zero) for g in range(G)] if need_b else None
+                dbp = arr(*[t.data_ptr() for t in db]) if (need_b and not ctx.bias_grad_is_zero) else None
             # one grouped launch: blockIdx.z = group * splits + split, x is read by every group, dy by its own
             _call(pre + "wgrad_grouped", G, dy.data_ptr(), x.data_ptr(), arr(*[t.data_ptr() for t in dwm]), dbp, n, hi, wi, ci, ho, wo,
                   co, kh, kw, stride, pad, 0, wsp, wsb, st)
             dw = [t.permute(0, 3, 1, 2) for t in dwm]
         return dx, dw, db, None, None, None, None, None, None, None
+
+
+def _fuse_bias_grad(ctx, dy, y, co):
+    """The conv applied an activation in its epilogue and its bias needs a gradient: one fused pass (eltwise.hip)."""
+    return (ctx.has_bias and ctx.needs_input_grad[2] and not ctx.bias_grad_is_zero and co % 4 == 0 and
+            dy.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0)
 
 
 def conv2d(x, w, b=None, stride=1, pad=0, act=None, slope=0.01, bias_grad_is_zero=False):
