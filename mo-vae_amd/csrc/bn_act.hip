@@ -244,23 +244,6 @@ inline Split4 make_split4(int rows, int c, int parts = 256) {
     return s;
 }
 
-template <int NV>  // NV doubles per thread
-__device__ __forceinline__ void block_fold(double (&v)[NV], double* sh, int CQB, int RG, int cl, int rg) {
-    // sh: [NV][256]
-#pragma unroll
-    for (int q = 0; q < NV; ++q) sh[q * 256 + threadIdx.x] = v[q];
-    __syncthreads();
-    if (rg == 0) {
-#pragma unroll
-        for (int q = 0; q < NV; ++q) {
-            double s = v[q];
-            for (int i = 1; i < RG; ++i) s += sh[q * 256 + i * CQB + cl];
-            v[q] = s;
-        }
-    }
-    __syncthreads();
-}
-
 __global__ __launch_bounds__(256) void bn_stats_partial4(const float* __restrict__ y, double* __restrict__ part, int rows,
                                                          int C, int CQB, int rows_per_block, unsigned* __restrict__ counter,
                                                          float eps, float momentum, float* __restrict__ save_mean,
@@ -288,7 +271,7 @@ __global__ __launch_bounds__(256) void bn_stats_partial4(const float* __restrict
                         v[4 + j] += (double)x[u][j] * (double)x[u][j];
                     }
             }
-        block_fold<8>(v, sh, CQB, RG, cl, rg);
+        fold_columns_256<8>(v, sh, CQB);
         if (rg == 0 && cq < CQ)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -364,7 +347,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial4(const float* __restrict__
                     }
             }
         }
-        block_fold<8>(v, sh, CQB, RG, cl, rg);
+        fold_columns_256<8>(v, sh, CQB);
         if (rg == 0 && cq < CQ)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {

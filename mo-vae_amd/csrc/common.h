@@ -110,6 +110,42 @@ __device__ __forceinline__ bool arrive_last(unsigned* counter, unsigned nblk) {
 }
 
 // block-wide sum for 256-thread blocks; result valid in every thread
+// Column fold of a 256-thread block whose thread t owns column cl = t % CQB of row group rg = t / CQB (CQB a power of two):
+// on return the threads with rg == 0 hold, in v[], the sums over all row groups of their column.  Row groups that share a
+// wave are folded with shuffles first, so the serial part is at most 4 LDS reads per value (the naive form made the
+// 256 / CQB row groups a serial loop on CQB threads -- 32 deep for a 32-channel tensor).  sh: NV * 256 doubles.
+template <int NV>
+__device__ __forceinline__ void fold_columns_256(double (&v)[NV], double* sh, int CQB) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (CQB < 64) {
+        for (int off = CQB; off < 64; off <<= 1)
+#pragma unroll
+            for (int q = 0; q < NV; ++q) v[q] += __shfl_xor(v[q], off, 64);
+        if (lane < CQB)
+#pragma unroll
+            for (int q = 0; q < NV; ++q) sh[q * 256 + wave * 64 + lane] = v[q];
+        __syncthreads();
+        if (t < CQB)
+#pragma unroll
+            for (int q = 0; q < NV; ++q)
+                v[q] = (sh[q * 256 + t] + sh[q * 256 + 64 + t]) + (sh[q * 256 + 128 + t] + sh[q * 256 + 192 + t]);
+    } else {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) sh[q * 256 + t] = v[q];
+        __syncthreads();
+        if (t < CQB) {
+            const int RG = 256 / CQB;
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                double s = v[q];
+                for (int i = 1; i < RG; ++i) s += sh[q * 256 + i * CQB + t];
+                v[q] = s;
+            }
+        }
+    }
+    __syncthreads();
+}
+
 __device__ __forceinline__ double block_sum_256(double v, double* sh /* >= 4 doubles */) {
     v = wave_sum(v);
     const int w = threadIdx.x >> 6;

@@ -140,18 +140,11 @@ __global__ __launch_bounds__(256) void colsum_partial4(const float* __restrict__
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] += (double)a[u][j];
             }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sh[j * 256 + t] = v[j];
-        __syncthreads();
+        fold_columns_256<4>(v, sh, CQB);
         if (rg == 0 && cq < CQ) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                double s = v[j];
-                for (int i = 1; i < RG; ++i) s += sh[j * 256 + i * CQB + cl];
-                part[(long)blockIdx.x * C + cq * 4 + j] = s;
-            }
+            for (int j = 0; j < 4; ++j) part[(long)blockIdx.x * C + cq * 4 + j] = v[j];
         }
-        __syncthreads();
     }
     if (counter == nullptr || !arrive_last(counter, gridDim.x)) return;
     const int lane = t & 63, nblk = gridDim.x;  // last block: one wave per column folds the partials
@@ -209,18 +202,11 @@ __global__ __launch_bounds__(256) void act_bwd_colsum4(const float* __restrict__
                     }
                 }
             }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sh[j * 256 + t] = v[j];
-        __syncthreads();
+        fold_columns_256<4>(v, sh, CQB);
         if (rg == 0 && cq < CQ) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                double s = v[j];
-                for (int i = 1; i < RG; ++i) s += sh[j * 256 + i * CQB + cl];
-                part[(long)blockIdx.x * C + cq * 4 + j] = s;
-            }
+            for (int j = 0; j < 4; ++j) part[(long)blockIdx.x * C + cq * 4 + j] = v[j];
         }
-        __syncthreads();
     }
 }
 
