@@ -167,9 +167,9 @@ __global__ void vq_bwd_dx_k(const float* __restrict__ x, const float* __restrict
 // ---- codebook gradient: de[k] = ge * 2 / numel * sum_{rows r with idx[r] == k} (q[r] - x[r]) -------------------------------
 // A scatter-add with float atomics (what ATen's index_add / embedding backward does) is neither deterministic nor fast
 // when few codes are in use (every row hits the same 64 addresses).  Here the rows are sorted by (code, row) with one
-// radix sort of 64-bit keys, each code's contiguous segment is summed in ascending row order by VQ_SPLITS blocks and
-// the partial sums are folded in fixed order: bit-reproducible, no atomics, no memset.
-constexpr int VQ_SPLITS = 8;
+// radix sort of 64-bit keys, each code's contiguous segment is cut into work items of VQ_CHUNK rows that are summed in
+// ascending row order, and the item partials are folded in fixed order: bit-reproducible, no atomics, no memset.
+constexpr int VQ_CHUNK = 128;  // rows per work item of the segmented sum
 
 __global__ void vq_keys_k(const int64_t* __restrict__ idx, unsigned long long* __restrict__ keys, int rows) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -186,19 +186,56 @@ __device__ __forceinline__ int lower_bound_key(const unsigned long long* __restr
     return lo;
 }
 
-// grid = (K, VQ_SPLITS): block (k, s) sums slice s of code k's segment; part[s][k][d]
-__global__ __launch_bounds__(256) void vq_embed_part_k(const float* __restrict__ x, const float* __restrict__ q,
-                                                       const unsigned long long* __restrict__ sorted, float* __restrict__ part,
-                                                       int rows, int K, int D) {
-    __shared__ float sh[256];
-    __shared__ int seg[2];
-    const int k = blockIdx.x, t = threadIdx.x;
-    if (t < 2) seg[t] = lower_bound_key(sorted, rows, (unsigned long long)(k + t) << 32);
+// One block: seg_lo[k] = first sorted position of code k (seg_lo[K] = rows), item_base[k] = exclusive prefix sum of
+// ceil(count_k / VQ_CHUNK) -- code k's segment is cut into that many work items so that a code holding most of the rows
+// (early training: a handful of codes in use) is summed by many blocks instead of one.
+__global__ __launch_bounds__(1024) void vq_segments_k(const unsigned long long* __restrict__ sorted, int rows, int K,
+                                                       int* __restrict__ seg_lo, int* __restrict__ item_base) {
+    __shared__ int sh[1024];
+    __shared__ int carry;
+    const int t = threadIdx.x;
+    if (t == 0) carry = 0;
+    for (int k = t; k <= K; k += 1024) seg_lo[k] = lower_bound_key(sorted, rows, (unsigned long long)k << 32);
     __syncthreads();
-    const int lo0 = seg[0], n = seg[1] - seg[0];
-    const int per = (n + VQ_SPLITS - 1) / VQ_SPLITS;
-    const int lo = lo0 + blockIdx.y * per, hi = min(lo0 + n, lo + per);
-    // DL lanes cover the D columns (power of two <= 256), the other 256 / DL row slots stride over the slice
+    for (int k0 = 0; k0 < K; k0 += 1024) {
+        const int k = k0 + t;
+        const int items = k < K ? (seg_lo[k + 1] - seg_lo[k] + VQ_CHUNK - 1) / VQ_CHUNK : 0;
+        sh[t] = items;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {  // inclusive Hillis-Steele scan
+            const int v = t >= off ? sh[t - off] : 0;
+            __syncthreads();
+            sh[t] += v;
+            __syncthreads();
+        }
+        if (k < K) item_base[k] = carry + sh[t] - items;
+        __syncthreads();
+        if (t == 1023) carry += sh[1023];
+        __syncthreads();
+    }
+    if (t == 0) item_base[K] = carry;
+}
+
+// block b = work item b: VQ_CHUNK consecutive sorted rows of one code; part[b][d] = sum_rows (q - x) in ascending row order
+__global__ __launch_bounds__(256) void vq_embed_part_k(const float* __restrict__ x, const float* __restrict__ q,
+                                                       const unsigned long long* __restrict__ sorted, const int* __restrict__ seg_lo,
+                                                       const int* __restrict__ item_base, float* __restrict__ part, int K, int D) {
+    __shared__ float sh[256];
+    __shared__ int code;
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (b >= item_base[K]) return;
+    if (t == 0) {  // largest k with item_base[k] <= b
+        int lo = 0, hi = K;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (item_base[mid] <= b) lo = mid;
+            else hi = mid;
+        }
+        code = lo;
+    }
+    __syncthreads();
+    const int k = code;
+    const int lo = seg_lo[k] + (b - item_base[k]) * VQ_CHUNK, hi = min(seg_lo[k + 1], lo + VQ_CHUNK);
     int DL = 1;
     while (DL < D && DL < 256) DL <<= 1;
     const int slots = 256 / DL, dl = t % DL, slot = t / DL;
@@ -215,21 +252,36 @@ __global__ __launch_bounds__(256) void vq_embed_part_k(const float* __restrict__
         if (slot == 0 && d < D) {
             float s = 0.f;
             for (int j = 0; j < slots; ++j) s += sh[j * DL + dl];  // fixed order
-            part[((long)blockIdx.y * K + k) * D + d] = s;
+            part[(long)b * D + d] = s;
         }
         __syncthreads();
     }
 }
 
-__global__ void vq_embed_final_k(const float* __restrict__ part, const float* __restrict__ ge, float* __restrict__ de, long kd,
-                                 float inv_numel) {
+// block k: de[k][d] = ge * 2 / numel * (sum of code k's item partials, in item order); zero for unused codes
+__global__ __launch_bounds__(256) void vq_embed_final_k(const float* __restrict__ part, const int* __restrict__ item_base,
+                                                        const float* __restrict__ ge, float* __restrict__ de, int D, float inv_numel) {
+    __shared__ float sh[256];
+    const int k = blockIdx.x, t = threadIdx.x;
     const float fe = ge[0] * 2.f * inv_numel;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= kd) return;
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < VQ_SPLITS; ++j) s += part[j * kd + i];
-    de[i] = fe * s;
+    const int b0 = item_base[k], b1 = item_base[k + 1];
+    int DL = 1;
+    while (DL < D && DL < 256) DL <<= 1;
+    const int slots = 256 / DL, dl = t % DL, slot = t / DL;
+    for (int d0 = 0; d0 < D; d0 += DL) {
+        const int d = d0 + dl;
+        float acc = 0.f;
+        if (d < D)
+            for (int b = b0 + slot; b < b1; b += slots) acc += part[(long)b * D + d];
+        sh[t] = acc;
+        __syncthreads();
+        if (slot == 0 && d < D) {
+            float s = 0.f;
+            for (int j = 0; j < slots; ++j) s += sh[j * DL + dl];
+            de[(long)k * D + d] = fe * s;
+        }
+        __syncthreads();
+    }
 }
 
 template <int D>
@@ -277,7 +329,9 @@ size_t movae_vq_bwd_ws_bytes(int rows, int k, int d) {
     if (rows <= 0 || k <= 0 || d <= 0) return 0;
     size_t temp = 0;
     (void)hipcub::DeviceRadixSort::SortKeys(nullptr, temp, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, rows, 0, 64);
-    return MOVAE_WS_HEADER_BYTES + 2 * (size_t)rows * sizeof(unsigned long long) + (size_t)VQ_SPLITS * k * d * sizeof(float) + temp + 512;
+    const size_t items = (size_t)rows / VQ_CHUNK + k + 1;
+    return MOVAE_WS_HEADER_BYTES + 2 * (size_t)rows * sizeof(unsigned long long) + items * d * sizeof(float) +
+           2 * ((size_t)k + 2) * sizeof(int) + temp + 1024;
 }
 
 int movae_vq_bwd(const float* x, const float* q, const int64_t* idx, const float* dq, const float* gc, const float* ge,
@@ -298,8 +352,11 @@ int movae_vq_bwd(const float* x, const float* q, const int64_t* idx, const float
         char* base = static_cast<char*>(ws);
         unsigned long long* keys = reinterpret_cast<unsigned long long*>(base);
         unsigned long long* sorted = keys + rows;
+        const int max_items = rows / VQ_CHUNK + k + 1;
         float* part = reinterpret_cast<float*>(sorted + rows);
-        void* temp = reinterpret_cast<char*>(part + (size_t)VQ_SPLITS * k * d);
+        int* seg_lo = reinterpret_cast<int*>(part + (size_t)max_items * d);
+        int* item_base = seg_lo + k + 2;
+        void* temp = reinterpret_cast<void*>(item_base + k + 2);
         temp = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(temp) + 255) & ~(uintptr_t)255);
         size_t temp_bytes = 0;
         (void)hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, keys, sorted, rows, 0, 64);
@@ -311,10 +368,11 @@ int movae_vq_bwd(const float* x, const float* q, const int64_t* idx, const float
             movae_set_error("movae_vq_bwd: radix sort failed");
             return MOVAE_ELAUNCH;
         }
-        hipLaunchKernelGGL(vq_embed_part_k, dim3(k, VQ_SPLITS), dim3(256), 0, st, x, q, sorted, part, rows, k, d);
+        hipLaunchKernelGGL(vq_segments_k, dim3(1), dim3(1024), 0, st, sorted, rows, k, seg_lo, item_base);
+        MOVAE_CHECK_LAUNCH("vq_segments");
+        hipLaunchKernelGGL(vq_embed_part_k, dim3(max_items), dim3(256), 0, st, x, q, sorted, seg_lo, item_base, part, k, d);
         MOVAE_CHECK_LAUNCH("vq_embed_part");
-        const long kd = (long)k * d;
-        hipLaunchKernelGGL(vq_embed_final_k, dim3(ceil_div(kd, 256)), dim3(256), 0, st, part, ge, de, kd, 1.f / (float)total);
+        hipLaunchKernelGGL(vq_embed_final_k, dim3(k), dim3(256), 0, st, part, item_base, ge, de, d, 1.f / (float)total);
         MOVAE_CHECK_LAUNCH("vq_embed_final");
     } else if (de) {
         if (hipMemsetAsync(de, 0, (size_t)k * d * sizeof(float), st) != hipSuccess) {

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Development tool: timing of the VQ lookup and its backward for uniform and skewed code usage."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import movae_amd  # noqa: E402,F401
+from movae_amd import ops  # noqa: E402
+
+
+def run(rows, K, D, used_codes, reps=10):
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    E = torch.randn(K, D, generator=g) * 3
+    pick = torch.randint(0, used_codes, (rows,), generator=g)
+    x = (E[pick] + 0.01 * torch.randn(rows, D, generator=g)).reshape(1, rows, 1, D).to(dev).requires_grad_(True)
+    Eg = E.to(dev).requires_grad_(True)
+    for _ in range(2):
+        q, c, e, idx, used = ops.vector_quantize(x, Eg)
+        (q.sum() + c + e).backward()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        q, c, e, idx, used = ops.vector_quantize(x, Eg)
+        (q.sum() + c + e).backward()
+    e1.record()
+    e1.synchronize()
+    print(f"rows {rows} K {K} D {D} used {used_codes}: {e0.elapsed_time(e1) * 1e3 / reps:8.1f} us per fwd+bwd (eager)")
+
+
+if __name__ == "__main__":
+    run(32768, 512, 64, 512)
+    run(32768, 512, 64, 20)
+    run(32768, 512, 64, 2)
