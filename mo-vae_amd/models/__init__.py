@@ -1,8 +1,9 @@
 """Model factory -- drop-in for the reference's models/__init__.py:18-211 for the four hot-path
-architectures (vae, vq_vae, vq_vae2, betatc_vae / btc_vae) and the SURVEY 8f.3 widening gg_vae / gg_vq_vae."""
+architectures (vae, vq_vae, vq_vae2, betatc_vae / btc_vae) and the SURVEY 8f.3 widening gg_vae / gg_vq_vae / gg_vq_vae2."""
 from .betatc_vae import BetaTCVAE
 from .gg_vae import GGVAE
 from .gg_vq_vae import GGVQVAE
+from .gg_vq_vae2 import GGVQVAE2
 from .vae import VAE
 from .vq_vae import VQVAE, VectorQuantizer
 from .vq_vae2 import VQVAE2
@@ -10,7 +11,7 @@ from .vq_vae2 import VQVAE2
 OUT_OF_SCOPE_ARCHS = {
     "gg_vae_v2", "gg_vae_v3", "gg_vae_v5", "gg_vae_v6", "recursive_kl_vae", "cycle_vae", "recursive_cyclic_vae",
     "rc_vae", "sphere_encoder", "sphere_encoder_vit", "gg_vq_vae_v2", "gg_vq_vae_v3",
-    "gg_vq_vae_v4", "gg_vq_vae_v5", "gg_vq_vae_v6", "gg_vq_vae_v7", "gg_vq_vae_v8", "gg_vq_vae2",
+    "gg_vq_vae_v4", "gg_vq_vae_v5", "gg_vq_vae_v6", "gg_vq_vae_v7", "gg_vq_vae_v8",
 }
 
 
@@ -66,6 +67,12 @@ def get_network(input_size, num_channels=3, args=None, device=None):
             lambda_weights = {"reconstruction_loss": 1.0, "commitment_loss": 1.0, "embedding_loss": 0.25}
         return VQVAE2(embedding_dim=embedding_dim, num_embeddings=num_embeddings, hidden_dims=hidden_dims,
                       num_residual_layers=num_residual_layers, lambda_weights=lambda_weights, **common)
+    if arch == "gg_vq_vae2":  # models/__init__.py:184-188
+        if lambda_weights is None:
+            lambda_weights = {"reconstruction_loss": 1.0, "commitment_loss": 1.0, "embedding_loss": 0.25,
+                              "gradient_guided_loss": 1.0, "edge_matching_loss": 1.0}
+        return GGVQVAE2(embedding_dim=embedding_dim, num_embeddings=num_embeddings, hidden_dims=hidden_dims,
+                        num_residual_layers=num_residual_layers, lambda_weights=lambda_weights, version="v3", **common)
     if arch in ("betatc_vae", "btc_vae"):
         ratio = args.batch_size / args.dataset_size
         if lambda_weights is None:
@@ -83,4 +90,4 @@ def get_network(input_size, num_channels=3, args=None, device=None):
     raise ValueError(f"Network architecture {arch} not supported")
 
 
-__all__ = ["VAE", "VQVAE", "VQVAE2", "BetaTCVAE", "VectorQuantizer", "get_network"]
+__all__ = ["VAE", "VQVAE", "VQVAE2", "BetaTCVAE", "GGVAE", "GGVQVAE", "GGVQVAE2", "VectorQuantizer", "get_network"]

@@ -228,6 +228,20 @@ def losses_gg_vq_vae(x, out, cfg):
     return OrderedDict(reconstruction_loss=r, embedding_loss=e, commitment_loss=c, gradient_guided_loss=gg, total_loss=r + e + c + gg)
 
 
+def losses_gg_vq_vae2(x, out, cfg):
+    """models/gg_vq_vae2.py:131-161 -- order reconstruction, commitment, embedding, gradient_guided, edge_matching
+    (edge_matching_loss_v2 :118-129 is the arithmetic of models/gg_vae.py:139-156)."""
+    fn, _ = O.resolve_objective(cfg.get("recons_objective", "mse"), cfg.get("recons_activation"))
+    lw = cfg["lambda_weights"]
+    r = lw["reconstruction_loss"] * fn(x, out["recons"])
+    c = lw["commitment_loss"] * out["commitment_loss"]
+    e = lw["embedding_loss"] * out["embedding_loss"]
+    gg = lw["gradient_guided_loss"] * edge_weighted_pixel_loss(x, out["recons"])
+    em = lw["edge_matching_loss"] * edge_matching_loss(x, out["recons"])
+    return OrderedDict(reconstruction_loss=r, commitment_loss=c, embedding_loss=e, gradient_guided_loss=gg, edge_matching_loss=em,
+                       total_loss=r + c + e + gg + em)
+
+
 # ---------------------------------------------------------------------------------------
 # Vector quantiser (models/vq_vae.py:27-64)
 # ---------------------------------------------------------------------------------------
@@ -593,6 +607,8 @@ ARCHS = {
                       losses=losses_gg_vq_vae, features=["encoding"], needs_eps=False),
     "vq_vae2": dict(init=init_vq_vae2, forward=forward_vq_vae2, losses=losses_vq_vae2,
                     features=["encoding_top", "encoding_bottom"], needs_eps=False),
+    "gg_vq_vae2": dict(init=lambda cfg: _with_sobel(init_vq_vae2(cfg)), forward=lambda *a, **k: forward_vq_vae2(*a, **k),
+                       losses=losses_gg_vq_vae2, features=["encoding_top", "encoding_bottom"], needs_eps=False),
     "betatc_vae": dict(init=init_betatc_vae, forward=forward_betatc_vae, losses=losses_betatc_vae,
                        features=["mu", "log_var"], needs_eps=True, eps_dim="latent_dim"),
 }
@@ -606,6 +622,8 @@ def default_lambda_weights(arch, batch_size, dataset_size):
         "vq_vae": {"reconstruction_loss": 1.0, "embedding_loss": 1.0, "commitment_loss": 0.25},
         "gg_vq_vae": {"reconstruction_loss": 1.0, "gradient_guided_loss": 1.0, "embedding_loss": 1.0, "commitment_loss": 0.25},
         "vq_vae2": {"reconstruction_loss": 1.0, "commitment_loss": 1.0, "embedding_loss": 0.25},
+        "gg_vq_vae2": {"reconstruction_loss": 1.0, "commitment_loss": 1.0, "embedding_loss": 0.25, "gradient_guided_loss": 1.0,
+                       "edge_matching_loss": 1.0},
         "betatc_vae": {"reconstruction_loss": 1.0, "mi_loss": 1.0, "tc_loss": 1.0, "kld": r},
     }[arch]
 

@@ -332,6 +332,8 @@ def gg_vae_fixture():
     _model_fixture("gg_vae_tiny", "gg_vae", 31, 4, 16, dict(latent_dim=8, hidden_dims=[8, 16]))
     _model_fixture("gg_vq_vae_tiny", "gg_vq_vae", 57, 3, 16,
                    dict(embedding_dim=8, num_embeddings=16, hidden_dims=[8, 16], num_residual_layers=2))
+    _model_fixture("gg_vq_vae2_tiny", "gg_vq_vae2", 77, 2, 32,
+                   dict(embedding_dim=8, num_embeddings=16, hidden_dims=[16, 32], num_residual_layers=2))
 
 
 # --------------------------------------------------------------------------------------

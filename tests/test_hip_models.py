@@ -8,7 +8,7 @@ from conftest import cfg_from_meta, load_golden, meta_of
 
 pytestmark = pytest.mark.gpu
 
-TINY = ["vae_tiny", "vae_tiny_bce", "vae_1x1", "vq_vae_tiny", "vq_vae2_tiny", "betatc_vae_tiny", "gg_vae_tiny", "gg_vq_vae_tiny"]
+TINY = ["vae_tiny", "vae_tiny_bce", "vae_1x1", "vq_vae_tiny", "vq_vae2_tiny", "betatc_vae_tiny", "gg_vae_tiny", "gg_vq_vae_tiny", "gg_vq_vae2_tiny"]
 
 
 class Args:
@@ -97,7 +97,7 @@ def test_forward_losses_sum_backward_and_adam(tag, gpu_device):
     assert_close(oe["recons"], fx["eval.recons"], "eval recons", rtol=2e-3, atol=5e-3 if tag.startswith(("vae", "gg_vae")) else 1e-4)
 
 
-@pytest.mark.parametrize("tag", ["vae_tiny", "vq_vae_tiny", "betatc_vae_tiny", "vq_vae2_tiny", "gg_vae_tiny", "gg_vq_vae_tiny"])
+@pytest.mark.parametrize("tag", ["vae_tiny", "vq_vae_tiny", "betatc_vae_tiny", "vq_vae2_tiny", "gg_vae_tiny", "gg_vq_vae_tiny", "gg_vq_vae2_tiny"])
 @pytest.mark.parametrize("agg", ["upgrad", "mgda", "mgda_ln", "mgda_gn", "aligned_mtl", "aligned_mtl_rmse", "jd_sum", "mean"])
 def test_mtl_backward_matches_oracle(tag, agg, gpu_device):
     import movae_amd  # noqa: F401
@@ -162,7 +162,7 @@ def test_unit_weights_equal_total_backward(tag, gpu_device):
         assert_close(p.grad if p.grad is not None else torch.zeros_like(p), fx["gsum." + n], n)
 
 
-@pytest.mark.parametrize("tag", ["vae_tiny", "betatc_vae_tiny", "vq_vae2_tiny", "gg_vae_tiny", "gg_vq_vae_tiny"])
+@pytest.mark.parametrize("tag", ["vae_tiny", "betatc_vae_tiny", "vq_vae2_tiny", "gg_vae_tiny", "gg_vq_vae_tiny", "gg_vq_vae2_tiny"])
 def test_batched_pullback_matches_sequential_passes(tag, gpu_device, monkeypatch):
     """autojac._batched_pullback (all loss cotangents through the shared graph at once: dgrad over K*n images,
     grouped wgrad / BatchNorm backward) fills the same Jacobian as one torch.autograd pass per loss."""
@@ -292,6 +292,8 @@ GRAPH_CASES = {
                    max_grad_norm=None),
     "vq_vae2": dict(embedding_dim=8, num_embeddings=32, hidden_dims=[16, 32], num_residual_layers=2, aggregator="mgda_ln",
                     max_grad_norm=None),
+    "gg_vq_vae2": dict(embedding_dim=8, num_embeddings=32, hidden_dims=[16, 32], num_residual_layers=2, aggregator="upgrad",
+                       max_grad_norm=None),
     "betatc_vae": dict(latent_dim=8, hidden_dims=[16, 32], anneal_steps=5, aggregator="upgrad", max_grad_norm=None),
 }
 

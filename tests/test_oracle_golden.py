@@ -9,7 +9,7 @@ from oracle import aggregation as A
 from oracle import nets, objectives as O
 from oracle.step import OracleTrainer
 
-TINY = ["vae_tiny", "vae_tiny_bce", "vae_1x1", "vq_vae_tiny", "vq_vae2_tiny", "betatc_vae_tiny", "gg_vae_tiny", "gg_vq_vae_tiny"]
+TINY = ["vae_tiny", "vae_tiny_bce", "vae_1x1", "vq_vae_tiny", "vq_vae2_tiny", "betatc_vae_tiny", "gg_vae_tiny", "gg_vq_vae_tiny", "gg_vq_vae2_tiny"]
 
 
 def T(a):
