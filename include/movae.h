@@ -156,8 +156,20 @@ int movae_tc_decomp_bwd(const float* z, const float* mu, const float* log_var, c
  * models/gg_vae.py:42-53 (depthwise Sobel x / y, zero padding 1), EPS = 1e-8 (gg_vae.py:8); images NHWC [n][h][w][c].
  * edge weights (gg_vae.py:125-132): w_raw[n*h*w] = max_c sqrt(gx^2 + gy^2 + EPS) of `inputs`, wmax[0] = global max;
  * edge-weighted pixel loss (gg_vae.py:134-137): out = scale * mean( w_raw / (wmax + EPS) * (recons - inputs)^2 );
- * edge matching loss v1 (gg_vae.py:139-156): out = scale * smooth_l1( |sobel recons|, |sobel inputs| ), mean reduction.
+ * edge matching losses: out = scale * mean f(sobel recons, sobel inputs), one point-wise variant per `mode`
+ * (enum movae_edge_match; gp / gt = |sobel recons| / |sobel inputs|, sl1 = smooth-L1 with beta 1):
+ *   MAG         sl1(gp - gt)                                  gg_vae.py:139-156, gg_vq_vae.py:184-199, gg_vq_vae2.py:118-129
+ *   SIGNED_MSE  (rx - tx)^2 + (ry - ty)^2                     gg_vq_vae.py:172-182
+ *   MAXNORM     sl1(gp / (max gp + EPS) - gt / (max gt + EPS)), gradient through the max   gg_vae.py:158-173, gg_vq_vae.py:201-216
+ *   ANGLE       sl1(atan2(ry, rx) - atan2(ty, tx))            gg_vae.py:176-190, gg_vq_vae.py:219-232
+ *   MASKED      sl1(m * gp - m * gt), m = gt > mean gt        gg_vq_vae.py:234-247
+ *   COSINE      1 - cos(normalize(rx, ry), normalize(tx, ty)) gg_vae.py:192-208, gg_vq_vae.py:249-264
+ * `stats`: device float[8] written by the forward and read by the backward of MAXNORM / MASKED (may be NULL otherwise).
  * The backward passes take the upstream gradient as a device scalar (gscale_dev, may be NULL = 1). */
+enum movae_edge_match {
+    MOVAE_EDGE_MAG = 0, MOVAE_EDGE_SIGNED_MSE = 1, MOVAE_EDGE_MAXNORM = 2, MOVAE_EDGE_ANGLE = 3, MOVAE_EDGE_MASKED = 4,
+    MOVAE_EDGE_COSINE = 5
+};
 int movae_edge_weights(const float* inputs, float* w_raw, float* wmax, int n, int h, int w, int c,
                        void* ws, size_t ws_bytes, movae_stream_t stream);
 int movae_edge_weighted_mse_fwd(const float* recons, const float* inputs, const float* w_raw, const float* wmax, float* out,
@@ -166,10 +178,11 @@ int movae_edge_weighted_mse_bwd(const float* recons, const float* inputs, const 
                                 const float* gscale_dev, float* drecons, int n, int h, int w, int c, float scale,
                                 movae_stream_t stream);
 int movae_edge_match_fwd(const float* recons, const float* inputs, float* out, int n, int h, int w, int c, float scale,
-                         void* ws, size_t ws_bytes, movae_stream_t stream);
+                         int mode, float* stats, void* ws, size_t ws_bytes, movae_stream_t stream);
 /* tmp_a / tmp_b: two scratch tensors of the images' size (d loss / d Sobel-x and -y responses) */
 int movae_edge_match_bwd(const float* recons, const float* inputs, const float* gscale_dev, float* drecons, float* tmp_a,
-                         float* tmp_b, int n, int h, int w, int c, float scale, movae_stream_t stream);
+                         float* tmp_b, int n, int h, int w, int c, float scale, int mode, const float* stats,
+                         movae_stream_t stream);
 
 /* ---- vector quantiser ------------------------------------------------------------------------------
  * models/vq_vae.py:27-64: nearest code under ||x||^2 + ||e||^2 - 2 x.e (first index on ties), gather, and

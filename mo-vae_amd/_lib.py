@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(HERE, "libmovae_hip.so")
 ACT = {"none": 0, None: 0, "lrelu": 1, "relu": 2, "tanh": 3, "sigmoid": 4}
 RECON = {"mse": 0, "bce": 1, "l1": 2, "smooth_l1": 3}
 UPGRAD_NORM = {"trace": 0, "min_l2": 1, "cosine": 2}
+EDGE_MATCH = {"mag": 0, "signed_mse": 1, "maxnorm": 2, "angle": 3, "masked": 4, "cosine": 5}  # enum movae_edge_match
 MGDA_NORM = {"none": 0, "l2": 1, "loss": 2, "loss+": 3}
 AMTL_SCALE = {"min": 0, "median": 1, "rmse": 2}
 MAX_K = 8
@@ -60,8 +61,8 @@ SIGNATURES = {
     "movae_edge_weights": ([_p, _p, _p, _i, _i, _i, _i, _p, _z, _p], _i),
     "movae_edge_weighted_mse_fwd": ([_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _z, _p], _i),
     "movae_edge_weighted_mse_bwd": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p], _i),
-    "movae_edge_match_fwd": ([_p, _p, _p, _i, _i, _i, _i, _f, _p, _z, _p], _i),
-    "movae_edge_match_bwd": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p], _i),
+    "movae_edge_match_fwd": ([_p, _p, _p, _i, _i, _i, _i, _f, _i, _p, _p, _z, _p], _i),
+    "movae_edge_match_bwd": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p, _p], _i),
     "movae_vq_nearest_fwd": ([_p] * 6 + [_i, _i, _i, _p, _z, _p], _i),
     "movae_vq_bwd_ws_bytes": ([_i, _i, _i], _z),
     "movae_vq_bwd": ([_p] * 8 + [_i, _i, _i, _p, _z, _p], _i),

@@ -1,5 +1,5 @@
 """Model factory -- drop-in for the reference's models/__init__.py:18-211 for the four hot-path
-architectures (vae, vq_vae, vq_vae2, betatc_vae / btc_vae) and the SURVEY 8f.3 widening gg_vae / gg_vq_vae / gg_vq_vae2."""
+architectures (vae, vq_vae, vq_vae2, betatc_vae / btc_vae) and the SURVEY 8f.3 widening gg_vae[_v2|_v3|_v5] / gg_vq_vae[_v1.._v7] / gg_vq_vae2."""
 from .betatc_vae import BetaTCVAE
 from .gg_vae import GGVAE
 from .gg_vq_vae import GGVQVAE
@@ -9,9 +9,7 @@ from .vq_vae import VQVAE, VectorQuantizer
 from .vq_vae2 import VQVAE2
 
 OUT_OF_SCOPE_ARCHS = {
-    "gg_vae_v2", "gg_vae_v3", "gg_vae_v5", "gg_vae_v6", "recursive_kl_vae", "cycle_vae", "recursive_cyclic_vae",
-    "rc_vae", "sphere_encoder", "sphere_encoder_vit", "gg_vq_vae_v2", "gg_vq_vae_v3",
-    "gg_vq_vae_v4", "gg_vq_vae_v5", "gg_vq_vae_v6", "gg_vq_vae_v7", "gg_vq_vae_v8",
+    "recursive_kl_vae", "cycle_vae", "recursive_cyclic_vae", "rc_vae", "sphere_encoder", "sphere_encoder_vit",
 }
 
 
@@ -45,13 +43,15 @@ def get_network(input_size, num_channels=3, args=None, device=None):
         else:
             lambda_weights = [lambda_weights[0], ratio]
         return VAE(latent_dim=latent_dim, hidden_dims=hidden_dims, lambda_weights=lambda_weights, **common)
-    if arch == "gg_vae":  # models/__init__.py:147-154 (edge_matching_version=1)
+    if arch in ("gg_vae", "gg_vae_v2", "gg_vae_v3", "gg_vae_v5", "gg_vae_v6"):  # models/__init__.py:147-163
+        version = 1 if arch == "gg_vae" else int(arch.split("_")[-1].replace("v", ""))
         ratio = args.batch_size / args.dataset_size
         if lambda_weights is None:
             lambda_weights = {"reconstruction_loss": 1.0, "kld_loss": ratio, "gradient_guided_loss": 1.0, "edge_matching_loss": 1.0}
         elif isinstance(lambda_weights, dict):
             lambda_weights = dict(lambda_weights, kld_loss=ratio)
-        return GGVAE(latent_dim=latent_dim, hidden_dims=hidden_dims, lambda_weights=lambda_weights, edge_matching_version=1, **common)
+        return GGVAE(latent_dim=latent_dim, hidden_dims=hidden_dims, lambda_weights=lambda_weights, edge_matching_version=version,
+                     **common)
     if arch == "vq_vae":
         if lambda_weights is None:
             lambda_weights = {"reconstruction_loss": 1.0, "embedding_loss": 1.0, "commitment_loss": 0.25}
@@ -62,6 +62,13 @@ def get_network(input_size, num_channels=3, args=None, device=None):
             lambda_weights = {"reconstruction_loss": 1.0, "gradient_guided_loss": 1.0, "embedding_loss": 1.0, "commitment_loss": 0.25}
         return GGVQVAE(embedding_dim=embedding_dim, num_embeddings=num_embeddings, hidden_dims=hidden_dims,
                        num_residual_layers=num_residual_layers, lambda_weights=lambda_weights, version="v1", **common)
+    if arch in tuple(f"gg_vq_vae_v{i}" for i in range(2, 9)):  # models/__init__.py:174-178
+        if lambda_weights is None:
+            lambda_weights = {"reconstruction_loss": 1.0, "gradient_guided_loss": 1.0, "embedding_loss": 1.0, "commitment_loss": 0.25,
+                              "edge_matching_loss": 1.0}
+        return GGVQVAE(embedding_dim=embedding_dim, num_embeddings=num_embeddings, hidden_dims=hidden_dims,
+                       num_residual_layers=num_residual_layers, lambda_weights=lambda_weights, version=arch.replace("gg_vq_vae_", ""),
+                       **common)
     if arch == "vq_vae2":
         if lambda_weights is None:
             lambda_weights = {"reconstruction_loss": 1.0, "commitment_loss": 1.0, "embedding_loss": 0.25}

@@ -33,10 +33,20 @@ def edge_weighted_pixel_loss(inputs, recons, scale=1.0):
     return ops.edge_weighted_pixel_loss(r, x, scale)
 
 
-def edge_matching_loss(inputs, recons, scale=1.0):
-    """models/gg_vae.py:139-156 (GGVAE.edge_matching_loss, version 1)."""
+def edge_matching_loss(inputs, recons, scale=1.0, mode="mag"):
+    """The edge-matching family of models/gg_vae.py:139-208 and models/gg_vq_vae.py:172-264; `mode` names the variant
+    (mag = GGVAE version 1 / GGVQVAE edge_matching_loss_v2, the default)."""
     x, r = _pair(inputs, recons)
-    return ops.edge_matching_loss(r, x, scale)
+    return ops.edge_matching_loss(r, x, scale, mode)
+
+
+def make_edge_matching(mode):
+    """An objective `fn(inputs, recons, scale=1.0)` bound to one edge-matching variant."""
+    def fn(inputs, recons, scale=1.0):
+        return edge_matching_loss(inputs, recons, scale, mode)
+
+    fn.mode = mode
+    return fn
 
 
 def kl_divergence(mu, log_var, scale=1.0):

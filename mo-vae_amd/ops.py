@@ -563,39 +563,41 @@ class EdgeWeightedPixelLoss(Function):
 
 
 class EdgeMatchingLoss(Function):
-    """models/gg_vae.py:139-156 (edge_matching_version 1): scale * smooth_l1(|sobel recons|, |sobel inputs|).  NHWC."""
+    """scale * mean f(sobel recons, sobel inputs) for the reference's edge-matching variants (`mode`, a key of
+    _lib.EDGE_MATCH; include/movae.h lists each variant's reference lines).  NHWC; no gradient flows into `inputs`."""
 
     @staticmethod
-    def forward(ctx, recons, inputs, scale):
+    def forward(ctx, recons, inputs, scale, mode):
         L.require_gpu(recons)
         recons, inputs = _c(recons), _c(inputs)
         assert recons.shape == inputs.shape and recons.dim() == 4, (recons.shape, inputs.shape)
         n, h, w, c = recons.shape
         out = torch.empty((), dtype=recons.dtype, device=recons.device)
+        stats = torch.empty(8, dtype=recons.dtype, device=recons.device)
         wsp, wsb = _ws(recons)
-        _call("movae_edge_match_fwd", recons.data_ptr(), inputs.data_ptr(), out.data_ptr(), n, h, w, c, float(scale), wsp, wsb,
-              _st(recons))
-        ctx.scale = scale
-        ctx.save_for_backward(recons, inputs)
+        _call("movae_edge_match_fwd", recons.data_ptr(), inputs.data_ptr(), out.data_ptr(), n, h, w, c, float(scale),
+              L.EDGE_MATCH[mode], stats.data_ptr(), wsp, wsb, _st(recons))
+        ctx.scale, ctx.mode = scale, mode
+        ctx.save_for_backward(recons, inputs, stats)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        recons, inputs = ctx.saved_tensors
+        recons, inputs, stats = ctx.saved_tensors
         g = _c(g)
         n, h, w, c = recons.shape
         dr, ta, tb = torch.empty_like(recons), torch.empty_like(recons), torch.empty_like(recons)
         _call("movae_edge_match_bwd", recons.data_ptr(), inputs.data_ptr(), g.data_ptr(), dr.data_ptr(), ta.data_ptr(), tb.data_ptr(),
-              n, h, w, c, float(ctx.scale), _st(recons))
-        return dr, None, None
+              n, h, w, c, float(ctx.scale), L.EDGE_MATCH[ctx.mode], stats.data_ptr(), _st(recons))
+        return dr, None, None, None
 
 
 def edge_weighted_pixel_loss(recons, inputs, scale=1.0):
     return EdgeWeightedPixelLoss.apply(recons, inputs, scale)
 
 
-def edge_matching_loss(recons, inputs, scale=1.0):
-    return EdgeMatchingLoss.apply(recons, inputs, scale)
+def edge_matching_loss(recons, inputs, scale=1.0, mode="mag"):
+    return EdgeMatchingLoss.apply(recons, inputs, scale, mode)
 
 
 def recon_loss(recons, inputs, kind, scale=1.0):

@@ -205,27 +205,74 @@ def edge_matching_loss(x, recons):
     return F.smooth_l1_loss(gp, gt)
 
 
+def _sobel_pair(x, recons):
+    sx, sy = _sobel()
+    g = x.size(1)
+    return (F.conv2d(recons, sx, padding=1, groups=g), F.conv2d(recons, sy, padding=1, groups=g),
+            F.conv2d(x, sx, padding=1, groups=g), F.conv2d(x, sy, padding=1, groups=g))
+
+
+def edge_matching_variant(x, recons, mode):
+    """The edge-matching family, one restatement per variant (the names are include/movae.h's enum movae_edge_match):
+    mag         models/gg_vae.py:139-156 == gg_vq_vae.py:184-199 (v2) == gg_vq_vae2.py:118-129
+    signed_mse  models/gg_vq_vae.py:172-182 (v1)
+    maxnorm     models/gg_vae.py:158-173 (v2) == gg_vq_vae.py:201-216 (v3)
+    angle       models/gg_vae.py:176-190 (v3) == gg_vq_vae.py:219-232 (v4)
+    masked      models/gg_vq_vae.py:234-247 (v5)
+    cosine      models/gg_vae.py:192-208 (v5) == gg_vq_vae.py:249-264 (v6)"""
+    if mode == "mag":
+        return edge_matching_loss(x, recons)
+    rx, ry, tx, ty = _sobel_pair(x, recons)
+    if mode == "signed_mse":
+        return F.mse_loss(rx, tx) + F.mse_loss(ry, ty)
+    if mode == "angle":
+        return F.smooth_l1_loss(torch.atan2(ry, rx), torch.atan2(ty, tx))
+    if mode == "cosine":
+        gt = F.normalize(torch.stack([tx, ty], dim=1), p=2, dim=1)
+        gp = F.normalize(torch.stack([rx, ry], dim=1), p=2, dim=1)
+        return 1 - F.cosine_similarity(gp, gt).mean()
+    gp = torch.sqrt(rx ** 2 + ry ** 2 + GG_EPS)
+    gt = torch.sqrt(tx ** 2 + ty ** 2 + GG_EPS)
+    if mode == "maxnorm":
+        return F.smooth_l1_loss(gp / (gp.max() + GG_EPS), gt / (gt.max() + GG_EPS))
+    if mode == "masked":
+        mask = (gt > gt.mean()).float()
+        return F.smooth_l1_loss(gp * mask, gt * mask)
+    raise ValueError(mode)
+
+
+GG_VAE_EDGE_MODE = {1: "mag", 2: "maxnorm", 3: "angle", 5: "cosine"}  # models/gg_vae.py:57-63
+GG_VQ_VAE_EDGE_MODE = {"v1": None, "v2": "signed_mse", "v3": "mag", "v4": "maxnorm", "v5": "angle", "v6": "masked",
+                       "v7": "cosine"}  # models/gg_vq_vae.py:65-88
+
+
 def losses_gg_vae(x, out, cfg):
     """models/gg_vae.py:222-251 -- order reconstruction, gradient_guided, edge_matching, kld."""
     fn, _ = O.resolve_objective(cfg.get("recons_objective", "mse"), cfg.get("recons_activation"))
     lw = cfg["lambda_weights"]
     r = lw["reconstruction_loss"] * fn(x, out["recons"])
     gg = lw["gradient_guided_loss"] * edge_weighted_pixel_loss(x, out["recons"])
-    em = lw["edge_matching_loss"] * edge_matching_loss(x, out["recons"])
+    mode = GG_VAE_EDGE_MODE.get(cfg.get("edge_matching_version", 1), "mag")
+    em = lw["edge_matching_loss"] * edge_matching_variant(x, out["recons"], mode)
     k = lw["kld_loss"] * O.kl_divergence(out["mu"], out["log_var"])
     return OrderedDict(reconstruction_loss=r, gradient_guided_loss=gg, edge_matching_loss=em, kld_loss=k, total_loss=r + gg + em + k)
 
 
 def losses_gg_vq_vae(x, out, cfg):
-    """models/gg_vq_vae.py (version v1) through VQVAE.loss_function (models/vq_vae.py:367-391): objectives order
-    reconstruction, embedding, commitment, gradient_guided."""
+    """models/gg_vq_vae.py through VQVAE.loss_function (models/vq_vae.py:367-391): objectives order reconstruction,
+    embedding, commitment, gradient_guided[, edge_matching for versions v2..v7]."""
     fn, _ = O.resolve_objective(cfg.get("recons_objective", "mse"), cfg.get("recons_activation"))
     lw = cfg["lambda_weights"]
-    r = lw["reconstruction_loss"] * fn(x, out["recons"])
-    e = lw["embedding_loss"] * out["embedding_loss"]
-    c = lw["commitment_loss"] * out["commitment_loss"]
-    gg = lw["gradient_guided_loss"] * edge_weighted_pixel_loss(x, out["recons"])
-    return OrderedDict(reconstruction_loss=r, embedding_loss=e, commitment_loss=c, gradient_guided_loss=gg, total_loss=r + e + c + gg)
+    ld = OrderedDict()
+    ld["reconstruction_loss"] = lw["reconstruction_loss"] * fn(x, out["recons"])
+    ld["embedding_loss"] = lw["embedding_loss"] * out["embedding_loss"]
+    ld["commitment_loss"] = lw["commitment_loss"] * out["commitment_loss"]
+    ld["gradient_guided_loss"] = lw["gradient_guided_loss"] * edge_weighted_pixel_loss(x, out["recons"])
+    mode = GG_VQ_VAE_EDGE_MODE[cfg.get("version", "v1")]
+    if mode is not None:
+        ld["edge_matching_loss"] = lw["edge_matching_loss"] * edge_matching_variant(x, out["recons"], mode)
+    ld["total_loss"] = sum(ld.values())
+    return ld
 
 
 def losses_gg_vq_vae2(x, out, cfg):
@@ -628,7 +675,20 @@ def default_lambda_weights(arch, batch_size, dataset_size):
     }[arch]
 
 
+def canonical_arch(arch):
+    """models/__init__.py:155-178: `gg_vae_vN` / `gg_vq_vae_vN` select one class plus a version argument."""
+    if arch.startswith("gg_vae_v"):
+        return "gg_vae", dict(edge_matching_version=int(arch[len("gg_vae_v"):]))
+    if arch.startswith("gg_vq_vae_v"):
+        return "gg_vq_vae", dict(version=arch[len("gg_vq_vae_"):])
+    return arch, {}
+
+
 def make_cfg(arch, input_size, batch_size, dataset_size, **kw):
+    arch, extra = canonical_arch(arch)
+    kw = dict(extra, **kw)
+    if arch == "gg_vq_vae" and kw.get("version", "v1") != "v1" and "lambda_weights" not in kw:
+        kw["lambda_weights"] = dict(default_lambda_weights(arch, batch_size, dataset_size), edge_matching_loss=1.0)
     cfg = dict(arch=arch, input_size=input_size, in_channels=3, batch_size=batch_size,
                dataset_size=dataset_size, recons_objective="mse", recons_activation=None)
     cfg.update(kw)

@@ -334,6 +334,46 @@ def gg_vae_fixture():
                    dict(embedding_dim=8, num_embeddings=16, hidden_dims=[8, 16], num_residual_layers=2))
     _model_fixture("gg_vq_vae2_tiny", "gg_vq_vae2", 77, 2, 32,
                    dict(embedding_dim=8, num_embeddings=16, hidden_dims=[16, 32], num_residual_layers=2))
+    # two versioned archs end to end (the objective order / K = 5 plumbing); every variant's arithmetic is in edge_variants.npz
+    _model_fixture("gg_vq_vae_v4_tiny", "gg_vq_vae_v4", 91, 3, 16,
+                   dict(embedding_dim=8, num_embeddings=16, hidden_dims=[8, 16], num_residual_layers=2))
+    _model_fixture("gg_vae_v5_tiny", "gg_vae_v5", 93, 4, 16, dict(latent_dim=8, hidden_dims=[8, 16]))
+    edge_variants_fixture()
+
+
+def edge_variants_fixture():
+    """Every edge-matching variant of models/gg_vae.py and models/gg_vq_vae.py on one random (inputs, recons) pair: the loss and
+    its gradient w.r.t. recons, computed by the reference's own methods."""
+    from models.gg_vae import GGVAE
+    from models.gg_vq_vae import GGVQVAE
+
+    torch.manual_seed(5)
+    vq = GGVQVAE(in_channels=3, embedding_dim=4, num_embeddings=8, hidden_dims=[4, 8], num_residual_layers=1, input_size=16,
+                 version="v2")
+    va = GGVAE(latent_dim=4, input_size=16, in_channels=3, hidden_dims=[4, 8])
+    gen = torch.Generator().manual_seed(6)
+    x = torch.rand(3, 3, 12, 10, generator=gen)
+    out = {"x": _np(x)}
+    # "flat" recons has constant patches: exactly-zero Sobel responses (the clamp branches of normalize / cosine_similarity)
+    cases = {"rand": torch.rand(3, 3, 12, 10, generator=gen) * 1.4 - 0.2, "far": torch.rand(3, 3, 12, 10, generator=gen) * 6 - 3}
+    flat = cases["rand"].clone()
+    flat[:, :, 2:8, 3:9] = 0.25
+    methods = {"signed_mse": vq.edge_matching_loss_v1, "mag": vq.edge_matching_loss_v2, "maxnorm": vq.edge_matching_loss_v3,
+               "angle": vq.edge_matching_loss_v4, "masked": vq.edge_matching_loss_v5, "cosine": vq.edge_matching_loss_v6,
+               "gg_vae.mag": va.edge_matching_loss, "gg_vae.maxnorm": va.edge_matching_loss_v2, "gg_vae.angle": va.edge_matching_loss_v3,
+               "gg_vae.cosine": va.edge_matching_loss_v5}
+    for cname, r in list(cases.items()) + [("flat", flat)]:
+        out[f"{cname}.recons"] = _np(r)
+        for mname, fn in methods.items():
+            if cname == "flat" and mname.split(".")[-1] in ("angle", "cosine"):
+                continue  # atan2 / the 1e-12 clamp give NaN / 1e20-scale gradients there: not a numerical fixture
+            rr = r.clone().requires_grad_(True)
+            loss = fn(x, rr)
+            (g,) = torch.autograd.grad(loss, rr)
+            out[f"{cname}.{mname}.loss"] = _np(loss)
+            out[f"{cname}.{mname}.grad"] = _np(g)
+    np.savez_compressed(os.path.join(HERE, "edge_variants.npz"), **out)
+    print("edge_variants.npz", len(out))
 
 
 # --------------------------------------------------------------------------------------

@@ -88,7 +88,11 @@ def test_factory_errors_and_quirks(pkg):
     with pytest.raises(ValueError):
         get_network(32, 3, Args(arch="nope", batch_size=1, dataset_size=1), None)
     with pytest.raises(NotImplementedError):
-        get_network(32, 3, Args(arch="gg_vq_vae_v3", batch_size=1, dataset_size=1), None)
+        get_network(32, 3, Args(arch="gg_vq_vae_v8", batch_size=1, dataset_size=1), None)  # step-function loss: no gradient
+    with pytest.raises(NotImplementedError):
+        get_network(32, 3, Args(arch="gg_vae_v6", batch_size=1, dataset_size=1), None)  # broken in the reference itself
+    with pytest.raises(ValueError):
+        get_network(32, 3, Args(arch="gg_vae_v4", batch_size=1, dataset_size=1), None)  # not in the reference's factory
     with pytest.raises(ValueError):
         VAE(latent_dim=4, hidden_dims=[4], input_size=8, lambda_weights=[1.0])
     with pytest.raises(ValueError):

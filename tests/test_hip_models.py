@@ -8,7 +8,8 @@ from conftest import cfg_from_meta, load_golden, meta_of
 
 pytestmark = pytest.mark.gpu
 
-TINY = ["vae_tiny", "vae_tiny_bce", "vae_1x1", "vq_vae_tiny", "vq_vae2_tiny", "betatc_vae_tiny", "gg_vae_tiny", "gg_vq_vae_tiny", "gg_vq_vae2_tiny"]
+TINY = ["vae_tiny", "vae_tiny_bce", "vae_1x1", "vq_vae_tiny", "vq_vae2_tiny", "betatc_vae_tiny", "gg_vae_tiny", "gg_vq_vae_tiny", "gg_vq_vae2_tiny",
+        "gg_vq_vae_v4_tiny", "gg_vae_v5_tiny"]
 
 
 class Args:
@@ -282,6 +283,39 @@ def test_full_size_configs_step0(tag, gpu_device):
         if not np.isclose(got, l2, rtol=2e-2, atol=1e-6):
             bad.append((n, got, l2))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("arch", ["gg_vae_v2", "gg_vae_v3", "gg_vq_vae_v2", "gg_vq_vae_v3", "gg_vq_vae_v5", "gg_vq_vae_v6",
+                                  "gg_vq_vae_v7"])
+def test_versioned_gg_archs_loss_dicts_match_oracle(arch, gpu_device):
+    """The versioned gradient-guided archs without a model fixture of their own: the factory's version plumbing, the
+    objective order and every component loss vs oracle.nets on the HIP model's own forward outputs, then one aggregated
+    step (UPGrad over K = 4 / 5 rows) that must leave finite parameters."""
+    import movae_amd  # noqa: F401
+    from movae_amd import aggregation, autojac
+    from movae_amd.models import get_network
+    from oracle import nets as ON
+
+    kw = dict(latent_dim=8, hidden_dims=[8, 16]) if arch.startswith("gg_vae") else dict(
+        embedding_dim=8, num_embeddings=16, hidden_dims=[8, 16], num_residual_layers=2)
+    torch.manual_seed(3)
+    net = get_network(16, 3, Args(arch=arch, batch_size=4, dataset_size=1000, recons_objective="mse", recons_activation=None,
+                                  loss_weights=None, **kw), torch.device("cuda")).to(gpu_device).train()
+    x = torch.rand(4, 3, 16, 16, generator=torch.Generator().manual_seed(4)).to(gpu_device)
+    out = net(x)
+    ld = net.loss_function(x, args=out)
+    cfg = ON.make_cfg(arch, 16, 4, 1000, **kw)
+    out_cpu = {k: v.detach().cpu() for k, v in out.items() if isinstance(v, torch.Tensor)}
+    want = ON.ARCHS[cfg["arch"]]["losses"](x.cpu(), out_cpu, cfg)
+    assert list(ld.keys()) == list(want.keys()) and set(want.keys()) == set(net.objectives.keys()) | {"total_loss"}
+    for k, v in want.items():
+        np.testing.assert_allclose(ld[k].item(), v.item(), rtol=3e-5, atol=1e-7, err_msg=k)
+    comp = [v for k, v in ld.items() if k != "total_loss"]
+    autojac.mtl_backward(losses=comp, features=[out[f] for f in net.features], aggregator=aggregation.UPGrad(), retain_graph=True)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    opt.step()
+    for n, p in net.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all() and torch.isfinite(p).all(), n
 
 
 GRAPH_CASES = {

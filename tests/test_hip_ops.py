@@ -1,5 +1,7 @@
 """Parity of every HIP kernel family (through the C ABI via mo-vae_amd/ops.py) against plain
 PyTorch fp32 on the CPU and against the oracle / golden vectors.  GPU only."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -602,6 +604,40 @@ def test_sobel_edge_losses(M, shape):
         got.backward()
         np.testing.assert_allclose(got.item(), want.item(), rtol=2e-5, atol=1e-7, err_msg=name)
         close(back(rg.grad), rr.grad, name + " grad", rtol=2e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("mode", ["mag", "signed_mse", "maxnorm", "angle", "masked", "cosine"])
+@pytest.mark.parametrize("case", ["rand", "far", "flat"])
+def test_edge_matching_variants(M, mode, case):
+    """Every `enum movae_edge_match` variant vs the reference's own numbers (tests/golden/edge_variants.npz: GGVQVAE /
+    GGVAE methods on one (inputs, recons) pair) and vs the oracle on a ragged shape; "far" leaves the quadratic zone of the
+    smooth-L1, "flat" has exactly-zero Sobel responses (the max-normalised variant's tie handling, the masked variant)."""
+    ops, _ = M
+    from oracle import nets as ON
+
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "edge_variants.npz"))
+    key = f"{case}.{mode}"
+    if key + ".loss" not in fx.files:
+        pytest.skip("atan2 / clamp branches at exactly-zero responses give NaN / 1e20-scale gradients in the reference")
+    x, r = torch.from_numpy(fx["x"]), torch.from_numpy(fx[f"{case}.recons"])
+    rg = nhwc(r)
+    got = ops.edge_matching_loss(rg, x.permute(0, 2, 3, 1).contiguous().cuda(), 1.0, mode)
+    got.backward()
+    # the angle variant's smooth-L1 argument sits near +-pi: a last-bit atan2 difference moves single elements only
+    np.testing.assert_allclose(got.item(), fx[key + ".loss"], rtol=3e-5, atol=1e-7, err_msg=key)
+    close(back(rg.grad), torch.from_numpy(fx[key + ".grad"]), key + " grad", rtol=5e-4, atol=3e-6)
+    if "gg_vae." + mode in {k.split(".", 1)[1].rsplit(".", 1)[0] for k in fx.files if k.startswith(case + ".gg_vae.")}:
+        np.testing.assert_allclose(got.item(), fx[f"{case}.gg_vae.{mode}.loss"], rtol=3e-5, atol=1e-7)
+    # ragged shape, non-unit scale, against the oracle
+    x2, r2 = rnd(2, 3, 7, 5, seed=41) * 0.5, rnd(2, 3, 7, 5, seed=42) * 0.5
+    rr = r2.clone().requires_grad_(True)
+    want = 0.6 * ON.edge_matching_variant(x2, rr, mode)
+    want.backward()
+    rg2 = nhwc(r2)
+    got2 = ops.edge_matching_loss(rg2, x2.permute(0, 2, 3, 1).contiguous().cuda(), 0.6, mode)
+    got2.backward()
+    np.testing.assert_allclose(got2.item(), want.item(), rtol=3e-5, atol=1e-7, err_msg=mode)
+    close(back(rg2.grad), rr.grad, mode + " grad (ragged)", rtol=5e-4, atol=3e-6)
 
 
 def test_invalid_arguments_raise(M):

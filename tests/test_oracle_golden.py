@@ -9,7 +9,8 @@ from oracle import aggregation as A
 from oracle import nets, objectives as O
 from oracle.step import OracleTrainer
 
-TINY = ["vae_tiny", "vae_tiny_bce", "vae_1x1", "vq_vae_tiny", "vq_vae2_tiny", "betatc_vae_tiny", "gg_vae_tiny", "gg_vq_vae_tiny", "gg_vq_vae2_tiny"]
+TINY = ["vae_tiny", "vae_tiny_bce", "vae_1x1", "vq_vae_tiny", "vq_vae2_tiny", "betatc_vae_tiny", "gg_vae_tiny", "gg_vq_vae_tiny", "gg_vq_vae2_tiny",
+        "gg_vq_vae_v4_tiny", "gg_vae_v5_tiny"]
 
 
 def T(a):
@@ -302,3 +303,27 @@ def test_full_size_step0_scalars():
         for n, g in grads.items():
             s, l2 = fx[f"{tag}.g.{n}"]
             np.testing.assert_allclose(g.double().norm().item(), l2, rtol=1e-3, atol=1e-6, err_msg=n)
+
+
+EDGE_MODES = ["mag", "signed_mse", "maxnorm", "angle", "masked", "cosine"]
+
+
+@pytest.mark.parametrize("case", ["rand", "far", "flat"])
+def test_edge_matching_variants_match_reference_methods(case):
+    """oracle.nets.edge_matching_variant vs the reference's GGVQVAE.edge_matching_loss_v1..v6 and GGVAE.edge_matching_loss
+    [_v2/_v3/_v5] (tests/golden/edge_variants.npz): loss and gradient w.r.t. the reconstruction."""
+    fx = load_golden("edge_variants")
+    x, r = torch.from_numpy(fx["x"]), torch.from_numpy(fx[f"{case}.recons"])
+    seen = 0
+    for mode in EDGE_MODES:
+        for prefix in ("", "gg_vae."):
+            key = f"{case}.{prefix}{mode}"
+            if key + ".loss" not in fx.files:
+                continue
+            rr = r.clone().requires_grad_(True)
+            loss = nets.edge_matching_variant(x, rr, mode)
+            (g,) = torch.autograd.grad(loss, rr)
+            np.testing.assert_allclose(loss.item(), fx[key + ".loss"], rtol=1e-6, err_msg=key)
+            np.testing.assert_allclose(g.numpy(), fx[key + ".grad"], rtol=1e-5, atol=1e-9, err_msg=key)
+            seen += 1
+    assert seen >= (6 if case == "flat" else 10)
