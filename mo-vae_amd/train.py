@@ -229,17 +229,42 @@ def train_epoch(net, train_loader, optimizer, aggregator, step, device, args, dp
 
 @torch.no_grad()
 def evaluate(net, loader, device, args):
-    """main.py:238-332, losses and codebook usage only."""
+    """main.py:238-332 -- losses and codebook usage over a whole loader.  Same meters as the reference (one update per
+    batch, un-weighted, `total_loss` included; codebook usage = distinct codes seen over ALL batches, the two VQ-VAE-2
+    codebooks averaged), but nothing leaves the device inside the loop: the reference reads every loss with `.item()`
+    and concatenates every batch's indices on the host; here each batch appends one stacked loss row and ORs its codes
+    into a K-entry device mask, and the host reads both once at the end."""
     net.eval()
     meters = {k: AverageMeter() for k in net.objectives.keys()}
     meters["total_loss"] = AverageMeter()
+    rows, keys = [], None
+    used = {}  # output key -> bool[K] on the device
+
+    def mark(name, inds, K):
+        if name not in used:
+            used[name] = torch.zeros(K, dtype=torch.bool, device=inds.device)
+        used[name][inds.reshape(-1)] = True
+
     for images, _ in loader:
         images = images.to(device)
         out = net(images)
         ld = net.loss_function(images, args=out)
-        vals = torch.stack([ld[k].detach() for k in meters]).cpu().tolist()
-        for k, v in zip(meters, vals):
-            meters[k].update(v, n=images.size(0))
+        if keys is None:
+            keys = list(ld.keys())
+        rows.append(torch.stack([ld[k].detach().float().reshape(()) for k in keys]))
+        if out.get("encoding_inds") is not None and hasattr(net, "vq_layer"):
+            mark("encoding_inds", out["encoding_inds"], net.vq_layer.K)
+        elif out.get("encoding_inds_top") is not None and out.get("encoding_inds_bottom") is not None and hasattr(net, "vq_top"):
+            mark("encoding_inds_top", out["encoding_inds_top"], net.vq_top.K)
+            mark("encoding_inds_bottom", out["encoding_inds_bottom"], net.vq_top.K)  # main.py:296 takes K from vq_top for both
+    if rows:
+        for vals in torch.stack(rows).cpu().tolist():
+            for k, v in zip(keys, vals):
+                meters[k].update(v)
+    if used:
+        usage = AverageMeter()
+        usage.update(sum(float(m.sum().item()) / m.numel() * 100.0 for m in used.values()) / len(used))
+        meters["codebook_usage_percentage"] = usage
     return meters
 
 

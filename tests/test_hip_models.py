@@ -318,6 +318,59 @@ def test_versioned_gg_archs_loss_dicts_match_oracle(arch, gpu_device):
         assert p.grad is not None and torch.isfinite(p.grad).all() and torch.isfinite(p).all(), n
 
 
+@pytest.mark.parametrize("tag", ["vq_vae_tiny", "vq_vae2_tiny", "gg_vq_vae_v4_tiny", "vae_tiny"])
+def test_evaluate_matches_reference_loop_semantics(tag, gpu_device):
+    """train.evaluate vs main.py:238-332 restated on the oracle: one un-weighted meter update per batch (ragged last batch
+    included), `total_loss` among the meters, codebook usage = distinct codes over ALL batches (VQ-VAE-2: mean of the two
+    codebooks).  parity unpinned: main.py cannot be imported here (wandb / pymoo / torchjd), so the loop itself is a
+    restatement; the per-batch numbers it feeds on are the golden-pinned oracle's."""
+    import movae_amd  # noqa: F401
+    from movae_amd import train
+    from oracle import nets as ON
+    from oracle.step import OracleTrainer
+
+    fx = load_golden(tag)
+    net, m = build(fx)
+    net = net.to(gpu_device)
+    cfg = ON.make_cfg(**cfg_from_meta(m))
+    tr = OracleTrainer(cfg, seed=int(m["seed"]))
+    tr.load_state({k: v.cpu() for k, v in net.state_dict().items()})
+    size = int(m["input_size"])
+    xs = torch.rand(11, 3, size, size, generator=torch.Generator().manual_seed(9))
+    loader = [(xs[0:4], None), (xs[4:8], None), (xs[8:11], None)]
+    if "eps.0" in fx.files:  # eval mode of the VAE family still samples (models/vae.py reparameterize): pin the draw
+        eps = torch.randn(4, cfg["latent_dim"], generator=torch.Generator().manual_seed(10))
+    want = {}
+    seen = {}
+    for xb, _ in loader:
+        if "eps.0" in fx.files:
+            net.eps_override = eps[: xb.size(0)].to(gpu_device)
+        with torch.no_grad():
+            out, ld = tr.forward(xb, eps[: xb.size(0)] if "eps.0" in fx.files else None, train=False)
+        for k, v in ld.items():
+            want.setdefault(k, []).append(float(v))
+        for k in ("encoding_inds", "encoding_inds_top", "encoding_inds_bottom"):
+            if k in out:
+                seen.setdefault(k, set()).update(out[k].reshape(-1).tolist())
+    if "eps.0" in fx.files:
+        # one batch at a time so that each sees its own slice of the pinned draw
+        got = {}
+        for xb, _ in loader:
+            net.eps_override = eps[: xb.size(0)].to(gpu_device)
+            for k, mt in train.evaluate(net, [(xb, None)], gpu_device, None).items():
+                got.setdefault(k, []).append(mt.avg)
+        for k, v in want.items():
+            np.testing.assert_allclose(got[k], v, rtol=2e-4, atol=1e-6, err_msg=k)
+        return
+    meters = train.evaluate(net, loader, gpu_device, None)
+    assert set(want) | ({"codebook_usage_percentage"} if seen else set()) == set(meters)
+    for k, v in want.items():
+        assert meters[k].count == 3
+        np.testing.assert_allclose(meters[k].avg, np.mean(v), rtol=2e-4, atol=1e-6, err_msg=k)
+    K = cfg["num_embeddings"]
+    np.testing.assert_allclose(meters["codebook_usage_percentage"].avg, np.mean([len(s) / K * 100.0 for s in seen.values()]), rtol=1e-6)
+
+
 GRAPH_CASES = {
     "vae": dict(latent_dim=16, hidden_dims=[16, 32, 64], aggregator="upgrad", max_grad_norm=None),
     "vae_clip": dict(arch="vae", latent_dim=16, hidden_dims=[16, 32, 64], aggregator="upgrad", max_grad_norm=0.5),
