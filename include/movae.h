@@ -219,6 +219,16 @@ int movae_weights_mgda_stable(const float* G, int k, int norm, const float* loss
                               float min_eigenvalue, float* w, int32_t* info, movae_stream_t stream);
 /* Aligned-MTL (utils/torchmoo/aligned_mtl.py:97-133) */
 int movae_weights_amtl(const float* G, int k, int scale_mode, const float* pref, float* w, movae_stream_t stream);
+/* torchjd aggregators that main.py:1196-1222 also offers (third-party torchjd @ main, absent from the reference tree:
+ * restated from the published algorithms, parity unpinned):
+ *   DualProj  one dual-cone projection of the preference vector (default mean weights) on the trace-normalised,
+ *             regularised Gramian -- movae_weights_upgrad's QP solved once;
+ *   PCGrad    gradient surgery on the Gramian; perm = K rows of a permutation of 0..K-1 (int32, device), row i is the
+ *             order in which task i is de-conflicted against the others (the reference: torch.randperm per task);
+ *   IMTL-G    w = pinv(G) d / sum(pinv(G) d), d_i = sqrt(G_ii); zeros when the sum vanishes. */
+int movae_weights_dualproj(const float* G, int k, float norm_eps, float reg_eps, const float* pref, float* w, movae_stream_t stream);
+int movae_weights_pcgrad(const float* G, int k, const int32_t* perm, float* w, movae_stream_t stream);
+int movae_weights_imtlg(const float* G, int k, float* w, movae_stream_t stream);
 /* constant weightings (torchjd Sum / Mean) */
 int movae_weights_const(int k, float value, float* w, movae_stream_t stream);
 /* g[m] (+)= sum_i w[i] J[i][:]  ; also usable as the hook's J.T @ w (main.py:112-118) */

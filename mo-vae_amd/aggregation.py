@@ -290,6 +290,73 @@ class Sum(GramianWeightedAggregator):
         super().__init__(_ConstWeighting(False))
 
 
+# ---- torchjd's other Gramian weightings offered by main.py:1196-1222 ---------------------------------------------------
+# torchjd is a third-party dependency pinned to "main" (requirements.txt:58) and absent from the reference tree; these
+# follow the published algorithms (oracle/aggregation.py restates them too) -- parity unpinned.
+class DualProjWeighting(Weighting):
+    def __init__(self, pref_vector=None, norm_eps=1e-4, reg_eps=1e-4):
+        super().__init__()
+        self.pref_vector, self.norm_eps, self.reg_eps = pref_vector, norm_eps, reg_eps
+
+    def forward(self, G):
+        k = G.shape[0]
+        w = torch.empty(k, dtype=torch.float32, device=G.device)
+        pref = _pref_tensor(self.pref_vector, G.device)
+        L.call("movae_weights_dualproj", G.data_ptr(), k, float(self.norm_eps), float(self.reg_eps), L.ptr(pref), w.data_ptr(), _st(G))
+        return w
+
+
+class DualProj(GramianWeightedAggregator):
+    """torchjd.aggregation.DualProj(pref_vector, norm_eps, reg_eps) as constructed at main.py:1220-1221."""
+
+    def __init__(self, pref_vector=None, norm_eps=0.0001, reg_eps=0.0001, solver="quadprog"):
+        super().__init__(DualProjWeighting(pref_vector, norm_eps, reg_eps))
+        self._pref_vector, self._norm_eps, self._reg_eps = pref_vector, norm_eps, reg_eps
+
+    def __repr__(self):
+        return f"DualProj(pref_vector={self._pref_vector!r}, norm_eps={self._norm_eps}, reg_eps={self._reg_eps}, solver='quadprog')"
+
+
+class PCGradWeighting(Weighting):
+    """The K task orders are drawn with torch.randperm on the host generator, one per task per call, exactly where the
+    reference draws them -- a seeded run sees the same orders; like PNUPGrad it is therefore not hipGraph-replayable."""
+
+    def forward(self, G):
+        k = G.shape[0]
+        perm = torch.stack([torch.randperm(k) for _ in range(k)]).to(dtype=torch.int32).to(G.device)
+        w = torch.empty(k, dtype=torch.float32, device=G.device)
+        L.call("movae_weights_pcgrad", G.data_ptr(), k, perm.data_ptr(), w.data_ptr(), _st(G))
+        return w
+
+
+class PCGrad(GramianWeightedAggregator):
+    """torchjd.aggregation.PCGrad() as constructed at main.py:1196-1197."""
+
+    def __init__(self):
+        super().__init__(PCGradWeighting())
+
+    def __repr__(self):
+        return "PCGrad()"
+
+
+class IMTLGWeighting(Weighting):
+    def forward(self, G):
+        k = G.shape[0]
+        w = torch.empty(k, dtype=torch.float32, device=G.device)
+        L.call("movae_weights_imtlg", G.data_ptr(), k, w.data_ptr(), _st(G))
+        return w
+
+
+class IMTLG(GramianWeightedAggregator):
+    """torchjd.aggregation.IMTLG() as constructed at main.py:1207-1208."""
+
+    def __init__(self):
+        super().__init__(IMTLGWeighting())
+
+    def __repr__(self):
+        return "IMTLG()"
+
+
 def beta_schedule(epoch, total_epochs, k=1.0, a=1.0, l=0.01, u=1.0):
     """utils/torchmoo/comfort.py:20-66."""
     import math
@@ -341,7 +408,7 @@ class COMFORT:
                 f"beta_a={self._beta_a}, beta_l={self._beta_l}, beta_u={self._beta_u})")
 
 
-OUT_OF_SCOPE = ("pcgrad", "imtlg", "cagrad", "nashmtl", "dualproj")
+OUT_OF_SCOPE = ("cagrad", "nashmtl")  # both need a conic solver (cvxpy + clarabel / ECOS in torchjd) per step
 
 
 def make_aggregator(args):
@@ -378,9 +445,15 @@ def make_aggregator(args):
                        mgda_max_iters=args.mgda_max_iters, mgda_min_eigenvalue_eps=getattr(args, "mgda_min_eigenvalue_eps", 1e-10),
                        beta_k=getattr(args, "comfort_beta_k", 1.0), beta_a=getattr(args, "comfort_beta_a", 1.0),
                        beta_l=getattr(args, "comfort_beta_l", 0.01), beta_u=getattr(args, "comfort_beta_u", 1.0))
+    if name == "pcgrad":
+        return PCGrad()
+    if name == "imtlg":
+        return IMTLG()
+    if name == "dualproj":
+        return DualProj(norm_eps=args.agg_norm_eps, reg_eps=args.agg_reg_eps)
     if name == "sum":
         return "sum"
     if name in OUT_OF_SCOPE:
         raise NotImplementedError(f"Aggregator {args.aggregator} exists in the reference but is outside this build's scope "
-                                  "(sum, upgrad, nupgrad, pnupgrad, comfort, mgda*, aligned_mtl*, mean, jd_sum); see DESIGN.md")
+                                  "(sum, upgrad, nupgrad, pnupgrad, comfort, mgda*, aligned_mtl*, mean, jd_sum, pcgrad, imtlg, dualproj); see DESIGN.md")
     raise ValueError(f"Aggregator {args.aggregator} not supported")

@@ -160,8 +160,10 @@ __global__ void similarity_final(const double* __restrict__ part, int nblk, floa
 // norm_mode: how the Gramian is normalised before the projection --
 //   0 trace (torchjd UPGrad), 1 min-L2-norm scaling (NUPGrad, utils/torchmoo/nupgrad.py:122-158),
 //   2 cosine (PNUPGrad's `normalize`, utils/torchmoo/pnupgrad.py:13-24)
+// dual != 0: torchjd DualProj -- ONE projection, of the whole preference vector u (default: the mean weights 1/K), instead of
+// one per row: w = u + argmin_{v >= 0} 1/2 v'Gv + (Gu)'v
 __global__ __launch_bounds__(64) void upgrad_k(const float* __restrict__ Gin, int K, int norm_mode, float norm_eps, float reg_eps,
-                                               const float* __restrict__ pref, float* __restrict__ wout) {
+                                               const float* __restrict__ pref, float* __restrict__ wout, int dual) {
     const int lane = threadIdx.x;
     double G[MAXK][MAXK];
     if (norm_mode == 0) {
@@ -194,10 +196,15 @@ __global__ __launch_bounds__(64) void upgrad_k(const float* __restrict__ Gin, in
     double wsum[MAXK];
     for (int i = 0; i < K; ++i) wsum[i] = 0.0;
     const int nsub = 1 << K;
-    for (int row = 0; row < K; ++row) {
+    for (int row = 0; row < (dual ? 1 : K); ++row) {
         const double ui = pref ? (double)pref[row] : 1.0 / K;
         double c[MAXK];
         for (int i = 0; i < K; ++i) c[i] = G[i][row] * ui;
+        if (dual)
+            for (int i = 0; i < K; ++i) {
+                c[i] = 0.0;
+                for (int j = 0; j < K; ++j) c[i] += G[i][j] * (pref ? (double)pref[j] : 1.0 / K);
+            }
         double cmax = 1.0;
         for (int i = 0; i < K; ++i) cmax = fmax(cmax, fabs(c[i]));
         double best_viol = 1e300;
@@ -261,7 +268,8 @@ __global__ __launch_bounds__(64) void upgrad_k(const float* __restrict__ Gin, in
                 for (int i = 0; i < K; ++i) best_v[i] = tmp[i];
             }
         }
-        for (int i = 0; i < K; ++i) wsum[i] += best_v[i] + (i == row ? ui : 0.0);
+        for (int i = 0; i < K; ++i)
+            wsum[i] += best_v[i] + (dual ? (pref ? (double)pref[i] : 1.0 / K) : (i == row ? ui : 0.0));
         (void)cmax;
     }
     if (lane == 0)
@@ -462,6 +470,60 @@ int launch_combine_k(const float* J, size_t ldj, size_t m, const float* w, float
         default: break;                                          \
     }
 
+// ---- torchjd PCGrad weighting (Yu et al. 2020, "Gradient Surgery"), on the Gramian --------------------------------
+// for each task i: walk the other tasks in the order perm[i][:], and whenever the running combination conflicts with
+// task j (gramian[j] . current < 0) subtract its projection: current[j] -= that inner product / G[j][j]; w = sum_i current.
+// The permutations come from the caller (the reference draws them with torch.randperm on the host).  K <= 8: one lane.
+__global__ __launch_bounds__(64) void pcgrad_k(const float* __restrict__ G, int K, const int32_t* __restrict__ perm,
+                                               float* __restrict__ wout) {
+    if (threadIdx.x != 0) return;
+    float w[MAXK];
+    for (int i = 0; i < K; ++i) w[i] = 0.f;
+    for (int i = 0; i < K; ++i) {
+        float cur[MAXK];
+        for (int q = 0; q < K; ++q) cur[q] = q == i ? 1.f : 0.f;
+        for (int t = 0; t < K; ++t) {
+            const int j = perm[i * K + t];
+            if (j == i || j < 0 || j >= K) continue;
+            float ip = 0.f;
+            for (int q = 0; q < K; ++q) ip += G[j * K + q] * cur[q];
+            if (ip < 0.f) cur[j] -= ip / G[j * K + j];
+        }
+        for (int q = 0; q < K; ++q) w[q] += cur[q];
+    }
+    for (int i = 0; i < K; ++i) wout[i] = w[i];
+}
+
+// ---- torchjd IMTL-G weighting (Liu et al. 2021) --------------------------------------------------------------------
+// v = pinv(G) d with d_i = ||row i|| = sqrt(G_ii); w = v / sum(v), or zeros when |sum(v)| < 1e-12.  The pseudo-inverse
+// goes through the Jacobi eigen-decomposition with torch.linalg.pinv's default cut-off (K * eps_f32 * largest).
+__global__ __launch_bounds__(64) void imtlg_k(const float* __restrict__ Gin, int K, float* __restrict__ wout) {
+    if (threadIdx.x != 0) return;
+    double A[MAXK][MAXK], V[MAXK][MAXK], d[MAXK], v[MAXK];
+    for (int i = 0; i < K; ++i)
+        for (int j = 0; j < K; ++j) {
+            A[i][j] = 0.5 * ((double)Gin[i * K + j] + (double)Gin[j * K + i]);
+            V[i][j] = i == j ? 1.0 : 0.0;
+        }
+    for (int i = 0; i < K; ++i) d[i] = sqrt(fmax((double)Gin[i * K + i], 0.0));
+    jacobi_eigh(A, V, K);
+    double lmax = 0.0;
+    for (int i = 0; i < K; ++i) lmax = fmax(lmax, fabs(A[i][i]));
+    const double cut = (double)K * 1.1920928955078125e-07 * lmax;
+    for (int i = 0; i < K; ++i) v[i] = 0.0;
+    for (int e = 0; e < K; ++e) {
+        if (fabs(A[e][e]) <= cut) continue;
+        double proj = 0.0;
+        for (int i = 0; i < K; ++i) proj += V[i][e] * d[i];
+        proj /= A[e][e];
+        for (int i = 0; i < K; ++i) v[i] += V[i][e] * proj;
+    }
+    double sum = 0.0;
+    for (int i = 0; i < K; ++i) sum += v[i];
+    for (int i = 0; i < K; ++i) wout[i] = fabs(sum) < 1e-12 ? 0.f : (float)(v[i] / sum);
+}
+
+
 }  // namespace
 
 extern "C" {
@@ -519,8 +581,32 @@ int movae_weights_upgrad_norm(const float* G, int k, int norm_mode, float norm_e
     MOVAE_CHECK_ARG(G && w, "movae_weights_upgrad: null pointer");
     MOVAE_CHECK_ARG(k >= 1 && k <= MAXK, "movae_weights_upgrad: k=%d outside 1..%d", k, MAXK);
     MOVAE_CHECK_ARG(norm_mode >= 0 && norm_mode <= 2, "movae_weights_upgrad: unknown normalisation %d", norm_mode);
-    hipLaunchKernelGGL(upgrad_k, dim3(1), dim3(64), 0, (hipStream_t)stream, G, k, norm_mode, norm_eps, reg_eps, pref, w);
+    hipLaunchKernelGGL(upgrad_k, dim3(1), dim3(64), 0, (hipStream_t)stream, G, k, norm_mode, norm_eps, reg_eps, pref, w, 0);
     MOVAE_CHECK_LAUNCH("upgrad");
+    return MOVAE_OK;
+}
+
+int movae_weights_dualproj(const float* G, int k, float norm_eps, float reg_eps, const float* pref, float* w, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(G && w, "movae_weights_dualproj: null pointer");
+    MOVAE_CHECK_ARG(k >= 1 && k <= MAXK, "movae_weights_dualproj: k=%d outside 1..%d", k, MAXK);
+    hipLaunchKernelGGL(upgrad_k, dim3(1), dim3(64), 0, (hipStream_t)stream, G, k, 0, norm_eps, reg_eps, pref, w, 1);
+    MOVAE_CHECK_LAUNCH("dualproj");
+    return MOVAE_OK;
+}
+
+int movae_weights_pcgrad(const float* G, int k, const int32_t* perm, float* w, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(G && w && perm, "movae_weights_pcgrad: null pointer");
+    MOVAE_CHECK_ARG(k >= 1 && k <= MAXK, "movae_weights_pcgrad: k=%d outside 1..%d", k, MAXK);
+    hipLaunchKernelGGL(pcgrad_k, dim3(1), dim3(64), 0, (hipStream_t)stream, G, k, perm, w);
+    MOVAE_CHECK_LAUNCH("pcgrad");
+    return MOVAE_OK;
+}
+
+int movae_weights_imtlg(const float* G, int k, float* w, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(G && w, "movae_weights_imtlg: null pointer");
+    MOVAE_CHECK_ARG(k >= 1 && k <= MAXK, "movae_weights_imtlg: k=%d outside 1..%d", k, MAXK);
+    hipLaunchKernelGGL(imtlg_k, dim3(1), dim3(64), 0, (hipStream_t)stream, G, k, w);
+    MOVAE_CHECK_LAUNCH("imtlg");
     return MOVAE_OK;
 }
 

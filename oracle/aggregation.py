@@ -107,6 +107,46 @@ def upgrad_weights(G, norm_eps=1e-4, reg_eps=1e-4, pref=None, norm="trace"):
     return W.sum(axis=0)
 
 
+# ---- torchjd DualProj / PCGrad / IMTL-G (main.py:1196-1222) -----------------------------------------------------------
+# third-party torchjd @ main (requirements.txt:58), absent from the reference tree: restated from the published algorithms
+# (DualProj: torchjd's `project_weights` applied once to the mean weights; PCGrad: Yu et al. 2020 on the Gramian with
+# torch.randperm task orders; IMTL-G: Liu et al. 2021, pinv(G) d normalised to sum 1).  parity unpinned.
+def dualproj_weights(G, norm_eps=1e-4, reg_eps=1e-4, pref=None):
+    Gd = np.asarray(G.detach().cpu().numpy() if isinstance(G, torch.Tensor) else G, dtype=np.float64)
+    K = Gd.shape[0]
+    tr = np.trace(Gd)
+    Gn = (np.zeros_like(Gd) if tr < norm_eps else Gd / tr) + reg_eps * np.eye(K)
+    u = np.full(K, 1.0 / K) if pref is None else np.asarray(pref, dtype=np.float64)
+    return _qp_lower_bounded(Gn, u)
+
+
+def pcgrad_weights(G):
+    """Draws K permutations from torch's global CPU generator, one per task, like torchjd's loop."""
+    Gt = torch.as_tensor(np.asarray(G), dtype=torch.float32)
+    K = Gt.shape[0]
+    weights = torch.zeros(K)
+    for i in range(K):
+        permutation = torch.randperm(K)
+        cur = torch.zeros(K)
+        cur[i] = 1.0
+        for j in permutation.tolist():
+            if j == i:
+                continue
+            ip = Gt[j] @ cur
+            if ip < 0.0:
+                cur[j] -= ip / Gt[j, j]
+        weights = weights + cur
+    return weights.numpy()
+
+
+def imtlg_weights(G):
+    Gt = torch.as_tensor(np.asarray(G), dtype=torch.float32)
+    d = torch.sqrt(torch.diagonal(Gt))
+    v = torch.linalg.pinv(Gt) @ d
+    vs = v.sum()
+    return (torch.zeros_like(v) if vs.abs() < 1e-12 else v / vs).numpy()
+
+
 # ---- MGDA (utils/torchmoo/mgda.py:221-367) ---------------------------------------------
 def mgda_weights(G, norm_type="none", losses=None, epsilon=1e-5, max_iters=250,
                  stable=False, min_eigenvalue_eps=1e-10, return_iters=False):
@@ -200,6 +240,12 @@ def make_weighting(name, **kw):
         nt = kw.get("mgda_norm_type", "none")
         return lambda G, losses=None: ((1.0 - beta) * np.asarray(mgda_weights(G, nt, losses, kw.get("epsilon", 1e-5), kw.get("max_iters", 250)),
                                                                   dtype=np.float64) + beta * upgrad_weights(G))
+    if n == "dualproj":
+        return lambda G, losses=None: dualproj_weights(G, kw.get("norm_eps", 1e-4), kw.get("reg_eps", 1e-4), kw.get("pref"))
+    if n == "pcgrad":
+        return lambda G, losses=None: pcgrad_weights(G)
+    if n == "imtlg":
+        return lambda G, losses=None: imtlg_weights(G)
     if n == "mean":
         return lambda G, losses=None: np.full(len(G), 1.0 / len(G))
     if n == "jd_sum":

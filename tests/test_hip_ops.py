@@ -448,12 +448,47 @@ def test_nupgrad_pnupgrad_comfort_aggregators(M):
     close(Cs(J.cuda()), torch.as_tensor(w, dtype=torch.float32) @ J, "comfort stable", rtol=5e-4)
 
 
+@pytest.mark.parametrize("case", ["k2", "k2_parallel", "k3", "k3_zero_row", "k4", "k4_conflict", "k5_rankdef"])
+def test_dualproj_pcgrad_imtlg_vs_oracle(M, case):
+    """torchjd's DualProj / PCGrad / IMTLG (main.py:1196-1222) vs the oracle's restatement (pinned only by torchjd's
+    published usage example, see test_oracle_golden): weights on the golden Gramians, PCGrad with the same seeded
+    torch.randperm draws, and the K = 2 usage example itself."""
+    _, agg = M
+    from oracle import aggregation as OA
+
+    fx = load_golden("weightings")
+    G = fx[f"{case}.G"]
+    Gd = torch.from_numpy(G).cuda()
+    scale = max(1.0, float(np.abs(G).max()))
+    want = OA.dualproj_weights(G)
+    np.testing.assert_allclose(agg.DualProjWeighting()(Gd).cpu().numpy(), want, rtol=2e-4, atol=1e-6 * max(1.0, np.abs(want).max()))
+    pref = np.linspace(0.5, 1.5, len(G))
+    want = OA.dualproj_weights(G, pref=pref)
+    np.testing.assert_allclose(agg.DualProjWeighting(pref_vector=torch.tensor(pref, dtype=torch.float32))(Gd).cpu().numpy(), want,
+                               rtol=2e-4, atol=1e-6 * max(1.0, np.abs(want).max()))
+    for seed in (0, 1, 2):
+        torch.manual_seed(seed)
+        want = OA.pcgrad_weights(G)
+        torch.manual_seed(seed)
+        np.testing.assert_allclose(agg.PCGradWeighting()(Gd).cpu().numpy(), want, rtol=1e-5, atol=1e-6)
+    want = OA.imtlg_weights(G)
+    got = agg.IMTLGWeighting()(Gd).cpu().numpy()
+    if np.linalg.matrix_rank(G.astype(np.float64), tol=len(G) * 1.2e-7 * np.linalg.norm(G, 2) * 10) == len(G):
+        np.testing.assert_allclose(got, want, rtol=5e-3, atol=1e-5 * scale)  # pinv amplifies fp32 noise by cond(G)
+    else:
+        assert np.isfinite(got).all() and abs(got.sum() - 1.0) < 1e-4 or not got.any()
+
+
 def test_aggregator_docstring_kats(M):
     """utils/torchmoo/mgda.py:54-86 and nupgrad.py:58-62."""
     _, agg = M
     J = torch.tensor([[-4.0, 1.0, 1.0], [6.0, 1.0, 1.0]]).cuda()
     np.testing.assert_allclose(agg.UPGrad()(J).cpu().numpy(), [0.2929, 1.9004, 1.9004], atol=5e-5)
     np.testing.assert_allclose(agg.MGDA()(J).cpu().numpy(), [0.0, 1.0, 1.0], atol=1e-5)
+    # torchjd's usage examples for the same matrix
+    np.testing.assert_allclose(agg.DualProj()(J).cpu().numpy(), [0.5563, 1.1109, 1.1109], atol=5e-5)
+    np.testing.assert_allclose(agg.PCGrad()(J).cpu().numpy(), [0.5848, 3.8012, 3.8012], atol=5e-5)
+    np.testing.assert_allclose(agg.IMTLG()(J).cpu().numpy(), [0.0767, 1.0, 1.0], atol=5e-5)
     np.testing.assert_allclose(agg.MGDA(norm_type="l2")(J).cpu().numpy(), [1.0, 1.0, 1.0], atol=1e-5)
     A = agg.MGDA(norm_type="loss")
     A.set_losses(torch.tensor([0.5, 2.0]).cuda())

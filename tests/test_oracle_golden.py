@@ -327,3 +327,20 @@ def test_edge_matching_variants_match_reference_methods(case):
             np.testing.assert_allclose(g.numpy(), fx[key + ".grad"], rtol=1e-5, atol=1e-9, err_msg=key)
             seen += 1
     assert seen >= (6 if case == "flat" else 10)
+
+
+def test_torchjd_dualproj_pcgrad_imtlg_usage_examples():
+    """torchjd's documented usage example J = [[-4, 1, 1], [6, 1, 1]] (the same matrix utils/torchmoo/mgda.py:54-86 and
+    nupgrad.py:58-62 quote for MGDA / UPGrad): DualProj -> [0.5563, 1.1109, 1.1109], PCGrad -> [0.5848, 3.8012, 3.8012],
+    IMTLG -> [0.0767, 1.0000, 1.0000].  The only published vectors for these three (torchjd is absent): parity unpinned
+    beyond them."""
+    from oracle import aggregation as OA
+
+    J = torch.tensor([[-4.0, 1.0, 1.0], [6.0, 1.0, 1.0]])
+    G = (J @ J.T).numpy()
+    for w, want in ((OA.dualproj_weights(G), [0.5563, 1.1109, 1.1109]), (OA.pcgrad_weights(G), [0.5848, 3.8012, 3.8012]),
+                    (OA.imtlg_weights(G), [0.0767, 1.0, 1.0])):
+        np.testing.assert_allclose((torch.as_tensor(w, dtype=torch.float32) @ J).numpy(), want, atol=5e-5)
+    # DualProj = the single-row case of the UPGrad projection; K = 1 degenerates to the mean weight
+    np.testing.assert_allclose(OA.dualproj_weights(np.array([[2.0]])), [1.0])
+    np.testing.assert_allclose(OA.imtlg_weights(np.zeros((3, 3))), np.zeros(3))
