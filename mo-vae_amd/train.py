@@ -105,7 +105,7 @@ class GraphedTrainStep:
 
     Data parallel (dp given): the step is two graphs around ONE eager collective --
     graph 1 = forward/backward + flatten of every gradient into a static flat bucket, then
-    `all_reduce(bucket)` over RCCL, then graph 2 = 1/N scaling + optimizer step on views of the bucket."""
+    `all_reduce(bucket)` over RCCL, then graph 2 = 1/N scaling + gradient clipping + optimizer step on views of the bucket."""
 
     def __init__(self, net, optimizer, aggregator, args, example, warmup=3, dp=None, record_calls=False):
         if not getattr(net, "graph_safe", False):
@@ -151,6 +151,8 @@ class GraphedTrainStep:
         self.graph2 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph2, pool=self.graph.pool()):
             self.flat.div_(dp.world_size)
+            if getattr(args, "max_grad_norm", None) is not None:  # same tail as train_step: clip the averaged gradient
+                clip_grad_norm_(params, max_norm=args.max_grad_norm)
             optimizer.step()
         self.graph2.replay()  # completes the step whose gradients were just reduced
 

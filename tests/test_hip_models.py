@@ -438,3 +438,56 @@ def test_hipgraph_replay_matches_eager_steps(case, gpu_device):
         np.testing.assert_allclose(q.detach().cpu().numpy(), p.detach().cpu().numpy(), err_msg=n, **tol)
     if "codebook_usage_percentage" in gs.outputs:  # a live LazyScalar over the graph's static counter
         assert 0.0 < float(gs.outputs["codebook_usage_percentage"]) <= 100.0
+
+
+def test_data_parallel_graphed_step_single_rank_rccl(gpu_device, monkeypatch):
+    """The N>1 code path of GraphedTrainStep (graph 1 -> eager RCCL all-reduce of the flat bucket -> graph 2 = 1/N,
+    gradient clipping, fused Adam) driven with ONE rank over the real RCCL backend: the mean over one rank is the
+    identity, so losses and parameters must equal the eager single-device loop, clipping included."""
+    import torch.distributed as dist
+
+    import movae_amd  # noqa: F401
+    from movae_amd import aggregation
+    from movae_amd.models import get_network
+    from movae_amd.parallel import DataParallelGrads
+    from movae_amd.train import GraphedTrainStep, make_optimizer, train_step
+
+    if dist.is_initialized():
+        pytest.skip("a process group is already up in this process")
+    monkeypatch.setenv("MOVAE_FORCE_DP", "1")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29577")
+
+    def make():
+        a = Args(arch="vae", batch_size=16, dataset_size=1000, recons_objective="mse", recons_activation=None, loss_weights=None,
+                 agg_norm_eps=1e-4, agg_reg_eps=1e-4, mgda_epsilon=1e-5, mgda_max_iters=250, pref_weights=None, optimizer="adam",
+                 lr=1e-3, wd=0, momentum=0.9, latent_dim=16, hidden_dims=[16, 32, 64], aggregator="upgrad", max_grad_norm=0.5)
+        torch.manual_seed(3)
+        net = get_network(32, 3, a, gpu_device).to(gpu_device).train()
+        net.eps_override = torch.randn(16, net.latent_dim, generator=torch.Generator().manual_seed(5)).to(gpu_device)
+        return net, a
+
+    g = torch.Generator().manual_seed(11)
+    batches = [torch.rand(16, 3, 32, 32, generator=g).to(gpu_device) for _ in range(3)]
+    net_e, a = make()
+    opt_e, agg_e = make_optimizer(net_e, a, capturable=True), aggregation.make_aggregator(a)
+    for _ in range(4):  # the DP twin runs 3 warm-up steps plus one real step while it builds its two graphs
+        train_step(net_e, batches[0], opt_e, agg_e, a)
+    want = [train_step(net_e, b, opt_e, agg_e, a)[0]["total_loss"].item() for b in batches]
+    dp = DataParallelGrads.from_env(backend="nccl")
+    try:
+        assert dp is not None and dp.world_size == 1
+        net_g, a2 = make()
+        dp.attach(net_g)
+        opt_g = make_optimizer(net_g, a2, capturable=True)
+        gs = GraphedTrainStep(net_g, opt_g, aggregation.make_aggregator(a2), a2, batches[0], dp=dp)
+        assert gs.graph2 is not None
+        got = [gs.step(b)[0]["total_loss"].item() for b in batches]
+        np.testing.assert_allclose(got, want, rtol=2e-5)
+        for (n, p), (_, q) in zip(net_g.named_parameters(), net_e.named_parameters()):
+            assert_close(p, q.detach().cpu().numpy(), "dp param " + n, rtol=2e-4, atol=2e-5)
+    finally:
+        dp.shutdown()
