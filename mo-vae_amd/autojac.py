@@ -244,8 +244,15 @@ def _aggregate_into_grads(jb, aggregator):
     return g
 
 
-def mtl_backward(losses, features, aggregator, tasks_params=None, shared_params=None, retain_graph=False,
-                 parallel_chunk_size=None):
+class _MtlState:
+    """What mtl_backward_begin hands to mtl_backward_finish: the Jacobian buffer and the per-loss feature cotangents."""
+    __slots__ = ("jb", "feat_diff", "feat_grads", "shared_params", "aggregator", "task_params")
+
+
+def mtl_backward_begin(losses, features, aggregator, tasks_params=None, shared_params=None):
+    """First half of mtl_backward: every loss is differentiated down to the features; the task-side parameters
+    (decoder, codebooks, ...) receive their final .grad here.  Nothing of the shared trunk has been touched yet, which
+    is what lets a data-parallel step start reducing the task-side gradients while mtl_backward_finish runs."""
     losses, features = list(losses), list(features)
     if len(losses) == 0:
         raise ValueError("`losses` cannot be empty")
@@ -257,17 +264,28 @@ def mtl_backward(losses, features, aggregator, tasks_params=None, shared_params=
         tasks_params = [_leaf_tensors([l], excluded=features) for l in losses]
     if len(tasks_params) != len(losses):
         raise ValueError("`losses` and `tasks_params` should have the same size.")
-    shared_params = list(shared_params)
-    jb = JacobianBuffer(shared_params, len(losses), features[0].device)
-    feat_diff = [f for f in features if f.requires_grad]
-    feat_grads = []
+    st = _MtlState()
+    st.shared_params = list(shared_params)
+    st.aggregator = aggregator
+    st.jb = JacobianBuffer(st.shared_params, len(losses), features[0].device)
+    st.feat_diff = [f for f in features if f.requires_grad]
+    st.feat_grads = []
+    st.task_params = []
     for i, (loss, tp) in enumerate(zip(losses, tasks_params)):
         tp = list(tp)
-        got = torch.autograd.grad(loss, tp + feat_diff, retain_graph=True, allow_unused=True)
+        got = torch.autograd.grad(loss, tp + st.feat_diff, retain_graph=True, allow_unused=True)
         for p, g in zip(tp, got[: len(tp)]):
             if g is not None:
                 _accumulate(p, g)
-        feat_grads.append(got[len(tp):])
+                st.task_params.append(p)
+        st.feat_grads.append(got[len(tp):])
+    return st
+
+
+def mtl_backward_finish(st):
+    """Second half: the K feature cotangents are pulled back through the shared trunk (batched), the Jacobian is
+    aggregated and the result lands in the shared parameters' .grad."""
+    jb, feat_diff, feat_grads, shared_params = st.jb, st.feat_diff, st.feat_grads, st.shared_params
     live_rows = [i for i, gf in enumerate(feat_grads) if any(g is not None for g in gf)]
     batched = BATCHED_VJP and shared_params and len(live_rows) > 1
     if batched:
@@ -289,11 +307,17 @@ def mtl_backward(losses, features, aggregator, tasks_params=None, shared_params=
             ops.GRAD_SINK.clear()
         jb.write_row(i, js)
     if shared_params:
-        _aggregate_into_grads(jb, aggregator)
+        _aggregate_into_grads(jb, st.aggregator)
+
+
+def mtl_backward(losses, features, aggregator, tasks_params=None, shared_params=None, retain_graph=False,
+                 parallel_chunk_size=None):
+    st = mtl_backward_begin(losses, features, aggregator, tasks_params, shared_params)
+    mtl_backward_finish(st)
     if not retain_graph:
         # torchjd frees the graph on the last differentiation; torch offers no explicit free, dropping
         # the references is enough for the caller's tensors to release their buffers
-        del jb
+        del st
 
 
 def backward(tensors, aggregator, inputs=None, retain_graph=False, parallel_chunk_size=None):

@@ -64,22 +64,35 @@ def print_gd_similarity(_, inputs, weights):
     _hook_values["similarity"] = aggregation.gd_similarity(inputs[0], weights)
 
 
-def forward_backward(net, images, optimizer, aggregator):
-    """zero_grad, forward, losses and the (aggregated) backward of one step (main.py:157-196)."""
+def forward_backward_begin(net, images, optimizer, aggregator):
+    """zero_grad, forward, losses and the backward down to the features (main.py:157-196, first half of torchjd's
+    mtl_backward).  Returns (loss_dict, outputs, pending): `pending` is None when the whole backward is already done
+    (sum / no features), else the state forward_backward_finish completes."""
     optimizer.zero_grad()
     outputs = net(images)
     loss_dict = net.loss_function(images, args=outputs)
     if aggregator is None or aggregator == "sum":
         loss_dict["total_loss"].backward()
-    else:
-        features = [outputs[f] for f in net.features] if net.features is not None else None
-        component_losses = [v for k, v in loss_dict.items() if k != "total_loss"]  # main.py:184
-        if isinstance(aggregator, (MGDA, COMFORT)):  # main.py:185
-            aggregator.set_losses(torch.stack([c.detach() for c in component_losses]))
-        if features is not None:
-            autojac.mtl_backward(losses=component_losses, features=features, aggregator=aggregator, retain_graph=True)
-        else:
-            autojac.backward(component_losses, aggregator=aggregator)
+        return loss_dict, outputs, None
+    features = [outputs[f] for f in net.features] if net.features is not None else None
+    component_losses = [v for k, v in loss_dict.items() if k != "total_loss"]  # main.py:184
+    if isinstance(aggregator, (MGDA, COMFORT)):  # main.py:185
+        aggregator.set_losses(torch.stack([c.detach() for c in component_losses]))
+    if features is None:
+        autojac.backward(component_losses, aggregator=aggregator)
+        return loss_dict, outputs, None
+    return loss_dict, outputs, autojac.mtl_backward_begin(component_losses, features, aggregator)
+
+
+def forward_backward_finish(pending):
+    if pending is not None:
+        autojac.mtl_backward_finish(pending)
+
+
+def forward_backward(net, images, optimizer, aggregator):
+    """zero_grad, forward, losses and the (aggregated) backward of one step (main.py:157-196)."""
+    loss_dict, outputs, pending = forward_backward_begin(net, images, optimizer, aggregator)
+    forward_backward_finish(pending)
     return loss_dict, outputs
 
 
@@ -96,6 +109,9 @@ def train_step(net, images, optimizer, aggregator, args, dp=None):
 
 
 
+DP_OVERLAP_MIN_BYTES = 32 << 20
+
+
 class GraphedTrainStep:
     """The whole optimisation step (forward, losses, K per-loss backward passes, Gram / solve / combine,
     optimizer) captured ONCE into a hipGraph and replayed per batch: the step is ~250 short kernels, so
@@ -103,9 +119,13 @@ class GraphedTrainStep:
     graph holds exactly the launches the eager step made.  The optimizer must keep its step counter on
     the device: make_optimizer(..., capturable=True) -> FusedAdam(device_step=True).
 
-    Data parallel (dp given): the step is two graphs around ONE eager collective --
-    graph 1 = forward/backward + flatten of every gradient into a static flat bucket, then
-    `all_reduce(bucket)` over RCCL, then graph 2 = 1/N scaling + gradient clipping + optimizer step on views of the bucket."""
+    Data parallel (dp given): the step is three graphs around two eager collectives over RCCL --
+    graph 1 = forward, losses and the backward down to the features, task-side gradients flattened into bucket A;
+    graph 1b = the shared trunk's batched pull-back + aggregation, flattened into bucket B, running while bucket A is
+    all-reduced on RCCL's stream; then all-reduce(B); graph 2 = gradient clipping + optimizer step on views of the
+    buckets (the 1/N rides in the collective: ncclAvg).  `--agg sum` has no second half: one bucket, one collective.
+    Gradients under DP_OVERLAP_MIN_BYTES keep the single-bucket form (the split's fixed cost exceeds what it hides);
+    MOVAE_DP_OVERLAP=0 / 1 forces either."""
 
     def __init__(self, net, optimizer, aggregator, args, example, warmup=3, dp=None, record_calls=False):
         if not getattr(net, "graph_safe", False):
@@ -141,28 +161,75 @@ class GraphedTrainStep:
             L.TRACE = None
         params = [p for p in net.parameters() if p.requires_grad]
         # the bucket handed to the collective is an ordinary allocation (not graph-pool memory)
-        self.flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=example.device)
+        self.flat = torch.zeros(sum(p.numel() for p in params) + 64, dtype=torch.float32, device=example.device)
+        # RCCL averages inside the collective (ncclAvg); gloo (CPU rehearsal of the N>1 path) has no AVG: sum, then scale
+        self._avg = dp.backend == "nccl"
+        # splitting the step costs one more graph launch and two cross-stream waits (~60 us measured on MI355X); it pays
+        # once the task-side bucket's exchange is longer than that, i.e. not for the 13 MB of the 32x32 VAEs
+        mode = os.environ.get("MOVAE_DP_OVERLAP", "auto")
+        overlap = mode == "1" or (mode == "auto" and self.flat.numel() * 4 >= DP_OVERLAP_MIN_BYTES)
         with torch.cuda.graph(self.graph):
-            self.loss_dict, self.outputs = forward_backward(net, self.static_x, optimizer, aggregator)
-            flatten_grads(params, out=self.flat)
-        self.graph.replay()  # the capture pass recorded but did not execute: materialise real gradients once
-        torch.distributed.all_reduce(self.flat)
-        unflatten_into_grads(self.flat, params)  # .grad := static views of the bucket, kept for every replay
+            self.loss_dict, self.outputs, pending = forward_backward_begin(net, self.static_x, optimizer, aggregator)
+            if pending is not None and overlap:
+                shared = {id(p) for p in pending.shared_params}
+                early = [p for p in params if p.grad is not None and id(p) not in shared]  # final already: task-side
+            else:
+                forward_backward_finish(pending)
+                pending, early = None, list(params)
+            n_early = sum(p.numel() for p in early)
+            self.flat_a = self.flat[:n_early]
+            flatten_grads(early, out=self.flat_a)
+        taken = {id(p) for p in early}
+        late = [p for p in params if id(p) not in taken]
+        self.graph_b, self.flat_b = None, None
+        if late:
+            off = (n_early + 63) // 64 * 64  # keep the second bucket 256-byte aligned
+            self.flat_b = self.flat[off: off + sum(p.numel() for p in late)]
+            self.graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_b, pool=self.graph.pool()):
+                forward_backward_finish(pending)
+                flatten_grads(late, out=self.flat_b)
+        # the capture passes recorded but did not execute: materialise real gradients once
+        self._reduced_replay()
+        unflatten_into_grads(self.flat_a, early)  # .grad := static views of the buckets, kept for every replay
+        if late:
+            unflatten_into_grads(self.flat_b, late)
         self.graph2 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph2, pool=self.graph.pool()):
-            self.flat.div_(dp.world_size)
+            if not self._avg:
+                self.flat.div_(dp.world_size)
             if getattr(args, "max_grad_norm", None) is not None:  # same tail as train_step: clip the averaged gradient
                 clip_grad_norm_(params, max_norm=args.max_grad_norm)
             optimizer.step()
         self.graph2.replay()  # completes the step whose gradients were just reduced
 
+    def reduce(self, buf=None, async_op=False):
+        """Mean over ranks of one flat gradient bucket, in place (the 1/N of gloo's sum happens in graph 2)."""
+        rop = torch.distributed.ReduceOp
+        return torch.distributed.all_reduce(self.flat_a if buf is None else buf, op=rop.AVG if self._avg else rop.SUM,
+                                            async_op=async_op)
+
+    def _reduced_replay(self):
+        """graph 1 -> all-reduce(task-side bucket) running under graph 1b (shared trunk: batched pull-back, Gram / solve /
+        combine) -> all-reduce(shared bucket).  The collectives go to RCCL's own stream (async_op) and the compute stream
+        waits for both only before the optimizer graph: the first bucket's exchange is hidden behind the second half
+        of the backward."""
+        self.graph.replay()
+        pending = [self.reduce(self.flat_a, async_op=True)]
+        if self.graph_b is not None:
+            self.graph_b.replay()
+            pending.append(self.reduce(self.flat_b, async_op=True))
+        for w in pending:
+            w.wait()
+
     def step(self, images):
         self.static_x.copy_(images, non_blocking=True)
         if hasattr(self.opt, "sync_hyper"):
             self.opt.sync_hyper()  # lr schedulers change the host value between replays
-        self.graph.replay()
-        if self.graph2 is not None:
-            torch.distributed.all_reduce(self.flat)
+        if self.graph2 is None:
+            self.graph.replay()
+        else:
+            self._reduced_replay()
             self.graph2.replay()
         return self.loss_dict, self.outputs
 

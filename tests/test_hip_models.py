@@ -440,10 +440,12 @@ def test_hipgraph_replay_matches_eager_steps(case, gpu_device):
         assert 0.0 < float(gs.outputs["codebook_usage_percentage"]) <= 100.0
 
 
-def test_data_parallel_graphed_step_single_rank_rccl(gpu_device, monkeypatch):
-    """The N>1 code path of GraphedTrainStep (graph 1 -> eager RCCL all-reduce of the flat bucket -> graph 2 = 1/N,
-    gradient clipping, fused Adam) driven with ONE rank over the real RCCL backend: the mean over one rank is the
-    identity, so losses and parameters must equal the eager single-device loop, clipping included."""
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_data_parallel_graphed_step_single_rank_rccl(overlap, gpu_device, monkeypatch):
+    """The N>1 code path of GraphedTrainStep driven with ONE rank over the real RCCL backend, in both forms: one bucket
+    (graph 1 -> all-reduce -> graph 2 = gradient clipping + fused Adam) and the overlapped two-bucket form (graph 1 ->
+    all-reduce(task side) under graph 1b -> all-reduce(shared) -> graph 2).  The mean over one rank is the identity, so
+    losses and parameters must equal the eager single-device loop, clipping included."""
     import torch.distributed as dist
 
     import movae_amd  # noqa: F401
@@ -455,6 +457,7 @@ def test_data_parallel_graphed_step_single_rank_rccl(gpu_device, monkeypatch):
     if dist.is_initialized():
         pytest.skip("a process group is already up in this process")
     monkeypatch.setenv("MOVAE_FORCE_DP", "1")
+    monkeypatch.setenv("MOVAE_DP_OVERLAP", overlap)
     monkeypatch.setenv("WORLD_SIZE", "1")
     monkeypatch.setenv("RANK", "0")
     monkeypatch.setenv("LOCAL_RANK", "0")
@@ -484,7 +487,7 @@ def test_data_parallel_graphed_step_single_rank_rccl(gpu_device, monkeypatch):
         dp.attach(net_g)
         opt_g = make_optimizer(net_g, a2, capturable=True)
         gs = GraphedTrainStep(net_g, opt_g, aggregation.make_aggregator(a2), a2, batches[0], dp=dp)
-        assert gs.graph2 is not None
+        assert gs.graph2 is not None and (gs.graph_b is not None) == (overlap == "1")
         got = [gs.step(b)[0]["total_loss"].item() for b in batches]
         np.testing.assert_allclose(got, want, rtol=2e-5)
         for (n, p), (_, q) in zip(net_g.named_parameters(), net_e.named_parameters()):
