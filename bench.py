@@ -37,7 +37,8 @@ CONFIGS = {
 }
 
 CONV_CALLS = {"movae_conv2d_fwd", "movae_conv2d_dgrad", "movae_conv2d_wgrad", "movae_convT2d_fwd", "movae_convT2d_dgrad",
-              "movae_convT2d_wgrad", "movae_conv2d_wgrad_grouped", "movae_convT2d_wgrad_grouped"}
+              "movae_convT2d_wgrad", "movae_conv2d_wgrad_grouped", "movae_convT2d_wgrad_grouped",
+              "movae_conv2d_dgrad_wgrad_grouped", "movae_convT2d_dgrad_wgrad_grouped"}
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 HBM_PEAK_GBS = 8000.0
 
@@ -49,6 +50,8 @@ class Args:
 
 def _geom_offset(name, a):
     """(index of `n` in the C-ABI argument tuple, cotangent groups) -- the grouped wgrads carry `groups` first."""
+    if "dgrad_wgrad" in name:  # (groups, dy, w, x, dx, dw[], dbias[], n, ...)
+        return 7, int(a[0])
     if name.endswith("_grouped"):
         return 5, int(a[0])
     return (4 if name.endswith("_fwd") or name.endswith("_wgrad") else 3), 1
@@ -60,13 +63,16 @@ def conv_call_flops(name, a):
     off, groups = _geom_offset(name, a)
     n, hi, wi, ci, ho, wo, co, kh, kw = a[off: off + 9]
     pix = hi * wi if "convT" in name else ho * wo
-    return 2.0 * groups * n * pix * kh * kw * ci * co
+    both = 2.0 if "dgrad_wgrad" in name else 1.0  # the paired call computes the input AND the weight gradient
+    return both * 2.0 * groups * n * pix * kh * kw * ci * co
 
 
 def conv_call_bytes(name, a):
     """Algorithmic bytes of one conv-family call: each operand and the result touched once (fp32)."""
     off, groups = _geom_offset(name, a)
     n, hi, wi, ci, ho, wo, co, kh, kw = a[off: off + 9]
+    if "dgrad_wgrad" in name:  # dy[G], x, w read; dx[G], dW[G] written
+        return 4.0 * (n * hi * wi * ci * (1 + groups) + groups * n * ho * wo * co + (1 + groups) * kh * kw * ci * co)
     return 4.0 * (n * hi * wi * ci + groups * (n * ho * wo * co + kh * kw * ci * co))
 
 
@@ -161,6 +167,10 @@ def measure_dominant_kernel(recorded, device, reps=20, live=False):
             import ctypes
             ws_ = [torch.randn(co * kh * kw * ci, device=device) for _ in range(groups)]
             arr = (ctypes.c_void_p * groups)(*[t.data_ptr() for t in ws_])
+            if "dgrad_wgrad" in name:
+                dxs = torch.empty(groups * n * hi * wi * ci, device=device)
+                args = (groups, y.data_ptr(), w.data_ptr(), x.data_ptr(), dxs.data_ptr(), arr, None) + geom + (0,) + tail
+                return args, (x, y, w, dxs, ws_, arr)
             args = (groups, y.data_ptr(), x.data_ptr(), arr, None) + geom + (0,) + tail
             return args, (x, y, ws_, arr)
         if name.endswith("_fwd"):

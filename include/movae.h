@@ -76,6 +76,16 @@ int movae_convT2d_dgrad(const float* dy, const float* w, float* dx,
 int movae_convT2d_wgrad(const float* dy, const float* x, float* dw, float* dbias,
                         int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad,
                         int accumulate, void* ws, size_t ws_bytes, movae_stream_t stream);
+/* The backward of one layer in one call: movae_conv[T]2d_dgrad over groups * n images (dy stacked [groups][n][ho][wo][co],
+ * dx likewise) followed by movae_conv[T]2d_wgrad_grouped.  When both land on the small-tile MFMA kernels they share ONE
+ * launch (igemm2_pair: the two problems only share read-only operands and neither fills the chip alone); results are
+ * bit-identical to the two separate calls.  MOVAE_NO_PAIR=1 forces the separate launches. */
+int movae_conv2d_dgrad_wgrad_grouped(int groups, const float* dy, const float* w, const float* x, float* dx, float* const* dw,
+                                     float* const* dbias, int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw,
+                                     int stride, int pad, int accumulate, void* ws, size_t ws_bytes, movae_stream_t stream);
+int movae_convT2d_dgrad_wgrad_grouped(int groups, const float* dy, const float* w, const float* x, float* dx, float* const* dw,
+                                      float* const* dbias, int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw,
+                                      int stride, int pad, int accumulate, void* ws, size_t ws_bytes, movae_stream_t stream);
 int movae_convT2d_wgrad_grouped(int groups, const float* dy, const float* x, float* const* dw, float* const* dbias,
                                 int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad,
                                 int accumulate, void* ws, size_t ws_bytes, movae_stream_t stream);

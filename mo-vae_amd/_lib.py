@@ -38,6 +38,8 @@ SIGNATURES = {
     "movae_convT2d_wgrad": (_conv_wgrad, _i),
     "movae_conv2d_wgrad_grouped": ([_i] + _conv_wgrad, _i),
     "movae_convT2d_wgrad_grouped": ([_i] + _conv_wgrad, _i),
+    "movae_conv2d_dgrad_wgrad_grouped": ([_i, _p, _p, _p, _p, _p, _p] + [_i] * 11 + [_i, _p, _z, _p], _i),
+    "movae_convT2d_dgrad_wgrad_grouped": ([_i, _p, _p, _p, _p, _p, _p] + [_i] * 11 + [_i, _p, _z, _p], _i),
     "movae_bn_ws_bytes": ([_i, _i], _z),
     "movae_bn_act_fwd": ([_p] * 9 + [_i, _i, _f, _f, _i, _i, _f, _p, _z, _p], _i),
     "movae_bn_act_bwd": ([_p] * 9 + [_i, _i, _i, _f, _i, _p, _z, _p], _i),
@@ -149,7 +151,12 @@ WS_BYTES = 96 << 20
 
 # Forking conv wgrad onto a second stream measured SLOWER on MI355X (C2 graph replay 2.42 ms vs 2.24 ms: the tiny
 # layers are launch/latency bound and the fork/join events cost more than the overlap wins) -> opt-in only.
-SIDE_STREAM_WGRAD = bool(os.environ.get("MOVAE_SIDE_STREAM"))
+SIDE_STREAM_WGRAD = os.environ.get("MOVAE_SIDE_STREAM") == "fork"  # per-layer fork/join (measured slower; experiments)
+#: deferred weight gradients (ops.wgrad_side_stream) in the training loop: off by default -- eager streams overlap the two
+#: launches well (333 vs 462 us over the C2 layers) but a replayed hipGraph serialises its branches with extra cross-queue
+#: waits (C2 step 1.397 ms vs 1.357 ms); the paired launch (igemm2_pair) gets the overlap inside one kernel instead
+DEFER_WGRAD_DEFAULT = os.environ.get("MOVAE_SIDE_STREAM", "0") == "1"
+DEFER = None  # the active ops.wgrad_side_stream block, if any
 _side_streams = {}
 
 

@@ -62,6 +62,7 @@ def _accumulate(p, g):
     if p.grad is None:
         p.grad = g
     else:
+        ops.join_wgrad()  # both operands may still be in flight on the weight-gradient side stream
         p.grad = p.grad + g
 
 
@@ -93,6 +94,7 @@ class JacobianBuffer:
             if g is not None:
                 dst = row[off: off + p.numel()]
                 if g.data_ptr() != dst.data_ptr():  # already written in place through the sink
+                    ops.join_wgrad()
                     dst.copy_(_mem_flat(g))
 
 
@@ -246,7 +248,7 @@ def _aggregate_into_grads(jb, aggregator):
 
 class _MtlState:
     """What mtl_backward_begin hands to mtl_backward_finish: the Jacobian buffer and the per-loss feature cotangents."""
-    __slots__ = ("jb", "feat_diff", "feat_grads", "shared_params", "aggregator", "task_params")
+    __slots__ = ("jb", "feat_diff", "feat_grads", "shared_params", "aggregator", "task_params", "device")
 
 
 def mtl_backward_begin(losses, features, aggregator, tasks_params=None, shared_params=None):
@@ -307,6 +309,7 @@ def mtl_backward_finish(st):
             ops.GRAD_SINK.clear()
         jb.write_row(i, js)
     if shared_params:
+        ops.join_wgrad()  # the Jacobian rows are written by deferred weight-gradient launches
         _aggregate_into_grads(jb, st.aggregator)
 
 
@@ -333,4 +336,5 @@ def backward(tensors, aggregator, inputs=None, retain_graph=False, parallel_chun
     for i, t in enumerate(tensors):
         js = torch.autograd.grad(t, inputs, retain_graph=True, allow_unused=True)
         jb.write_row(i, js)
+    ops.join_wgrad()
     _aggregate_into_grads(jb, aggregator)

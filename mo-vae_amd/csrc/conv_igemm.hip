@@ -976,4 +976,52 @@ int movae_convT2d_wgrad(const float* dy, const float* x, float* dw, float* dbias
                                        ws, ws_bytes, stream);
 }
 
+// dgrad (over groups * n images) and the grouped wgrad of one layer through ONE main launch when both land on the small-tile
+// MFMA kernels (igemm2_pair); otherwise exactly the two calls above, in that order.
+static int pair_calls(bool transposed, int groups, const float* dy, const float* w, const float* x, float* dx, float* const* dw,
+                      float* const* dbias, int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad,
+                      int accumulate, void* ws, size_t ws_bytes, movae_stream_t stream) {
+    static const bool enabled = !getenv("MOVAE_NO_PAIR");
+    v2::g_pending.active = false;
+    v2::g_pair_collect = enabled;
+    int rc = transposed ? movae_convT2d_dgrad(dy, w, dx, groups * n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, ws, ws_bytes, stream)
+                        : movae_conv2d_dgrad(dy, w, dx, groups * n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, ws, ws_bytes, stream);
+    v2::g_pair_collect = false;
+    if (rc) {
+        v2::g_pending.active = false;
+        return rc;
+    }
+    size_t used = v2::g_pending.active ? (v2::g_pending.ws_used + 255) / 256 * 256 : 0;
+    if (v2::g_pending.active && (!ws || used + (32u << 20) > ws_bytes)) {  // no room left for the wgrad's slabs next to the dgrad's
+        if ((rc = v2::flush_pending((hipStream_t)stream))) return rc;
+        used = 0;
+    }
+    void* ws2 = ws ? static_cast<char*>(ws) + used : nullptr;
+    rc = transposed ? movae_convT2d_wgrad_grouped(groups, dy, x, dw, dbias, n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, accumulate, ws2,
+                                                  ws_bytes - used, stream)
+                    : movae_conv2d_wgrad_grouped(groups, dy, x, dw, dbias, n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, accumulate, ws2,
+                                                 ws_bytes - used, stream);
+    if (v2::g_pending.active) {  // the wgrad took a kernel that does not pair (thin / linear / generic)
+        const int rc2 = v2::flush_pending((hipStream_t)stream);
+        if (!rc) rc = rc2;
+    }
+    return rc;
+}
+
+int movae_conv2d_dgrad_wgrad_grouped(int groups, const float* dy, const float* w, const float* x, float* dx, float* const* dw,
+                                     float* const* dbias, int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw,
+                                     int stride, int pad, int accumulate, void* ws, size_t ws_bytes, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(dx && w, "movae_conv2d_dgrad_wgrad: null pointer");
+    return pair_calls(false, groups, dy, w, x, dx, dw, dbias, n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, accumulate, ws, ws_bytes,
+                      stream);
+}
+
+int movae_convT2d_dgrad_wgrad_grouped(int groups, const float* dy, const float* w, const float* x, float* dx, float* const* dw,
+                                      float* const* dbias, int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw,
+                                      int stride, int pad, int accumulate, void* ws, size_t ws_bytes, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(dx && w, "movae_convT2d_dgrad_wgrad: null pointer");
+    return pair_calls(true, groups, dy, w, x, dx, dw, dbias, n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, accumulate, ws, ws_bytes,
+                      stream);
+}
+
 }  // extern "C"

@@ -109,16 +109,40 @@ __device__ __forceinline__ void mma_kk(const float* __restrict__ As, const float
 #define ZERO4 (f32x4{0.f, 0.f, 0.f, 0.f})
 
 // ------------------------------------------------------------------------------------------------
+// Kernel arguments as plain structs and kernel bodies as device functions of an explicit block index (bx, by, bz) and an
+// LDS base: the stand-alone kernels below pass blockIdx, the paired kernel (igemm2_pair) runs a dgrad body and a wgrad
+// body side by side in ONE launch, sharing one LDS allocation.
+struct FwdArgs {
+    const float* X;
+    const float* W;
+    float* Y;
+    Geom g;
+    Epilogue ep;
+    int M, K, ktiles_per_split;
+    float* slab;
+};
+
 template <int BM, int BN>
-__global__ __launch_bounds__(256) void igemm2_fwd(const float* __restrict__ X, const float* __restrict__ W,
-                                                  float* __restrict__ Y, Geom g, Epilogue ep, int M, int K,
-                                                  int ktiles_per_split, float* __restrict__ slab) {
+struct FwdSmem {
+    static constexpr int ASZ = BM * LDR, BSZ = BN * LDR;
+    static constexpr int FLOATS = (T2<BM, BN>::DB ? 2 : 1) * (ASZ + BSZ);
+};
+
+template <int BM, int BN>
+__device__ __forceinline__ void igemm2_fwd_body(const FwdArgs& a, float* __restrict__ smem, int bx, int by, int bz) {
     using T = T2<BM, BN>;
     constexpr int ASZ = BM * LDR, BSZ = BN * LDR;
-    __shared__ __attribute__((aligned(16))) float As[(T::DB ? 2 : 1) * ASZ];  // double buffered when it fits
-    __shared__ __attribute__((aligned(16))) float Bs[(T::DB ? 2 : 1) * BSZ];
+    float* As = smem;                                   // double buffered when it fits
+    float* Bs = smem + (T::DB ? 2 : 1) * ASZ;
+    const float* __restrict__ X = a.X;
+    const float* __restrict__ W = a.W;
+    float* __restrict__ Y = a.Y;
+    float* __restrict__ slab = a.slab;
+    const Geom g = a.g;
+    const Epilogue ep = a.ep;
+    const int M = a.M, K = a.K, ktiles_per_split = a.ktiles_per_split;
     const int t = threadIdx.x;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int m0 = bx * BM, n0 = by * BN;
     const int N = g.Nn;
     constexpr int AC = BM / RPP, BC = BN / RPP;  // 16-byte chunks per thread
     const int kq = t % CPR, r8 = t / CPR;
@@ -147,7 +171,7 @@ __global__ __launch_bounds__(256) void igemm2_fwd(const float* __restrict__ X, c
         b_base[i] = W + (long)(b_ok[i] ? n : 0) * K;
     }
     const int nk_total = (K + BK2 - 1) / BK2;
-    const int kt_begin = blockIdx.z * ktiles_per_split;
+    const int kt_begin = bz * ktiles_per_split;
     const int kt_end = min(nk_total, kt_begin + ktiles_per_split);
 
     f32x4 ra[AC], rb[BC];
@@ -214,7 +238,7 @@ __global__ __launch_bounds__(256) void igemm2_fwd(const float* __restrict__ X, c
 
     const int lane = t & 63, half = lane >> 5, l31 = lane & 31;
     const bool to_slab = slab != nullptr;
-    float* out = to_slab ? slab + (long)blockIdx.z * M * N : Y;
+    float* out = to_slab ? slab + (long)bz * M * N : Y;
 #pragma unroll
     for (int tn = 0; tn < T::TN; ++tn) {
         const int n = n0 + wn * T::TN * 32 + tn * 32 + l31;
@@ -231,27 +255,57 @@ __global__ __launch_bounds__(256) void igemm2_fwd(const float* __restrict__ X, c
     }
 }
 
-// ------------------------------------------------------------------------------------------------
 template <int BM, int BN>
-__global__ __launch_bounds__(256) void igemm2_bwd(const float* __restrict__ X, const float* __restrict__ W,
-                                                  float* __restrict__ Y, Geom g, Epilogue ep, ClsSplit scls, ClsSplit kps,
-                                                  float* __restrict__ slab, long total) {
+__global__ __launch_bounds__(256) void igemm2_fwd(FwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[FwdSmem<BM, BN>::FLOATS];
+    igemm2_fwd_body<BM, BN>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// ------------------------------------------------------------------------------------------------
+struct BwdArgs {
+    const float* X;
+    const float* W;
+    float* Y;
+    Geom g;
+    Epilogue ep;
+    ClsSplit scls, kps;
+    float* slab;
+    long total;
+};
+
+template <int BM, int BN>
+struct BwdSmem {
+    static constexpr int ASZ = BM * LDR, BSZ = BK2 * T2<BM, BN>::LDKB;
+    static constexpr int FLOATS = (T2<BM, BN>::DB ? 2 : 1) * (ASZ + BSZ);
+};
+
+template <int BM, int BN>
+__device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restrict__ smem, int bx, int by, int bz) {
     using T = T2<BM, BN>;
     constexpr int ASZ = BM * LDR, BSZ = BK2 * T::LDKB;
-    __shared__ __attribute__((aligned(16))) float As[(T::DB ? 2 : 1) * ASZ];
-    __shared__ __attribute__((aligned(16))) float Bs[(T::DB ? 2 : 1) * BSZ];
+    float* As = smem;
+    float* Bs = smem + (T::DB ? 2 : 1) * ASZ;
+    const float* __restrict__ X = a.X;
+    const float* __restrict__ W = a.W;
+    float* __restrict__ Y = a.Y;
+    float* __restrict__ slab = a.slab;
+    const Geom g = a.g;
+    const Epilogue ep = a.ep;
+    const ClsSplit& scls = a.scls;  // indexed by a run-time class: stays in the kernel-argument segment (a local copy
+    const ClsSplit& kps = a.kps;    // would be an alloca the compiler parks in LDS, 4 KiB per block)
+    const long total = a.total;
     const int t = threadIdx.x;
     const int s = g.stride;
     // blockIdx.z enumerates (class, split) pairs; class c owns scls.s[c] consecutive z values and kps.s[c] k-tiles per split
     // (the s*s output-parity classes of a 3x3 stride-2 layer carry 1/2/2/4 taps: one split factor for all would let the
     // 4-tap class set the kernel's duration)
-    int cls = 0, split = blockIdx.z;
+    int cls = 0, split = bz;
     while (cls < s * s - 1 && split >= scls.s[cls]) split -= scls.s[cls++];
     const int ktiles_per_split = kps.s[cls];
     const int ph = cls / s, pw = cls % s;
     const int Hoc = (g.Ho - ph + s - 1) / s, Woc = (g.Wo - pw + s - 1) / s;
     const int M = g.Nimg * Hoc * Woc;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int m0 = bx * BM, n0 = by * BN;
     if (m0 >= M) return;
     const int N = g.Nn;
     const int kh0 = (ph + g.pad) % s, kw0 = (pw + g.pad) % s;
@@ -382,6 +436,12 @@ __global__ __launch_bounds__(256) void igemm2_bwd(const float* __restrict__ X, c
         }
 }
 
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void igemm2_bwd(BwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[BwdSmem<BM, BN>::FLOATS];
+    igemm2_bwd_body<BM, BN>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Cotangent groups (batched pull-back): blockIdx.z = group * Sp + split.  A group adds s_gs / b_gs floats to the
 // operand bases (0 for the operand the groups share) and owns its own Sp slabs / its own destination.
@@ -389,20 +449,37 @@ struct WOut {
     float* p[8];
 };
 
+struct WgArgs {
+    const float* Sm;
+    const float* Bg;
+    float* out;
+    WGeom g;
+    int K, kchunk, to_slab, Sp;
+    long s_gs, b_gs;
+    WOut tab;
+};
+
 template <int BM, int BN>
-__global__ __launch_bounds__(256) void igemm2_wgrad(const float* __restrict__ Sm, const float* __restrict__ Bg,
-                                                    float* __restrict__ out, WGeom g, int K, int kchunk, int to_slab, int Sp,
-                                                    long s_gs, long b_gs, WOut tab) {
+struct WgSmem {
+    static constexpr int ASZ = BK2 * T2<BM, BN>::LDKA, BSZ = BK2 * T2<BM, BN>::LDKB;
+    static constexpr int FLOATS = (T2<BM, BN>::DB ? 2 : 1) * (ASZ + BSZ);
+};
+
+template <int BM, int BN>
+__device__ __forceinline__ void igemm2_wgrad_body(const WgArgs& a, float* __restrict__ smem, int bx, int by, int bz) {
     using T = T2<BM, BN>;
     constexpr int ASZ = BK2 * T::LDKA, BSZ = BK2 * T::LDKB;
-    __shared__ __attribute__((aligned(16))) float As[(T::DB ? 2 : 1) * ASZ];
-    __shared__ __attribute__((aligned(16))) float Bs[(T::DB ? 2 : 1) * BSZ];
+    float* As = smem;
+    float* Bs = smem + (T::DB ? 2 : 1) * ASZ;
+    const WGeom g = a.g;
+    const int K = a.K, kchunk = a.kchunk, to_slab = a.to_slab, Sp = a.Sp;
+    float* __restrict__ out = a.out;
     const int t = threadIdx.x;
     const int M = g.Cs, N = g.KH * g.KW * g.Cb;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int grp = blockIdx.z / Sp, split = blockIdx.z - grp * Sp;
-    Sm += grp * s_gs;
-    Bg += grp * b_gs;
+    const int m0 = bx * BM, n0 = by * BN;
+    const int grp = bz / Sp, split = bz - grp * Sp;
+    const float* __restrict__ Sm = a.Sm + grp * a.s_gs;
+    const float* __restrict__ Bg = a.Bg + grp * a.b_gs;
     const int k_begin = split * kchunk, k_end = min(K, k_begin + kchunk);
     constexpr int AQ = BM / 4, BQ = BN / 4;
     constexpr int ACH = BK2 * AQ / 256, BCH = BK2 * BQ / 256;
@@ -480,7 +557,7 @@ __global__ __launch_bounds__(256) void igemm2_wgrad(const float* __restrict__ Sm
     }
 
     const int lane = t & 63, half = lane >> 5, l31 = lane & 31;
-    float* dst = to_slab ? out + (long)blockIdx.z * M * N : tab.p[grp];
+    float* dst = to_slab ? out + (long)bz * M * N : a.tab.p[grp];
 #pragma unroll
     for (int tn = 0; tn < T::TN; ++tn) {
         const int n = n0 + wn * T::TN * 32 + tn * 32 + l31;
@@ -495,19 +572,130 @@ __global__ __launch_bounds__(256) void igemm2_wgrad(const float* __restrict__ Sm
     }
 }
 
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void igemm2_wgrad(WgArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[WgSmem<BM, BN>::FLOATS];
+    igemm2_wgrad_body<BM, BN>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// ---- one launch, two problems: the input gradient (FWD or BWD gather form) and the weight gradient of one layer ----------
+// blocks [0, nd) run the dgrad body on its (dgx, dgy, *) grid, the rest the wgrad body on (wgx, wgy, *).  The two only
+// share read-only operands.  Each alone is a latency-bound launch that cannot fill 256 CUs (C2: <= 2 blocks per CU, one
+// 32-deep k-stage chain each); together the CU's wave slots and the HBM queue stay busy.  LDS: one allocation, the larger
+// of the two bodies' needs.
+template <int FORM, int ABM, int ABN, int WBM, int WBN>
+__global__ __launch_bounds__(256) void igemm2_pair(FwdArgs fa, BwdArgs ba, WgArgs wa, int nd, int dgx, int dgy, int wgx, int wgy,
+                                                   int nw, int inter) {
+    constexpr int DF = FORM == 0 ? FwdSmem<ABM, ABN>::FLOATS : BwdSmem<ABM, ABN>::FLOATS;
+    constexpr int WF = WgSmem<WBM, WBN>::FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[DF > WF ? DF : WF];
+    int b = blockIdx.x;
+    if (inter == 2) {  // weight-gradient blocks first
+        b = b < nw ? nd + b : b - nw;
+    } else if (inter) {  // alternate the two problems' blocks while both last (the dispatcher hands out blocks in index order)
+        const int m = nd < nw ? nd : nw;
+        if (b < 2 * m) b = (b & 1) ? nd + (b >> 1) : (b >> 1);
+        else b = nd < nw ? b : b - m;  // tail: the longer problem's remaining blocks (dgrad tail keeps indices m.., wgrad tail nd + m..)
+    }
+    if (b < nd) {
+        const int bx = b % dgx, r = b / dgx;
+        if (FORM == 0)
+            igemm2_fwd_body<ABM, ABN>(fa, smem, bx, r % dgy, r / dgy);
+        else
+            igemm2_bwd_body<ABM, ABN>(ba, smem, bx, r % dgy, r / dgy);
+    } else {
+        b -= nd;
+        const int bx = b % wgx, r = b / wgx;
+        igemm2_wgrad_body<WBM, WBN>(wa, smem, bx, r % wgy, r / wgy);
+    }
+}
+
 #undef ZERO4
 
 // ---- host side ------------------------------------------------------------------------------------
+// Pairing (movae_conv*_dgrad_wgrad*): while g_pair_collect is set, a dgrad that lands on one of the small-tile kernels is
+// PLANNED but not launched -- its arguments wait in g_pending -- and the wgrad that follows launches both through
+// igemm2_pair when it lands on a small-tile kernel too.  Anything else flushes the pending dgrad as an ordinary launch.
+struct PendingDgrad {
+    bool active = false;
+    int form = 0, bm = 0, bn = 0;  // 0 = FWD gather (transposed-conv dgrad), 1 = BWD gather (conv dgrad)
+    FwdArgs fa;
+    BwdArgs ba;
+    int gx = 0, gy = 0, gz = 0;
+    size_t ws_used = 0;            // bytes of the scratch arena taken by the dgrad's slabs
+    // split-K epilogue of the dgrad, issued after the (paired or plain) main launch
+    bool reduce = false;
+    int S = 1;
+    long total = 0;
+};
+static thread_local PendingDgrad g_pending;
+static thread_local bool g_pair_collect = false;
+
+// a paired launch brings the partner's blocks onto the chip as well: the split-K cost model is asked about this many
+// times the own tiles (tuning knob MOVAE_PAIR_TILES, percent)
+inline long pair_tiles(long tiles, bool paired) {
+    static const int pct = getenv("MOVAE_PAIR_TILES") ? atoi(getenv("MOVAE_PAIR_TILES")) : 100;
+    return paired ? (tiles * pct + 99) / 100 : tiles;
+}
+
+template <int BM, int BN>
+constexpr bool pair_dgrad_tile() { return (BM == 64 && BN == 64) || (BM == 128 && BN == 32); }
+template <int BM, int BN>
+constexpr bool pair_wgrad_tile() { return (BM == 64 && BN == 64) || (BM == 32 && BN == 128); }
+
+inline int finish_pending(hipStream_t st) {  // the stashed dgrad's reduce
+    PendingDgrad& p = g_pending;
+    if (!p.reduce || g_bench_main_only) return MOVAE_OK;
+    if (p.form == 0) {
+        const FwdArgs& a = p.fa;
+        return launch_reduce(a.slab, a.Y, (long)a.M * a.g.Nn, p.S, a.g.Nn, a.ep.bias, a.ep.act, a.ep.slope, 0, st);
+    }
+    const BwdArgs& a = p.ba;
+    long gq = (a.total / 4 + 255) / 256;
+    if (gq > 4096) gq = 4096;
+    hipLaunchKernelGGL(splitk_reduce_cls, dim3((unsigned)gq), dim3(256), 0, st, a.slab, a.Y, a.total, a.g.Nn, a.g.Ho, a.g.Wo, a.g.stride,
+                       a.scls, a.ep.bias, a.ep.act, a.ep.slope);
+    MOVAE_CHECK_LAUNCH("splitk_reduce_cls");
+    return MOVAE_OK;
+}
+
+inline int flush_pending(hipStream_t st) {  // launch the stashed dgrad on its own
+    PendingDgrad& p = g_pending;
+    if (!p.active) return MOVAE_OK;
+    p.active = false;
+    const dim3 grid(p.gx, p.gy, p.gz);
+    if (p.form == 0) {
+        if (p.bm == 64) hipLaunchKernelGGL((igemm2_fwd<64, 64>), grid, dim3(256), 0, st, p.fa);
+        else hipLaunchKernelGGL((igemm2_fwd<128, 32>), grid, dim3(256), 0, st, p.fa);
+    } else {
+        if (p.bm == 64) hipLaunchKernelGGL((igemm2_bwd<64, 64>), grid, dim3(256), 0, st, p.ba);
+        else hipLaunchKernelGGL((igemm2_bwd<128, 32>), grid, dim3(256), 0, st, p.ba);
+    }
+    MOVAE_CHECK_LAUNCH("igemm2 dgrad (unpaired)");
+    return finish_pending(st);
+}
+
 template <int BM, int BN>
 int launch_fwd2(const float* X, const float* W, float* Y, const Geom& g, const Epilogue& ep, int M, int K, void* ws,
                 size_t ws_bytes, hipStream_t st) {
     const int gx = ceil_div(M, BM), gy = ceil_div(g.Nn, BN);
     const int nk = ceil_div(K, BK2);
-    int S = choose_split(FORM_FWD, BM * BN, BK2, (long)gx * gy, nk, (size_t)M * g.Nn * sizeof(float), ws_bytes, ws != nullptr);
+    const bool pairing = g_pair_collect && pair_dgrad_tile<BM, BN>();
+    int S = choose_split(FORM_FWD, BM * BN, BK2, pair_tiles((long)gx * gy, pairing), nk, (size_t)M * g.Nn * sizeof(float), ws_bytes,
+                         ws != nullptr);
     const int per_split = ceil_div(nk, S);
     S = ceil_div(nk, per_split);
     float* slab = S > 1 ? static_cast<float*>(ws) : nullptr;
-    hipLaunchKernelGGL((igemm2_fwd<BM, BN>), dim3(gx, gy, S), dim3(256), 0, st, X, W, Y, g, ep, M, K, per_split, slab);
+    const FwdArgs a{X, W, Y, g, ep, M, K, per_split, slab};
+    if (g_pair_collect && pair_dgrad_tile<BM, BN>()) {
+        PendingDgrad& p = g_pending;
+        p.active = true;
+        p.form = 0, p.bm = BM, p.bn = BN, p.fa = a, p.gx = gx, p.gy = gy, p.gz = S;
+        p.reduce = S > 1, p.S = S, p.total = (long)M * g.Nn;
+        p.ws_used = S > 1 ? (size_t)M * g.Nn * sizeof(float) * S : 0;
+        return MOVAE_OK;
+    }
+    hipLaunchKernelGGL((igemm2_fwd<BM, BN>), dim3(gx, gy, S), dim3(256), 0, st, a);
     MOVAE_CHECK_LAUNCH("igemm2_fwd");
     if (S > 1) return launch_reduce(slab, Y, (long)M * g.Nn, S, g.Nn, ep.bias, ep.act, ep.slope, 0, st);
     return MOVAE_OK;
@@ -537,7 +725,7 @@ int launch_bwd2(const float* X, const float* W, float* Y, const Geom& g, const E
         return MOVAE_EUNSUPPORTED;
     }
     // split factor of the heaviest class from the cost model, on the block count the balanced grid will have
-    const long tiles_eff = ceil_div((long)gx * gy * nk_sum, nk_max);
+    const long tiles_eff = pair_tiles(ceil_div((long)gx * gy * nk_sum, nk_max), g_pair_collect && pair_dgrad_tile<BM, BN>());
     int Smax = choose_split(FORM_BWD, BM * BN, BK2, tiles_eff, nk_max, (size_t)total * sizeof(float), ws_bytes, ws != nullptr);
     // the cost model sees balanced blocks; unsplit but unbalanced (heaviest class >= 2x the lightest) it is better to split
     int nk_min = nk_max;
@@ -570,7 +758,16 @@ int launch_bwd2(const float* X, const float* W, float* Y, const Geom& g, const E
         movae_set_error("conv bwd-form: workspace too small for %d slabs", Sreal);
         return MOVAE_EINVAL;
     }
-    hipLaunchKernelGGL((igemm2_bwd<BM, BN>), dim3(gx, gy, zsum), dim3(256), 0, st, X, W, Y, g, ep, scls, kps, slab, total);
+    const BwdArgs a{X, W, Y, g, ep, scls, kps, slab, total};
+    if (g_pair_collect && pair_dgrad_tile<BM, BN>()) {
+        PendingDgrad& p = g_pending;
+        p.active = true;
+        p.form = 1, p.bm = BM, p.bn = BN, p.ba = a, p.gx = gx, p.gy = gy, p.gz = zsum;
+        p.reduce = Sreal > 1, p.S = Sreal, p.total = total;
+        p.ws_used = Sreal > 1 ? (size_t)total * sizeof(float) * Sreal : 0;
+        return MOVAE_OK;
+    }
+    hipLaunchKernelGGL((igemm2_bwd<BM, BN>), dim3(gx, gy, zsum), dim3(256), 0, st, a);
     MOVAE_CHECK_LAUNCH("igemm2_bwd");
     if (Sreal > 1 && !g_bench_main_only) {
         long gq = (total / 4 + 255) / 256;
@@ -582,14 +779,22 @@ int launch_bwd2(const float* X, const float* W, float* Y, const Geom& g, const E
     return MOVAE_OK;
 }
 
+template <int FORM, int ABM, int ABN, int WBM, int WBN>
+inline void launch_pair(const PendingDgrad& p, const WgArgs& wa, int wgx, int wgy, int wgz, hipStream_t st) {
+    const int nd = p.gx * p.gy * p.gz, nw = wgx * wgy * wgz;
+    static const int inter = getenv("MOVAE_PAIR_INTERLEAVE") ? atoi(getenv("MOVAE_PAIR_INTERLEAVE")) : 0;
+    hipLaunchKernelGGL((igemm2_pair<FORM, ABM, ABN, WBM, WBN>), dim3(nd + nw), dim3(256), 0, st, p.fa, p.ba, wa, nd, p.gx, p.gy, wgx,
+                       wgy, nw, inter);
+}
+
 template <int BM, int BN>
 int launch_wgrad2(const float* Sm, const float* Bg, float* const* dW, int G, long s_gs, long b_gs, const WGeom& g, int K,
                   int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
     const int M = g.Cs, N = g.KH * g.KW * g.Cb;
     const int gx = ceil_div(M, BM), gy = ceil_div(N, BN);
     // the G groups run side by side, so the split factor is chosen for G times the tiles
-    int Sp = choose_split(FORM_WGRAD, BM * BN, BK2, (long)gx * gy * G, ceil_div(K, BK2), (size_t)M * N * sizeof(float) * G, ws_bytes,
-                          ws != nullptr);
+    int Sp = choose_split(FORM_WGRAD, BM * BN, BK2, pair_tiles((long)gx * gy * G, g_pending.active && pair_wgrad_tile<BM, BN>()),
+                          ceil_div(K, BK2), (size_t)M * N * sizeof(float) * G, ws_bytes, ws != nullptr);
     const int kchunk = ceil_div(ceil_div(K, Sp), BK2) * BK2;
     Sp = ceil_div(K, kchunk);
     const bool slab = Sp > 1 || accumulate;
@@ -600,9 +805,32 @@ int launch_wgrad2(const float* Sm, const float* Bg, float* const* dW, int G, lon
     WOut tab;
     for (int i = 0; i < 8; ++i) tab.p[i] = i < G ? dW[i] : nullptr;
     float* out = slab ? static_cast<float*>(ws) : nullptr;
-    hipLaunchKernelGGL((igemm2_wgrad<BM, BN>), dim3(gx, gy, Sp * G), dim3(256), 0, st, Sm, Bg, out, g, K, kchunk, slab ? 1 : 0, Sp,
-                       s_gs, b_gs, tab);
-    MOVAE_CHECK_LAUNCH("igemm2_wgrad");
+    const WgArgs a{Sm, Bg, out, g, K, kchunk, slab ? 1 : 0, Sp, s_gs, b_gs, tab};
+    PendingDgrad& p = g_pending;
+    if (p.active && pair_wgrad_tile<BM, BN>() && (long)p.gx * p.gy * p.gz + (long)gx * gy * Sp * G < 0x7fffffffL) {
+        p.active = false;
+        constexpr int W64 = BM == 64 ? 1 : 0;  // wgrad tile: <64,64> or <32,128>
+        // names as rocprofv3 prints the instantiations: <form, dgrad tile, wgrad tile>
+        if (p.form == 0 && p.bm == 64) {
+            launch_pair<0, 64, 64, W64 ? 64 : 32, W64 ? 64 : 128>(p, a, gx, gy, Sp * G, st);
+            g_last_kernel = W64 ? "igemm2_pair<0,64,64,64,64>" : "igemm2_pair<0,64,64,32,128>";
+        } else if (p.form == 0) {
+            launch_pair<0, 128, 32, W64 ? 64 : 32, W64 ? 64 : 128>(p, a, gx, gy, Sp * G, st);
+            g_last_kernel = W64 ? "igemm2_pair<0,128,32,64,64>" : "igemm2_pair<0,128,32,32,128>";
+        } else if (p.bm == 64) {
+            launch_pair<1, 64, 64, W64 ? 64 : 32, W64 ? 64 : 128>(p, a, gx, gy, Sp * G, st);
+            g_last_kernel = W64 ? "igemm2_pair<1,64,64,64,64>" : "igemm2_pair<1,64,64,32,128>";
+        } else {
+            launch_pair<1, 128, 32, W64 ? 64 : 32, W64 ? 64 : 128>(p, a, gx, gy, Sp * G, st);
+            g_last_kernel = W64 ? "igemm2_pair<1,128,32,64,64>" : "igemm2_pair<1,128,32,32,128>";
+        }
+        MOVAE_CHECK_LAUNCH("igemm2_pair");
+        if (int rc = finish_pending(st)) return rc;
+    } else {
+        if (int rc = flush_pending(st)) return rc;
+        hipLaunchKernelGGL((igemm2_wgrad<BM, BN>), dim3(gx, gy, Sp * G), dim3(256), 0, st, a);
+        MOVAE_CHECK_LAUNCH("igemm2_wgrad");
+    }
     if (slab)
         for (int i = 0; i < G; ++i)
             if (int rc = launch_reduce(out + (long)i * Sp * M * N, dW[i], (long)M * N, Sp, N, nullptr, 0, 0.f, accumulate, st)) return rc;

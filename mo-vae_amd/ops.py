@@ -168,6 +168,43 @@ def unflatten_nchw(x, c, h, w):
 
 
 # ---------------------------------------------------------------------------------------------
+class wgrad_side_stream:
+    """Inside this block every convolution's weight / bias gradient is launched on a forked side stream (own scratch arena)
+    and the compute stream does NOT wait for it: the backward's critical path is dgrad -> BatchNorm backward -> dgrad ...,
+    the weight gradients are leaves nobody reads until the aggregation / optimizer.  Two short latency-bound launches
+    then share the chip (measured on the C2 layers: 333 us for the 13 dgrad+wgrad pairs side by side vs 462 us in
+    sequence).  The block's exit -- or join_wgrad() -- makes the compute stream wait for the side stream once.  Works
+    under hipGraph capture (the side stream joins the capture at its first wait and returns at the join)."""
+
+    def __init__(self, device, enabled=True):
+        self.device, self.enabled = device, enabled and device.type == "cuda"
+        self.keep, self.used, self.prev = [], False, None
+
+    def __enter__(self):
+        if self.enabled:
+            self.prev, L.DEFER = L.DEFER, self
+            self.side = L.side_stream(self.device)
+        return self
+
+    def join(self):
+        if self.used:
+            torch.cuda.current_stream(self.device).wait_stream(self.side)
+            self.keep.clear()  # operands the side stream was still reading (the allocator may recycle them now)
+            self.used = False
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            self.join()
+            L.DEFER = self.prev
+        return False
+
+
+def join_wgrad():
+    """Make the compute stream wait for every deferred weight gradient (no-op outside wgrad_side_stream)."""
+    if L.DEFER is not None:
+        L.DEFER.join()
+
+
 class Conv(Function):
     """conv2d / conv_transpose2d / linear (+bias, + fused activation)."""
 
@@ -221,15 +258,18 @@ class Conv(Function):
         # dgrad and wgrad only share read-only operands: when both are needed the wgrad (+ its reduce / bias sum)
         # is issued on a forked side stream with its own scratch arena and joined afterwards, so the two short,
         # latency-bound launches overlap on the device (also inside a captured hipGraph, as parallel branches)
-        fork = L.SIDE_STREAM_WGRAD and need_w and ctx.needs_input_grad[0]
+        defer = L.DEFER
+        fork = need_w and (defer is not None or (L.SIDE_STREAM_WGRAD and ctx.needs_input_grad[0]))
         if fork:
             main, side = torch.cuda.current_stream(dy.device), L.side_stream(dy.device)
             side.wait_stream(main)
+        pair = need_w and ctx.needs_input_grad[0] and not fork  # both gradients, one stream: one call, one main launch
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             wm = weight_mem(w)
-            _call(pre + "dgrad", dy.data_ptr(), wm.data_ptr(), dx.data_ptr(), n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad,
-                  wsp, wsb, st)
+            if not pair:
+                _call(pre + "dgrad", dy.data_ptr(), wm.data_ptr(), dx.data_ptr(), n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad,
+                      wsp, wsb, st)
         if fork:
             ws2 = L.workspace(dy.device, slot=1)
             wsp, wsb, st = ws2.data_ptr(), ws2.numel(), side.cuda_stream
@@ -246,10 +286,18 @@ class Conv(Function):
                     db = _sink_zeros(b, (co,))
                 else:
                     db = db_k = _sink(b, (co,))
-            _call(pre + "wgrad", dy.data_ptr(), x.data_ptr(), dwm.data_ptr(), L.ptr(db_k), n, hi, wi, ci, ho, wo, co, kh, kw,
-                  stride, pad, 0, wsp, wsb, st)
+            if pair:
+                _call(pre + "dgrad_wgrad_grouped", 1, dy.data_ptr(), wm.data_ptr(), x.data_ptr(), dx.data_ptr(),
+                      (C.c_void_p * 1)(dwm.data_ptr()), (C.c_void_p * 1)(db_k.data_ptr()) if db_k is not None else None, n, hi, wi, ci,
+                      ho, wo, co, kh, kw, stride, pad, 0, wsp, wsb, st)
+            else:
+                _call(pre + "wgrad", dy.data_ptr(), x.data_ptr(), dwm.data_ptr(), L.ptr(db_k), n, hi, wi, ci, ho, wo, co, kh, kw,
+                      stride, pad, 0, wsp, wsb, st)
             dw = dwm.permute(0, 3, 1, 2)
-        if fork:
+        if fork and defer is not None:
+            defer.keep.append((dy, x, dwm, db))  # joined once, by wgrad_side_stream
+            defer.used = True
+        elif fork:
             main.wait_stream(side)
         return dx, dw, db, None, None, None, None, None, None, None
 
@@ -279,13 +327,22 @@ class Conv(Function):
             dy = dpre
         pre = "movae_convT2d_" if ctx.transposed else "movae_conv2d_"
         dx = dw = db = None
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        need_w = ctx.needs_input_grad[1] or need_b
+        defer = L.DEFER if need_w else None
+        pair = need_w and ctx.needs_input_grad[0] and defer is None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((G,) + tuple(x.shape), dtype=x.dtype, device=x.device)
             wm = weight_mem(w)
-            _call(pre + "dgrad", dy.data_ptr(), wm.data_ptr(), dx.data_ptr(), G * n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad,
-                  wsp, wsb, st)
-        need_b = ctx.has_bias and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1] or need_b:
+            if not pair:
+                _call(pre + "dgrad", dy.data_ptr(), wm.data_ptr(), dx.data_ptr(), G * n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad,
+                      wsp, wsb, st)
+        if defer is not None:  # the grouped wgrad goes to the side stream (see wgrad_side_stream)
+            side = L.side_stream(dy.device)
+            side.wait_stream(torch.cuda.current_stream(dy.device))
+            ws2 = L.workspace(dy.device, slot=1)
+            wsp, wsb, st = ws2.data_ptr(), ws2.numel(), side.cuda_stream
+        if need_w:
             wm_shape = (ci, kh, kw, co) if ctx.transposed else (co, kh, kw, ci)
             dwm = [_sink_row(g, w, wm_shape) for g in range(G)]
             arr = C.c_void_p * G
@@ -294,10 +351,18 @@ class Conv(Function):
             else:
                 db = [_sink_row(g, b, (co,), zeros=ctx.bias_grad_is_zero) for g in range(G)] if need_b else None
                 dbp = arr(*[t.data_ptr() for t in db]) if (need_b and not ctx.bias_grad_is_zero) else None
-            # one grouped launch: blockIdx.z = group * splits + split, x is read by every group, dy by its own
-            _call(pre + "wgrad_grouped", G, dy.data_ptr(), x.data_ptr(), arr(*[t.data_ptr() for t in dwm]), dbp, n, hi, wi, ci, ho, wo,
-                  co, kh, kw, stride, pad, 0, wsp, wsb, st)
+            # one grouped launch: blockIdx.z = group * splits + split, x is read by every group, dy by its own; with the
+            # input gradient wanted too, dgrad and wgrad share the launch (igemm2_pair)
+            if pair:
+                _call(pre + "dgrad_wgrad_grouped", G, dy.data_ptr(), wm.data_ptr(), x.data_ptr(), dx.data_ptr(),
+                      arr(*[t.data_ptr() for t in dwm]), dbp, n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, 0, wsp, wsb, st)
+            else:
+                _call(pre + "wgrad_grouped", G, dy.data_ptr(), x.data_ptr(), arr(*[t.data_ptr() for t in dwm]), dbp, n, hi, wi, ci,
+                      ho, wo, co, kh, kw, stride, pad, 0, wsp, wsb, st)
             dw = [t.permute(0, 3, 1, 2) for t in dwm]
+            if defer is not None:
+                defer.keep.append((dy, x, dwm, db))
+                defer.used = True
         return dx, dw, db, None, None, None, None, None, None, None
 
 

@@ -16,8 +16,10 @@ from argparse import ArgumentParser
 import torch
 import torch.optim as optim
 
+from . import _lib as L
 from . import aggregation
 from . import autojac
+from . import ops
 from .aggregation import COMFORT, MGDA
 from .models import get_network
 from .optim import FusedAdam, FusedAdamW, clip_grad_norm_
@@ -71,22 +73,27 @@ def forward_backward_begin(net, images, optimizer, aggregator):
     optimizer.zero_grad()
     outputs = net(images)
     loss_dict = net.loss_function(images, args=outputs)
-    if aggregator is None or aggregator == "sum":
-        loss_dict["total_loss"].backward()
-        return loss_dict, outputs, None
-    features = [outputs[f] for f in net.features] if net.features is not None else None
-    component_losses = [v for k, v in loss_dict.items() if k != "total_loss"]  # main.py:184
-    if isinstance(aggregator, (MGDA, COMFORT)):  # main.py:185
-        aggregator.set_losses(torch.stack([c.detach() for c in component_losses]))
-    if features is None:
-        autojac.backward(component_losses, aggregator=aggregator)
-        return loss_dict, outputs, None
-    return loss_dict, outputs, autojac.mtl_backward_begin(component_losses, features, aggregator)
+    # weight gradients leave the backward's critical path (ops.wgrad_side_stream); the block's exit is the one join
+    with ops.wgrad_side_stream(images.device, enabled=L.DEFER_WGRAD_DEFAULT):
+        if aggregator is None or aggregator == "sum":
+            loss_dict["total_loss"].backward()
+            return loss_dict, outputs, None
+        features = [outputs[f] for f in net.features] if net.features is not None else None
+        component_losses = [v for k, v in loss_dict.items() if k != "total_loss"]  # main.py:184
+        if isinstance(aggregator, (MGDA, COMFORT)):  # main.py:185
+            aggregator.set_losses(torch.stack([c.detach() for c in component_losses]))
+        if features is None:
+            autojac.backward(component_losses, aggregator=aggregator)
+            return loss_dict, outputs, None
+        pending = autojac.mtl_backward_begin(component_losses, features, aggregator)
+    pending.device = images.device
+    return loss_dict, outputs, pending
 
 
 def forward_backward_finish(pending):
     if pending is not None:
-        autojac.mtl_backward_finish(pending)
+        with ops.wgrad_side_stream(pending.device, enabled=L.DEFER_WGRAD_DEFAULT):
+            autojac.mtl_backward_finish(pending)
 
 
 def forward_backward(net, images, optimizer, aggregator):
