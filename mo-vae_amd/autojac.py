@@ -58,6 +58,18 @@ def _view_like(flat, p):
     return flat.as_strided(p.shape, p.stride())
 
 
+_ONES = {}
+
+
+def _ones_like(t):
+    key = (t.device, t.dtype)
+    o = _ONES.get(key)
+    if o is None:
+        with torch.no_grad():
+            o = _ONES[key] = torch.ones((), dtype=t.dtype, device=t.device)
+    return o
+
+
 def _accumulate(p, g):
     if p.grad is None:
         p.grad = g
@@ -101,6 +113,21 @@ class JacobianBuffer:
 def _group(t, g):
     """Group g of a stacked gradient (a [G, ...] tensor or a list of G tensors)."""
     return None if t is None else t[g]
+
+
+def _restack(lst):
+    """Per-group results of a torch-native view node are usually G equal slices of one stacked buffer: hand them on as the
+    [G, ...] view they are (no copy), so that later accumulations / kernels see one tensor instead of a list."""
+    t0 = lst[0]
+    if not isinstance(t0, torch.Tensor) or not t0.is_contiguous() or t0.numel() == 0:
+        return lst
+    nbytes = t0.numel() * t0.element_size()
+    base = t0.untyped_storage().data_ptr()
+    for g, t in enumerate(lst):
+        if (not isinstance(t, torch.Tensor) or t.shape != t0.shape or t.dtype != t0.dtype or not t.is_contiguous() or
+                t.untyped_storage().data_ptr() != base or t.data_ptr() != t0.data_ptr() + g * nbytes):
+            return lst
+    return t0.as_strided((len(lst),) + tuple(t0.shape), (t0.numel(),) + tuple(t0.stride()), t0.storage_offset())
 
 
 def _accumulate_stacked(a, b, G):
@@ -222,7 +249,7 @@ def _batched_pullback(features, feat_grads, rows, jb):
                     for g in range(G):
                         r = fn(*[_group(a, g) for a in args])
                         per.append(r if isinstance(r, tuple) else (r,))
-                    outs = tuple(None if all(per[g][i] is None for g in range(G)) else [per[g][i] for g in range(G)]
+                    outs = tuple(None if all(per[g][i] is None for g in range(G)) else _restack([per[g][i] for g in range(G)])
                                  for i in range(len(per[0])))
             for i, (nf, nr) in enumerate(edges):
                 if nf is None:
@@ -275,7 +302,9 @@ def mtl_backward_begin(losses, features, aggregator, tasks_params=None, shared_p
     st.task_params = []
     for i, (loss, tp) in enumerate(zip(losses, tasks_params)):
         tp = list(tp)
-        got = torch.autograd.grad(loss, tp + st.feat_diff, retain_graph=True, allow_unused=True)
+        # the seed cotangent is a persistent ones tensor: autograd would launch a fill per loss for its implicit ones_like
+        seed = _ones_like(loss) if loss.dim() == 0 and loss.dtype == torch.float32 else None
+        got = torch.autograd.grad(loss, tp + st.feat_diff, grad_outputs=seed, retain_graph=True, allow_unused=True)
         for p, g in zip(tp, got[: len(tp)]):
             if g is not None:
                 _accumulate(p, g)

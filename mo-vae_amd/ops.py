@@ -48,13 +48,22 @@ def _stacked(t, G):
     return _c(t)
 
 
+_ZERO_GRADS = {}
+
+
 def _sink_zeros(param, shape):
     """An all-zero gradient: sinks are zero-initialised by their owner (autojac.JacobianBuffer) and written at most
-    once, so a registered sink is returned untouched -- no fill launch."""
+    once, so a registered sink is returned untouched -- no fill launch.  Without a sink the parameter gets ONE persistent
+    zero tensor for life (a bias in front of a training-mode BatchNorm: its gradient is identically zero, so whatever is
+    accumulated into this tensor later is zero as well); nothing here launches a fill per step."""
     dst = GRAD_SINK.pop(param.data_ptr(), None) if GRAD_SINK else None
     if dst is not None and dst.numel() == param.numel():
         return dst.view(shape)
-    return torch.zeros(shape, dtype=param.dtype, device=param.device)
+    key = (param.data_ptr(), param.numel(), param.dtype)
+    z = _ZERO_GRADS.get(key)
+    if z is None or z.device != param.device:
+        z = _ZERO_GRADS[key] = torch.zeros(param.numel(), dtype=param.dtype, device=param.device)
+    return z.view(shape)
 
 
 def _ws(t):
