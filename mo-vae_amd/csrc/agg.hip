@@ -162,22 +162,32 @@ __global__ void similarity_final(const double* __restrict__ part, int nblk, floa
 //   2 cosine (PNUPGrad's `normalize`, utils/torchmoo/pnupgrad.py:13-24)
 // dual != 0: torchjd DualProj -- ONE projection, of the whole preference vector u (default: the mean weights 1/K), instead of
 // one per row: w = u + argmin_{v >= 0} 1/2 v'Gv + (Gu)'v
-__global__ __launch_bounds__(64) void upgrad_k(const float* __restrict__ Gin, int K, int norm_mode, float norm_eps, float reg_eps,
+// KT = K at compile time (every loop unrolls, every array index is a constant, so the fp64 work lives in registers; with a
+// run-time K the 8x8 arrays sit in scratch memory and the K = 2 solve took 12 us instead of ~2).  An active set is handled
+// without compaction: rows / columns outside the free set are replaced by the identity and their right-hand side by 0, which
+// leaves the free block's Cholesky arithmetic untouched and yields v = 0 on the active coordinates.
+template <int KT>
+__global__ __launch_bounds__(64) void upgrad_k(const float* __restrict__ Gin, int norm_mode, float norm_eps, float reg_eps,
                                                const float* __restrict__ pref, float* __restrict__ wout, int dual) {
+    constexpr int K = KT;
     const int lane = threadIdx.x;
-    double G[MAXK][MAXK];
+    double G[K][K];
     if (norm_mode == 0) {
         double tr = 0.0;
+#pragma unroll
         for (int i = 0; i < K; ++i) tr += (double)Gin[i * K + i];
         const bool zero = tr < (double)norm_eps;
+#pragma unroll
         for (int i = 0; i < K; ++i)
+#pragma unroll
             for (int j = 0; j < K; ++j) G[i][j] = zero ? 0.0 : (double)Gin[i * K + j] / tr;
     } else {
         // the reference normalises with float32 tensor ops and only then hands the matrix to the fp64 QP; the same
         // roundings are kept here because the QP of a rank-deficient Gramian amplifies them by ~1 / reg_eps
-        float l2[MAXK], sf[MAXK];
+        float l2[K], sf[K];
         float amin = 0.f;
         bool any = false;
+#pragma unroll
         for (int i = 0; i < K; ++i) {
             l2[i] = sqrtf(fmaxf(Gin[i * K + i], norm_eps));
             if (l2[i] > norm_eps && (!any || l2[i] < amin)) {
@@ -185,74 +195,93 @@ __global__ __launch_bounds__(64) void upgrad_k(const float* __restrict__ Gin, in
                 any = true;
             }
         }
+#pragma unroll
         for (int i = 0; i < K; ++i) sf[i] = (any && l2[i] > norm_eps) ? amin / l2[i] : 0.f;
+#pragma unroll
         for (int i = 0; i < K; ++i)
+#pragma unroll
             for (int j = 0; j < K; ++j) {
                 const float g = Gin[i * K + j];
                 G[i][j] = norm_mode == 1 ? (double)(g * (sf[i] * sf[j])) : (double)(g / (l2[i] * l2[j]));
             }
     }
+#pragma unroll
     for (int i = 0; i < K; ++i) G[i][i] += (double)reg_eps;
-    double wsum[MAXK];
-    for (int i = 0; i < K; ++i) wsum[i] = 0.0;
-    const int nsub = 1 << K;
+    double u[K], wsum[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        u[i] = pref ? (double)pref[i] : 1.0 / K;
+        wsum[i] = 0.0;
+    }
+    constexpr int nsub = 1 << K;
     for (int row = 0; row < (dual ? 1 : K); ++row) {
-        const double ui = pref ? (double)pref[row] : 1.0 / K;
-        double c[MAXK];
-        for (int i = 0; i < K; ++i) c[i] = G[i][row] * ui;
-        if (dual)
-            for (int i = 0; i < K; ++i) {
-                c[i] = 0.0;
-                for (int j = 0; j < K; ++j) c[i] += G[i][j] * (pref ? (double)pref[j] : 1.0 / K);
-            }
-        double cmax = 1.0;
-        for (int i = 0; i < K; ++i) cmax = fmax(cmax, fabs(c[i]));
+        double c[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < K; ++j) acc += G[i][j] * ((dual || j == row) ? u[j] : 0.0);
+            c[i] = acc;  // one projection per row of diag(u): c = G[:, row] * u_row; DualProj: c = G u
+        }
         double best_viol = 1e300;
         int best_mask = 0;
-        double best_v[MAXK];
+        double best_v[K];
+#pragma unroll
         for (int i = 0; i < K; ++i) best_v[i] = 0.0;
         for (int mask = lane; mask < nsub; mask += 64) {
-            int idx[MAXK], nf = 0;
-            for (int i = 0; i < K; ++i)
-                if (mask >> i & 1) idx[nf++] = i;
-            double L[MAXK][MAXK], y[MAXK], v[MAXK];
+            double L[K][K], y[K], v[K];
             bool ok = true;
-            for (int a = 0; a < nf; ++a) {
+#pragma unroll
+            for (int a = 0; a < K; ++a) {
+                const bool fa = mask >> a & 1;
+#pragma unroll
                 for (int b = 0; b <= a; ++b) {
-                    double s = G[idx[a]][idx[b]];
+                    const bool fb = mask >> b & 1;
+                    double s = (fa && fb) ? G[a][b] : (a == b ? 1.0 : 0.0);
+#pragma unroll
                     for (int q = 0; q < b; ++q) s -= L[a][q] * L[b][q];
                     if (a == b) {
-                        if (s <= 0.0) { ok = false; s = 1.0; }
+                        if (s <= 0.0) {
+                            ok = false;
+                            s = 1.0;
+                        }
                         L[a][a] = sqrt(s);
                     } else {
                         L[a][b] = s / L[b][b];
                     }
                 }
             }
-            for (int a = 0; a < nf; ++a) {
-                double s = -c[idx[a]];
+#pragma unroll
+            for (int a = 0; a < K; ++a) {
+                double s = (mask >> a & 1) ? -c[a] : 0.0;
+#pragma unroll
                 for (int q = 0; q < a; ++q) s -= L[a][q] * y[q];
                 y[a] = s / L[a][a];
             }
-            for (int i = 0; i < K; ++i) v[i] = 0.0;
-            for (int a = nf - 1; a >= 0; --a) {
+#pragma unroll
+            for (int a = K - 1; a >= 0; --a) {
                 double s = y[a];
-                for (int q = a + 1; q < nf; ++q) s -= L[q][a] * v[idx[q]];
-                v[idx[a]] = s / L[a][a];
+#pragma unroll
+                for (int q = a + 1; q < K; ++q) s -= L[q][a] * v[q];
+                v[a] = s / L[a][a];
             }
             double viol = ok ? 0.0 : 1e200;
+#pragma unroll
             for (int i = 0; i < K; ++i) {
                 if (mask >> i & 1) {
                     viol = fmax(viol, -v[i]);
                 } else {
+                    v[i] = 0.0;  // exactly zero on the active set (the identity rows give +-0)
                     double gr = c[i];
-                    for (int j = 0; j < K; ++j) gr += G[i][j] * v[j];
+#pragma unroll
+                    for (int j = 0; j < K; ++j) gr += G[i][j] * ((mask >> j & 1) ? v[j] : 0.0);
                     viol = fmax(viol, -gr);
                 }
             }
             if (viol < best_viol) {
                 best_viol = viol;
                 best_mask = mask;
+#pragma unroll
                 for (int i = 0; i < K; ++i) best_v[i] = v[i];
             }
         }
@@ -260,20 +289,39 @@ __global__ __launch_bounds__(64) void upgrad_k(const float* __restrict__ Gin, in
         for (int o = 32; o > 0; o >>= 1) {
             const double ov = __shfl_xor(best_viol, o, 64);
             const int om = __shfl_xor(best_mask, o, 64);
-            double tmp[MAXK];
+            double tmp[K];
+#pragma unroll
             for (int i = 0; i < K; ++i) tmp[i] = __shfl_xor(best_v[i], o, 64);
             if (ov < best_viol || (ov == best_viol && om < best_mask)) {
                 best_viol = ov;
                 best_mask = om;
+#pragma unroll
                 for (int i = 0; i < K; ++i) best_v[i] = tmp[i];
             }
         }
-        for (int i = 0; i < K; ++i)
-            wsum[i] += best_v[i] + (dual ? (pref ? (double)pref[i] : 1.0 / K) : (i == row ? ui : 0.0));
-        (void)cmax;
+#pragma unroll
+        for (int i = 0; i < K; ++i) wsum[i] += best_v[i] + ((dual || i == row) ? u[i] : 0.0);
     }
     if (lane == 0)
+#pragma unroll
         for (int i = 0; i < K; ++i) wout[i] = (float)wsum[i];
+}
+
+inline void launch_upgrad(const float* G, int k, int norm_mode, float norm_eps, float reg_eps, const float* pref, float* w, int dual,
+                          hipStream_t st) {
+#define MOVAE_UPG(KV) \
+    hipLaunchKernelGGL((upgrad_k<KV>), dim3(1), dim3(64), 0, st, G, norm_mode, norm_eps, reg_eps, pref, w, dual)
+    switch (k) {
+        case 1: MOVAE_UPG(1); break;
+        case 2: MOVAE_UPG(2); break;
+        case 3: MOVAE_UPG(3); break;
+        case 4: MOVAE_UPG(4); break;
+        case 5: MOVAE_UPG(5); break;
+        case 6: MOVAE_UPG(6); break;
+        case 7: MOVAE_UPG(7); break;
+        default: MOVAE_UPG(8); break;
+    }
+#undef MOVAE_UPG
 }
 
 // ---- MGDA Frank-Wolfe (fp32, op order of utils/torchmoo/mgda.py:241-265) ------------------------------
@@ -581,7 +629,7 @@ int movae_weights_upgrad_norm(const float* G, int k, int norm_mode, float norm_e
     MOVAE_CHECK_ARG(G && w, "movae_weights_upgrad: null pointer");
     MOVAE_CHECK_ARG(k >= 1 && k <= MAXK, "movae_weights_upgrad: k=%d outside 1..%d", k, MAXK);
     MOVAE_CHECK_ARG(norm_mode >= 0 && norm_mode <= 2, "movae_weights_upgrad: unknown normalisation %d", norm_mode);
-    hipLaunchKernelGGL(upgrad_k, dim3(1), dim3(64), 0, (hipStream_t)stream, G, k, norm_mode, norm_eps, reg_eps, pref, w, 0);
+    launch_upgrad(G, k, norm_mode, norm_eps, reg_eps, pref, w, 0, (hipStream_t)stream);
     MOVAE_CHECK_LAUNCH("upgrad");
     return MOVAE_OK;
 }
@@ -589,7 +637,7 @@ int movae_weights_upgrad_norm(const float* G, int k, int norm_mode, float norm_e
 int movae_weights_dualproj(const float* G, int k, float norm_eps, float reg_eps, const float* pref, float* w, movae_stream_t stream) {
     MOVAE_CHECK_ARG(G && w, "movae_weights_dualproj: null pointer");
     MOVAE_CHECK_ARG(k >= 1 && k <= MAXK, "movae_weights_dualproj: k=%d outside 1..%d", k, MAXK);
-    hipLaunchKernelGGL(upgrad_k, dim3(1), dim3(64), 0, (hipStream_t)stream, G, k, 0, norm_eps, reg_eps, pref, w, 1);
+    launch_upgrad(G, k, 0, norm_eps, reg_eps, pref, w, 1, (hipStream_t)stream);
     MOVAE_CHECK_LAUNCH("dualproj");
     return MOVAE_OK;
 }
