@@ -6,6 +6,7 @@ are the reference's parameter shapes ([Co,Ci,kh,kw] / [Ci,Co,kh,kw]) held in cha
 so that `w.permute(0,2,3,1)` is the contiguous [.,kh,kw,.] image the kernels read.
 """
 import ctypes as C
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -152,12 +153,32 @@ class NhwcToNchw(Function):
         return (dx,)
 
 
+_LAST_NHWC = [None]  # (weakref to the NCHW source, its version counter, data_ptr, capturing?, the NHWC copy)
+
+
+def forget_nhwc():
+    """Drop the remembered conversion (train.GraphedTrainStep calls this around every capture: a result produced eagerly
+    must not stand in for a launch the graph has to contain, and graph-pool memory must not leak into eager code)."""
+    _LAST_NHWC[0] = None
+
+
+
 def to_nhwc(x):
-    """logical NCHW tensor -> NHWC tensor (zero copy when it already is a permuted NHWC buffer)."""
+    """logical NCHW tensor -> NHWC tensor (zero copy when it already is a permuted NHWC buffer).
+    A step converts the same constant input batch twice -- for the encoder and again for the losses -- so the most recent
+    conversion of a tensor that needs no gradient is remembered and handed out again while that tensor is unmodified."""
     v = x.permute(0, 2, 3, 1)
     if v.is_contiguous():
         return v
-    return NchwToNhwc.apply(x)
+    if x.requires_grad or torch.is_grad_enabled() and x.grad_fn is not None:
+        return NchwToNhwc.apply(x)
+    last = _LAST_NHWC[0]
+    cap = torch.cuda.is_current_stream_capturing()
+    if last is not None and last[0]() is x and last[1] == x._version and last[2] == x.data_ptr() and last[3] == cap:
+        return last[4]
+    out = NchwToNhwc.apply(x)
+    _LAST_NHWC[0] = (weakref.ref(x), x._version, x.data_ptr(), cap, out)
+    return out
 
 
 def flatten_nchw(x_nhwc):

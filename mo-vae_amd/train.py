@@ -161,8 +161,10 @@ class GraphedTrainStep:
             L.TRACE = lambda name, cargs: self.calls.append((name, cargs))
         try:
             if dp is None:
+                ops.forget_nhwc()
                 with torch.cuda.graph(self.graph):
                     self.loss_dict, self.outputs = train_step(net, self.static_x, optimizer, aggregator, args)
+                ops.forget_nhwc()
                 return
         finally:
             L.TRACE = None
@@ -175,6 +177,7 @@ class GraphedTrainStep:
         # once the task-side bucket's exchange is longer than that, i.e. not for the 13 MB of the 32x32 VAEs
         mode = os.environ.get("MOVAE_DP_OVERLAP", "auto")
         overlap = mode == "1" or (mode == "auto" and self.flat.numel() * 4 >= DP_OVERLAP_MIN_BYTES)
+        ops.forget_nhwc()
         with torch.cuda.graph(self.graph):
             self.loss_dict, self.outputs, pending = forward_backward_begin(net, self.static_x, optimizer, aggregator)
             if pending is not None and overlap:
@@ -186,6 +189,7 @@ class GraphedTrainStep:
             n_early = sum(p.numel() for p in early)
             self.flat_a = self.flat[:n_early]
             flatten_grads(early, out=self.flat_a)
+        ops.forget_nhwc()
         taken = {id(p) for p in early}
         late = [p for p in params if id(p) not in taken]
         self.graph_b, self.flat_b = None, None
