@@ -684,6 +684,11 @@ PAIR_SHAPES = [  # (transposed, n, hi, wi, ci, ho, wo, co, k, stride, pad)
     (False, 8, 32, 32, 3, 16, 16, 32, 3, 2, 1),   # 3-channel end: thin kernels, nothing pairs (the pending dgrad is flushed)
     (False, 16, 1, 1, 128, 1, 1, 64, 1, 1, 0),    # linear layer
     (False, 5, 7, 9, 8, 4, 5, 12, 3, 2, 1),       # ragged, partial tiles
+    (False, 16, 8, 8, 64, 8, 8, 64, 3, 1, 1),     # stride 1: a single parity class on the BWD-gather side
+    (False, 8, 16, 16, 32, 8, 8, 64, 4, 2, 1),    # 4x4 taps, stride 2 (the VQ-VAE encoders)
+    (True, 8, 8, 8, 64, 16, 16, 32, 4, 2, 1),     # ... and their transposed twins
+    (False, 4, 8, 8, 128, 8, 8, 32, 1, 1, 0),     # 1x1 conv on a feature map (residual stacks)
+    (True, 3, 5, 6, 16, 10, 12, 8, 3, 2, 1),      # transposed, ragged, output_padding 1
 ]
 
 
