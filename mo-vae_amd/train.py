@@ -266,8 +266,9 @@ def _host_values(loss_dict):
     return out
 
 
-def train_epoch(net, train_loader, optimizer, aggregator, step, device, args, dp=None, log=None):
-    """main.py:125-235."""
+def train_epoch(net, train_loader, optimizer, aggregator, step, device, args, dp=None, log=None, graphed=None):
+    """main.py:125-235.  `graphed` (a dict, `--graph on`): the step is captured into a hipGraph on the first full batch
+    (train.GraphedTrainStep) and replayed for every batch of that shape; ragged batches take the eager step."""
     global _current_step
     net.train()
     meters = {k: AverageMeter() for k in net.objectives.keys()}
@@ -278,7 +279,15 @@ def train_epoch(net, train_loader, optimizer, aggregator, step, device, args, dp
         _current_step = step + 1
         _hook_values.clear()
         try:
-            loss_dict, outputs = train_step(net, images, optimizer, aggregator, args, dp)
+            if graphed is not None and graphed.get("step") is None and images.size(0) == graphed["batch"]:
+                graphed["step"] = GraphedTrainStep(net, optimizer, aggregator, args, images, dp=dp)
+                graphed["hooks"] = dict(_hook_values)  # the weighting's forward hooks ran while capturing: static tensors
+            gs = graphed.get("step") if graphed is not None else None
+            if gs is not None and images.shape == gs.static_x.shape:
+                loss_dict, outputs = gs.step(images)
+                _hook_values.update(graphed["hooks"])
+            else:
+                loss_dict, outputs = train_step(net, images, optimizer, aggregator, args, dp)
         except RuntimeError as e:  # main.py:197-208: skip the batch on device-side assertion errors
             if "cuda" in str(e).lower() or "hip" in str(e).lower() or "assert" in str(e).lower():
                 print(f"Step {step}: device error during backward: {e}\n  Skipping this batch...")
@@ -354,18 +363,23 @@ SYNTHETIC = {"synthetic_cifar10": (32, 50000), "synthetic_celeba": (64, 162770),
 
 
 class SyntheticImages(torch.utils.data.Dataset):
-    """Seeded uniform [0,1) images (the un-normalised ToTensor range, utils/utils.py:187-192)."""
+    """Seeded uniform [0,1) images (the un-normalised ToTensor range, utils/utils.py:187-192).  Item i is entry
+    i mod POOL of a pool drawn once from the seed: the loader then costs a view per item instead of a generator per item
+    (the per-item generator held a 32x32 step at 38 ms; the device needs 1.2 ms)."""
+
+    POOL = 4096
 
     def __init__(self, n, size, seed, normalize=False):
         self.n, self.size, self.seed, self.normalize = n, size, seed, normalize
+        pool = min(n, max(64, min(self.POOL, (256 << 20) // (12 * size * size))))  # <= 256 MB of host memory
+        x = torch.rand(pool, 3, size, size, generator=torch.Generator().manual_seed(seed))
+        self.pool = 2 * x - 1 if normalize else x
 
     def __len__(self):
         return self.n
 
     def __getitem__(self, i):
-        g = torch.Generator().manual_seed(self.seed * 1_000_003 + i)
-        x = torch.rand(3, self.size, self.size, generator=g)
-        return (2 * x - 1 if self.normalize else x), 0
+        return self.pool[i % self.pool.size(0)], 0
 
 
 def get_dataset(name, data_dir="./data", normalize=False, max_items=None):
@@ -441,6 +455,9 @@ def build_parser():
     p.add_argument("--max_gen_metrics_samples", type=int, default=10000)
     p.add_argument("--skip_pixelcnn", action="store_true")
     # additions of this build (not in the reference)
+    p.add_argument("--graph", choices=["off", "on"], default="off",
+                   help="on: capture the step into a hipGraph on the first full batch and replay it (device-bound instead of "
+                        "host-bound; that first batch is also used for the capture's three warm-up steps)")
     p.add_argument("--max_items", type=int, default=None, help="cap the synthetic dataset length")
     p.add_argument("--max_steps", type=int, default=None, help="stop after this many optimisation steps")
     return p
@@ -502,7 +519,8 @@ def main(args):
     if dp is not None:
         sampler = torch.utils.data.distributed.DistributedSampler(train_ds, num_replicas=dp.world_size, rank=dp.rank,
                                                                   shuffle=True, seed=args.seed or 0)
-    loader_kw = dict(num_workers=args.num_workers, pin_memory=True, drop_last=False,
+    # pinning in the main thread (num_workers == 0) allocates and frees page-locked memory per batch: ~20 ms per batch on ROCm
+    loader_kw = dict(num_workers=args.num_workers, pin_memory=args.num_workers > 0, drop_last=False,
                      persistent_workers=args.num_workers > 0)
     train_loader = torch.utils.data.DataLoader(train_ds, batch_size=per_rank_bs, shuffle=sampler is None, sampler=sampler, **loader_kw)
     test_loader = torch.utils.data.DataLoader(test_ds, batch_size=per_rank_bs, shuffle=False, **loader_kw)
@@ -513,9 +531,17 @@ def main(args):
         setattr(args, f"{name}_weight", w)
     if dp is not None:
         dp.attach(net)
-    optimizer = make_optimizer(net, args)
-    scheduler = make_scheduler(optimizer, args)
     aggregator = aggregation.make_aggregator(args)
+    graphed = None
+    if getattr(args, "graph", "off") == "on":
+        # PNUPGrad / PCGrad draw torch's CPU generator per call, COMFORT's blend factor is a host scalar that changes per epoch
+        host_rng = isinstance(aggregator, (aggregation.PNUPGrad, aggregation.PCGrad, aggregation.COMFORT))
+        if getattr(net, "graph_safe", False) and not host_rng and args.optimizer.lower() in ("adam", "adamw"):
+            graphed = {"batch": per_rank_bs, "step": None}
+        else:
+            print("--graph on: this model / aggregator / optimizer combination is not replayable; running the eager step")
+    optimizer = make_optimizer(net, args, capturable=graphed is not None)
+    scheduler = make_scheduler(optimizer, args)
     if aggregator is not None and aggregator != "sum":
         aggregator.weighting.register_forward_hook(print_weights)
         aggregator.weighting.register_forward_hook(print_gd_similarity)
@@ -543,7 +569,7 @@ def main(args):
         if isinstance(aggregator, COMFORT):  # main.py:1290-1291
             aggregator.set_epoch(epoch, args.epochs)
         t0 = time.time()
-        meters, step = train_epoch(net, train_loader, optimizer, aggregator, step, device, args, dp, log)
+        meters, step = train_epoch(net, train_loader, optimizer, aggregator, step, device, args, dp, log, graphed)
         torch.cuda.synchronize()
         dt = time.time() - t0
         rec = {k: m.avg for k, m in meters.items()}

@@ -494,3 +494,30 @@ def test_data_parallel_graphed_step_single_rank_rccl(overlap, gpu_device, monkey
             assert_close(p, q.detach().cpu().numpy(), "dp param " + n, rtol=2e-4, atol=2e-5)
     finally:
         dp.shutdown()
+
+
+@pytest.mark.parametrize("graph", ["off", "on"])
+def test_cli_training_loop_eager_and_graphed(graph, gpu_device, tmp_path):
+    """The reference's loop (main.py:1088-1497 -> train.main) end to end on the synthetic data set: two epochs, evaluation,
+    checkpoint with the reference's keys -- once with the eager step and once with `--graph on` (the step captured on the first
+    full batch and replayed; the ragged last batch takes the eager step).  Both must train (loss falls, stays finite) and end
+    within a few percent of each other (the graphed run spends its three capture warm-up steps on the first batch)."""
+    import movae_amd  # noqa: F401
+    from movae_amd import train
+
+    argv = ["--dataset", "synthetic_cifar10", "--arch", "vae", "--agg", "upgrad", "--batch_size", "64", "--epochs", "2", "--max_items", "1000",
+            "--seed", "3", "--latent_dim", "16", "--hidden_dims", "16", "32", "64", "--graph", graph, "--save_path", str(tmp_path),
+            "--max_grad_norm", "5.0", "--device", "cuda:0"]
+    args = train.parse_args(argv)
+    hist = train.main(args)
+    assert len(hist) == 2 and all(np.isfinite(list(h.values())).all() for h in hist)
+    assert hist[1]["total_loss"] < hist[0]["total_loss"]
+    ckpts = list(tmp_path.rglob("final_checkpoint.pth"))
+    assert len(ckpts) == 1
+    ck = torch.load(ckpts[0], weights_only=False)
+    assert {"epoch", "model_state_dict", "args", "train_losses", "best_eval_loss"} <= set(ck)
+    test_cli_training_loop_eager_and_graphed.results = getattr(test_cli_training_loop_eager_and_graphed, "results", {})
+    test_cli_training_loop_eager_and_graphed.results[graph] = hist[1]["total_loss"]
+    r = test_cli_training_loop_eager_and_graphed.results
+    if len(r) == 2:
+        np.testing.assert_allclose(r["on"], r["off"], rtol=5e-2)
