@@ -119,6 +119,34 @@ def train_step(net, images, optimizer, aggregator, args, dp=None):
 DP_OVERLAP_MIN_BYTES = 32 << 20
 
 
+def _state_tensors(net):
+    extra = [t for t in (getattr(net, "_iter_dev", None),) if isinstance(t, torch.Tensor)]  # BetaTC's device-side step counter
+    return list(net.parameters()) + list(net.buffers()) + extra
+
+
+def _snapshot_state(net, optimizer, device):
+    return {"tensors": [t.detach().clone() for t in _state_tensors(net)],
+            "opt": {id(p): {k: v.detach().clone() for k, v in st.items() if torch.is_tensor(v)} for p, st in optimizer.state.items()},
+            "cuda_rng": torch.cuda.get_rng_state(device), "cpu_rng": torch.get_rng_state()}
+
+
+@torch.no_grad()
+def _restore_state(snap, net, optimizer, device):
+    torch.cuda.synchronize(device)
+    for t, s in zip(_state_tensors(net), snap["tensors"]):
+        t.copy_(s)
+    for p, st in optimizer.state.items():  # the state tensors keep their addresses (the captured graph points at them)
+        old = snap["opt"].get(id(p), {})
+        for k, v in st.items():
+            if torch.is_tensor(v):
+                if k in old:
+                    v.copy_(old[k])
+                else:
+                    v.zero_()
+    torch.cuda.set_rng_state(snap["cuda_rng"], device)
+    torch.set_rng_state(snap["cpu_rng"])
+
+
 class GraphedTrainStep:
     """The whole optimisation step (forward, losses, K per-loss backward passes, Gram / solve / combine,
     optimizer) captured ONCE into a hipGraph and replayed per batch: the step is ~250 short kernels, so
@@ -134,10 +162,21 @@ class GraphedTrainStep:
     Gradients under DP_OVERLAP_MIN_BYTES keep the single-bucket form (the split's fixed cost exceeds what it hides);
     MOVAE_DP_OVERLAP=0 / 1 forces either."""
 
-    def __init__(self, net, optimizer, aggregator, args, example, warmup=3, dp=None, record_calls=False):
+    def __init__(self, net, optimizer, aggregator, args, example, warmup=3, dp=None, record_calls=False, preserve_state=False):
         if not getattr(net, "graph_safe", False):
             raise NotImplementedError(f"{type(net).__name__}: forward syncs with the host; use the eager train_step")
         net.prepare_for_graph()
+        # preserve_state: the warm-up steps a capture needs are real optimisation steps; with this flag everything they
+        # touched (parameters, buffers, optimizer state, RNG streams) is rewound afterwards, so the first replay is step 1
+        # of the run exactly as the eager loop would have made it (train_epoch uses this)
+        snap = _snapshot_state(net, optimizer, example.device) if preserve_state else None
+        try:
+            self._build(net, optimizer, aggregator, args, example, warmup, dp, record_calls)
+        finally:
+            if snap is not None:
+                _restore_state(snap, net, optimizer, example.device)
+
+    def _build(self, net, optimizer, aggregator, args, example, warmup, dp, record_calls):
         self.net, self.opt, self.agg, self.args, self.dp = net, optimizer, aggregator, args, dp
         self.static_x = example.clone()
         from . import _lib as L
@@ -280,7 +319,7 @@ def train_epoch(net, train_loader, optimizer, aggregator, step, device, args, dp
         _hook_values.clear()
         try:
             if graphed is not None and graphed.get("step") is None and images.size(0) == graphed["batch"]:
-                graphed["step"] = GraphedTrainStep(net, optimizer, aggregator, args, images, dp=dp)
+                graphed["step"] = GraphedTrainStep(net, optimizer, aggregator, args, images, dp=dp, preserve_state=True)
                 graphed["hooks"] = dict(_hook_values)  # the weighting's forward hooks ran while capturing: static tensors
             gs = graphed.get("step") if graphed is not None else None
             if gs is not None and images.shape == gs.static_x.shape:
@@ -455,9 +494,10 @@ def build_parser():
     p.add_argument("--max_gen_metrics_samples", type=int, default=10000)
     p.add_argument("--skip_pixelcnn", action="store_true")
     # additions of this build (not in the reference)
-    p.add_argument("--graph", choices=["off", "on"], default="off",
-                   help="on: capture the step into a hipGraph on the first full batch and replay it (device-bound instead of "
-                        "host-bound; that first batch is also used for the capture's three warm-up steps)")
+    p.add_argument("--graph", choices=["auto", "off", "on"], default="auto",
+                   help="auto / on: capture the step into a hipGraph on the first full batch and replay it (device-bound "
+                        "instead of host-bound; the capture's warm-up steps are rewound, so the run makes the eager loop's "
+                        "steps -- only random draws inside the step come from the graph's own Philox offsets); auto falls back to the eager step silently where replay is not possible, on says so")
     p.add_argument("--max_items", type=int, default=None, help="cap the synthetic dataset length")
     p.add_argument("--max_steps", type=int, default=None, help="stop after this many optimisation steps")
     return p
@@ -533,12 +573,12 @@ def main(args):
         dp.attach(net)
     aggregator = aggregation.make_aggregator(args)
     graphed = None
-    if getattr(args, "graph", "off") == "on":
+    if getattr(args, "graph", "off") in ("on", "auto"):
         # PNUPGrad / PCGrad draw torch's CPU generator per call, COMFORT's blend factor is a host scalar that changes per epoch
         host_rng = isinstance(aggregator, (aggregation.PNUPGrad, aggregation.PCGrad, aggregation.COMFORT))
         if getattr(net, "graph_safe", False) and not host_rng and args.optimizer.lower() in ("adam", "adamw"):
             graphed = {"batch": per_rank_bs, "step": None}
-        else:
+        elif args.graph == "on":
             print("--graph on: this model / aggregator / optimizer combination is not replayable; running the eager step")
     optimizer = make_optimizer(net, args, capturable=graphed is not None)
     scheduler = make_scheduler(optimizer, args)

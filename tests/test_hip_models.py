@@ -500,8 +500,9 @@ def test_data_parallel_graphed_step_single_rank_rccl(overlap, gpu_device, monkey
 def test_cli_training_loop_eager_and_graphed(graph, gpu_device, tmp_path):
     """The reference's loop (main.py:1088-1497 -> train.main) end to end on the synthetic data set: two epochs, evaluation,
     checkpoint with the reference's keys -- once with the eager step and once with `--graph on` (the step captured on the first
-    full batch and replayed; the ragged last batch takes the eager step).  Both must train (loss falls, stays finite) and end
-    within a few percent of each other (the graphed run spends its three capture warm-up steps on the first batch)."""
+    full batch and replayed; the ragged last batch takes the eager step; the capture's warm-up steps are rewound).  Both must
+    train (loss falls, stays finite) and end at the same loss level: same data order, same initial state, same number of
+    steps -- only the reparameterisation noise differs (a replayed graph draws it from the graph-safe Philox offsets)."""
     import movae_amd  # noqa: F401
     from movae_amd import train
 
@@ -520,4 +521,4 @@ def test_cli_training_loop_eager_and_graphed(graph, gpu_device, tmp_path):
     test_cli_training_loop_eager_and_graphed.results[graph] = hist[1]["total_loss"]
     r = test_cli_training_loop_eager_and_graphed.results
     if len(r) == 2:
-        np.testing.assert_allclose(r["on"], r["off"], rtol=5e-2)
+        np.testing.assert_allclose(r["on"], r["off"], rtol=2e-2)
