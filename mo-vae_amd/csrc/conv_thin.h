@@ -590,7 +590,8 @@ inline bool thin_out_tile_plan(const Geom& g, const float* X, int& TH, int& TW, 
     if (TW < 1) return false;
     // two pixels per thread halve the weight reads per FMA but also the block count (measured: better from ~200k pixels)
     const long px_total = (long)g.Nimg * g.Ho * g.Wo;
-    for (int ppt = px_total >= 200000L ? 2 : 1; ppt >= 1; --ppt) {
+    static const int force_ppt = getenv("MOVAE_THIN_PPT") ? atoi(getenv("MOVAE_THIN_PPT")) : 0;  // tuning knob
+    for (int ppt = force_ppt ? force_ppt : (px_total >= 200000L ? 2 : 1); ppt >= 1; --ppt) {
         int th = 256 * ppt / TW;
         if (BWD) th = th / 2 * 2;
         if (th < (BWD ? 2 : 1)) continue;
