@@ -731,6 +731,41 @@ def test_paired_dgrad_wgrad_is_bit_identical(M, shape, groups):
         assert torch.isfinite(a).all() and torch.equal(a, b)
 
 
+def test_to_nhwc_remembers_only_unmodified_constant_inputs(M):
+    """ops.to_nhwc hands out the previous conversion of the same NCHW tensor only while that tensor is unmodified, needs no
+    gradient and no capture boundary lies in between (the step converts its input batch twice)."""
+    ops, _ = M
+    x = torch.rand(4, 3, 8, 8).cuda()
+    a = ops.to_nhwc(x)
+    assert ops.to_nhwc(x) is a                      # same object, same version: remembered
+    x.mul_(2.0)                                     # in-place change bumps the version counter
+    b = ops.to_nhwc(x)
+    assert b is not a and torch.equal(b, x.permute(0, 2, 3, 1))
+    y = x.clone()
+    assert ops.to_nhwc(y) is not b                  # another tensor
+    xr = torch.rand(4, 3, 8, 8).cuda().requires_grad_(True)
+    c1, c2 = ops.to_nhwc(xr), ops.to_nhwc(xr)       # differentiable inputs always get their own autograd node
+    assert c1 is not c2
+    ops.forget_nhwc()
+    assert ops.to_nhwc(y) is not None
+    v = torch.rand(4, 8, 8, 3).cuda().permute(0, 3, 1, 2)  # already NHWC memory: zero-copy view
+    assert ops.to_nhwc(v).data_ptr() == v.data_ptr()
+
+
+def test_restack_rebuilds_stacked_views_only(M):
+    """autojac._restack: G equal, adjacent, contiguous slices of one buffer come back as the [G, ...] view of that buffer
+    (no copy); anything else stays a list."""
+    from movae_amd import autojac
+
+    buf = torch.arange(2 * 3 * 4, dtype=torch.float32).cuda().reshape(2, 3, 4)
+    r = autojac._restack([buf[0].view(12), buf[1].view(12)])
+    assert isinstance(r, torch.Tensor) and r.shape == (2, 12) and r.data_ptr() == buf.data_ptr() and torch.equal(r, buf.view(2, 12))
+    assert isinstance(autojac._restack([buf[1], buf[0]]), list)                  # wrong order
+    assert isinstance(autojac._restack([buf[0], buf[0].clone()]), list)         # different storage
+    assert isinstance(autojac._restack([buf[0, :2], buf[1, :2]]), list)          # not adjacent
+    assert isinstance(autojac._restack([buf[0].t(), buf[1].t()]), list)          # not contiguous
+
+
 def test_invalid_arguments_raise(M):
     ops, agg = M
     with pytest.raises(RuntimeError):
