@@ -23,6 +23,10 @@ struct Geom {
     int Hi, Wi, Cr;  // gathered tensor: spatial dims, reduction channels
     int Ho, Wo, Nn;  // output pixel grid, output channels
     int KH, KW, stride, pad;
+    // FWD gather only, 0 = dense: the taps form a KH x KW window of a larger stored kernel -- the weight row of one output
+    // channel has wrow floats, starts woff floats in, and every wlen floats (one window row) jump to the next stored row
+    // wstride floats on (tap_window(): 1x1 outputs whose other taps only ever meet padding)
+    int wrow, wlen, wstride, woff;
 };
 
 struct Epilogue {
@@ -637,7 +641,7 @@ inline int choose_split(int form, int tile_area, int bk, long tiles, int nk, siz
 #include "linear_small.h"
 
 inline bool is_linear(const Geom& g) {
-    return g.KH == 1 && g.KW == 1 && g.Hi == 1 && g.Wi == 1 && g.Ho == 1 && g.Wo == 1 && g.stride == 1 && g.pad == 0;
+    return g.KH == 1 && g.KW == 1 && g.Hi == 1 && g.Wi == 1 && g.Ho == 1 && g.Wo == 1 && g.stride == 1 && g.pad == 0 && g.wlen == 0;
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -670,8 +674,32 @@ int launch_fwd_t(const float* X, const float* W, float* Y, const Geom& g, const 
     return MOVAE_OK;
 }
 
-int launch_fwd(const float* X, const float* W, float* Y, const Geom& g, const Epilogue& ep, void* ws, size_t ws_bytes,
+// A 1x1 output grid reads tap (kh, kw) at input (kh - pad, kw - pad) for every image alike: taps outside the image multiply
+// padding only.  The window of taps that can hit the image becomes the kernel (pad 0) and the stored weights are addressed
+// through Geom::wrow/wlen/wstride/woff.  conv 2x2x256 -> 1x1x512 (k3 s2 p1): K 2304 -> 1024.
+inline bool tap_window(const Geom& g, Geom* out) {
+    static const bool enabled = !getenv("MOVAE_NO_TAPWIN");
+    if (!enabled || g.Ho != 1 || g.Wo != 1 || g.pad >= g.KH || g.pad >= g.KW) return false;
+    const int nkh = g.KH - g.pad < g.Hi ? g.KH - g.pad : g.Hi, nkw = g.KW - g.pad < g.Wi ? g.KW - g.pad : g.Wi;
+    if (nkh < 1 || nkw < 1 || nkh * nkw == g.KH * g.KW) return false;
+    *out = g;
+    out->KH = nkh, out->KW = nkw, out->pad = 0;
+    out->wrow = g.KH * g.KW * g.Cr;
+    out->wlen = nkw * g.Cr, out->wstride = g.KW * g.Cr, out->woff = (g.pad * g.KW + g.pad) * g.Cr;
+    return true;
+}
+
+int launch_fwd(const float* X, const float* W, float* Y, const Geom& g_in, const Epilogue& ep, void* ws, size_t ws_bytes,
                hipStream_t st) {
+    Geom g = g_in;
+    {
+        const long Kfull = (long)g.KH * g.KW * g.Cr;
+        Geom gw;
+        // (fast MFMA path only: the other kernels address dense weights)
+        if (g.Cr % 4 == 0 && aligned16(X) && aligned16(W) && !is_linear(g) && !thin::thin_in_ok(g) && g.Nn > 4 && Kfull <= 0x7fffffffL &&
+            tap_window(g, &gw))
+            g = gw;
+    }
     const long Ml = (long)g.Nimg * g.Ho * g.Wo;
     const long Kl = (long)g.KH * g.KW * g.Cr;
     if (Ml <= 0 || g.Nn <= 0 || Kl <= 0 || Ml > 0x7fffffffL) {

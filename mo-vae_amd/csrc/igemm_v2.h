@@ -164,11 +164,12 @@ __device__ __forceinline__ void igemm2_fwd_body(const FwdArgs& a, float* __restr
     }
     const float* b_base[BC];
     bool b_ok[BC];
+    const int wrow = g.wlen ? g.wrow : K;  // floats per output channel in the stored weights (tap window: Geom)
 #pragma unroll
     for (int i = 0; i < BC; ++i) {
         const int n = n0 + r8 + RPP * i;
         b_ok[i] = n < N;
-        b_base[i] = W + (long)(b_ok[i] ? n : 0) * K;
+        b_base[i] = W + (long)(b_ok[i] ? n : 0) * wrow + g.woff;
     }
     const int nk_total = (K + BK2 - 1) / BK2;
     const int kt_begin = bz * ktiles_per_split;
@@ -187,8 +188,9 @@ __device__ __forceinline__ void igemm2_fwd_body(const FwdArgs& a, float* __restr
             const bool v = kv && a_ok[i] && h >= 0 && h < g.Hi && w >= 0 && w < g.Wi;
             ra[i] = v ? *reinterpret_cast<const f32x4*>(a_base[i] + ((long)h * g.Wi + w) * g.Cr + c) : ZERO4;
         }
+        const int kb = g.wlen ? (kk / g.wlen) * g.wstride + kk % g.wlen : kk;  // window row -> stored kernel row
 #pragma unroll
-        for (int i = 0; i < BC; ++i) rb[i] = (kv && b_ok[i]) ? *reinterpret_cast<const f32x4*>(b_base[i] + kk) : ZERO4;
+        for (int i = 0; i < BC; ++i) rb[i] = (kv && b_ok[i]) ? *reinterpret_cast<const f32x4*>(b_base[i] + kb) : ZERO4;
     };
 
     f32x16 acc[T::TM * T::TN];

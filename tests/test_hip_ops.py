@@ -61,6 +61,9 @@ CONV_CASES = [
     (2, 3, 16, 16, 64, 4, 2, 1),     # ... with 4x4 taps and two 32-channel blocks
     (2, 32, 9, 7, 3, 3, 1, 1),       # 3-channel output, stride 1: thin wgrad sweep kernel (thin = small side)
     (2, 64, 40, 36, 3, 3, 1, 1),     # ... several tiles per image, two channel blocks
+    (4, 32, 1, 1, 48, 3, 1, 1),      # 1x1 input, 3x3 taps: the tap window is the centre tap alone (and it is NOT a linear layer)
+    (3, 16, 2, 2, 24, 4, 2, 1),      # 2x2 -> 1x1 with 4x4 taps: window rows/cols 1..2 of the stored kernel
+    (2, 256, 2, 2, 512, 3, 2, 1),    # the C2 layer itself: K 2304 -> 1024
 ]
 
 
