@@ -483,6 +483,24 @@ __device__ __forceinline__ void igemm2_wgrad_body(const WgArgs& a, float* __rest
     const float* __restrict__ Sm = a.Sm + grp * a.s_gs;
     const float* __restrict__ Bg = a.Bg + grp * a.b_gs;
     const int k_begin = split * kchunk, k_end = min(K, k_begin + kchunk);
+    if (g.Hs == 1 && g.Ws == 1) {
+        // a 1x1 small side meets tap (kh, kw) at big-side pixel (kh - pad, kw - pad) only: column tiles whose taps all fall
+        // outside the image are identically zero -- store the zeros, skip the reduction (5 of 9 taps for 2x2 <-> 1x1, k3 p1)
+        const int t0 = n0 / g.Cb, t1 = (min(n0 + BN, N) - 1) / g.Cb;
+        bool any = false;
+        for (int tp = t0; tp <= t1; ++tp) {
+            const int h = tp / g.KW - g.pad, w = tp % g.KW - g.pad;
+            any = any || (h >= 0 && h < g.Hb && w >= 0 && w < g.Wb);
+        }
+        if (!any) {
+            float* dst0 = to_slab ? out + (long)bz * M * N : a.tab.p[grp];
+            for (int i = t; i < BM * BN; i += 256) {  // scalar stores: a Jacobian-row destination is only 4-byte aligned
+                const int m = m0 + i / BN, n = n0 + i % BN;
+                if (m < M && n < N) dst0[(long)m * N + n] = 0.f;
+            }
+            return;
+        }
+    }
     constexpr int AQ = BM / 4, BQ = BN / 4;
     constexpr int ACH = BK2 * AQ / 256, BCH = BK2 * BQ / 256;
     constexpr int AKS = 256 / AQ, BKS = 256 / BQ;
