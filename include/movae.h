@@ -235,10 +235,13 @@ int movae_weights_amtl(const float* G, int k, int scale_mode, const float* pref,
  *             regularised Gramian -- movae_weights_upgrad's QP solved once;
  *   PCGrad    gradient surgery on the Gramian; perm = K rows of a permutation of 0..K-1 (int32, device), row i is the
  *             order in which task i is de-conflicted against the others (the reference: torch.randperm per task);
- *   IMTL-G    w = pinv(G) d / sum(pinv(G) d), d_i = sqrt(G_ii); zeros when the sum vanishes. */
+ *   IMTL-G    w = pinv(G) d / sum(pinv(G) d), d_i = sqrt(G_ii); zeros when the sum vanishes;
+ *   CAGrad    w = 1/K + c g0 / sqrt(w*'G w*) w*, w* = argmin over the simplex of (G 1/K)'w + c g0 sqrt(w'Gw), g0 = sqrt(1/K' G 1/K)
+ *             (main.py:1216-1217: c = 1.0); the mean weights when c g0 or sqrt(w*'G w*) is <= norm_eps. */
 int movae_weights_dualproj(const float* G, int k, float norm_eps, float reg_eps, const float* pref, float* w, movae_stream_t stream);
 int movae_weights_pcgrad(const float* G, int k, const int32_t* perm, float* w, movae_stream_t stream);
 int movae_weights_imtlg(const float* G, int k, float* w, movae_stream_t stream);
+int movae_weights_cagrad(const float* G, int k, float c, float norm_eps, float* w, movae_stream_t stream);
 /* constant weightings (torchjd Sum / Mean) */
 int movae_weights_const(int k, float value, float* w, movae_stream_t stream);
 /* g[m] (+)= sum_i w[i] J[i][:]  ; also usable as the hook's J.T @ w (main.py:112-118) */

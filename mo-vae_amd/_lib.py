@@ -78,6 +78,7 @@ SIGNATURES = {
     "movae_weights_dualproj": ([_p, _i, _f, _f, _p, _p, _p], _i),
     "movae_weights_pcgrad": ([_p, _i, _p, _p, _p], _i),
     "movae_weights_imtlg": ([_p, _i, _p, _p], _i),
+    "movae_weights_cagrad": ([_p, _i, _f, _f, _p, _p], _i),
     "movae_weights_const": ([_i, _f, _p, _p], _i),
     "movae_combine": ([_p, _z, _i, _z, _p, _p, _i, _p], _i),
     "movae_gd_similarity": ([_p, _z, _i, _z, _p, _p, _p, _z, _p], _i),

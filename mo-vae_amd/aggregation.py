@@ -357,6 +357,32 @@ class IMTLG(GramianWeightedAggregator):
         return "IMTLG()"
 
 
+class CAGradWeighting(Weighting):
+    def __init__(self, c, norm_eps=1e-4):
+        super().__init__()
+        if c < 0.0:
+            raise ValueError(f"Parameter `c` should be a non-negative float. Found `c = {c}`.")
+        self.c, self.norm_eps = c, norm_eps
+
+    def forward(self, G):
+        k = G.shape[0]
+        w = torch.empty(k, dtype=torch.float32, device=G.device)
+        L.call("movae_weights_cagrad", G.data_ptr(), k, float(self.c), float(self.norm_eps), w.data_ptr(), _st(G))
+        return w
+
+
+class CAGrad(GramianWeightedAggregator):
+    """torchjd.aggregation.CAGrad(c, norm_eps) as constructed at main.py:1216-1217 (cvxpy / CLARABEL there; a closed-form
+    KKT enumeration on the device here -- see csrc/agg.hip)."""
+
+    def __init__(self, c, norm_eps=0.0001):
+        super().__init__(CAGradWeighting(c, norm_eps))
+        self._c, self._norm_eps = c, norm_eps
+
+    def __repr__(self):
+        return f"CAGrad(c={self._c}, norm_eps={self._norm_eps})"
+
+
 def beta_schedule(epoch, total_epochs, k=1.0, a=1.0, l=0.01, u=1.0):
     """utils/torchmoo/comfort.py:20-66."""
     import math
@@ -408,7 +434,7 @@ class COMFORT:
                 f"beta_a={self._beta_a}, beta_l={self._beta_l}, beta_u={self._beta_u})")
 
 
-OUT_OF_SCOPE = ("cagrad", "nashmtl")  # both need a conic solver (cvxpy + clarabel / ECOS in torchjd) per step
+OUT_OF_SCOPE = ("nashmtl",)  # stateful, solves a cvxpy problem (ECOS) every `update_weights_every` steps
 
 
 def make_aggregator(args):
@@ -449,11 +475,13 @@ def make_aggregator(args):
         return PCGrad()
     if name == "imtlg":
         return IMTLG()
+    if name == "cagrad":
+        return CAGrad(c=1.0, norm_eps=args.agg_norm_eps)
     if name == "dualproj":
         return DualProj(norm_eps=args.agg_norm_eps, reg_eps=args.agg_reg_eps)
     if name == "sum":
         return "sum"
     if name in OUT_OF_SCOPE:
         raise NotImplementedError(f"Aggregator {args.aggregator} exists in the reference but is outside this build's scope "
-                                  "(sum, upgrad, nupgrad, pnupgrad, comfort, mgda*, aligned_mtl*, mean, jd_sum, pcgrad, imtlg, dualproj); see DESIGN.md")
+                                  "(sum, upgrad, nupgrad, pnupgrad, comfort, mgda*, aligned_mtl*, mean, jd_sum, pcgrad, imtlg, dualproj, cagrad); see DESIGN.md")
     raise ValueError(f"Aggregator {args.aggregator} not supported")

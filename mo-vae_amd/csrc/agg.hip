@@ -307,6 +307,170 @@ __global__ __launch_bounds__(64) void upgrad_k(const float* __restrict__ Gin, in
         for (int i = 0; i < K; ++i) wout[i] = (float)wsum[i];
 }
 
+// ---- torchjd CAGrad (Liu et al. 2021) ---------------------------------------------------------------------------------
+// u = 1/K, b = G u, kappa = c sqrt(u'Gu):  w* = argmin_{w in simplex} b'w + kappa sqrt(w'Gw),  weights = u + kappa / sqrt(w*'Gw*) w*
+// (the mean weights when kappa or sqrt(w*'Gw*) is <= norm_eps).  On a support S the KKT system is closed-form:
+//   G_S w = (t / kappa)(lambda 1 - b_S),  p = G_S^-1 1, q = G_S^-1 b_S,  A = 1'p, B = 1'q, C = b_S'q,
+//   kappa^2 = A lambda^2 - 2 B lambda + C  (larger root),  w = (lambda p - q) / (lambda A - B)
+// one lane per support, masked-identity Cholesky in fp64 as in upgrad_k, wave arg-min on the KKT violation.  torchjd solves the
+// same cone problem with cvxpy / CLARABEL; Gramians with a null direction inside the simplex (singular supports are skipped
+// here) are where the two can differ.  Raw Gramian: CAGrad neither normalises nor regularises.
+template <int KT>
+__global__ __launch_bounds__(64) void cagrad_k(const float* __restrict__ Gin, float c, float norm_eps, float* __restrict__ wout) {
+    constexpr int K = KT;
+    const int lane = threadIdx.x;
+    double G[K][K], b[K];
+    double tr = 0.0, uGu = 0.0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            G[i][j] = 0.5 * ((double)Gin[i * K + j] + (double)Gin[j * K + i]);
+            uGu += G[i][j];
+        }
+        tr += G[i][i];
+    }
+    uGu /= (double)K * K;
+    const double kappa = (double)c * sqrt(fmax(uGu, 0.0)), jitter = 1e-14 * tr;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < K; ++j) acc += G[i][j];
+        b[i] = acc / K;
+    }
+    double best_viol = 1e300;
+    int best_mask = 0;
+    double best_w[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) best_w[i] = 0.0;
+    for (int mask = lane + 1; mask < (1 << K); mask += 64) {
+        double L[K][K], yp[K], yq[K], p[K], q[K], w[K];
+        bool ok = true;
+#pragma unroll
+        for (int a = 0; a < K; ++a) {
+            const bool fa = mask >> a & 1;
+#pragma unroll
+            for (int bb = 0; bb <= a; ++bb) {
+                const bool fb = mask >> bb & 1;
+                double s = (fa && fb) ? G[a][bb] + (a == bb ? jitter : 0.0) : (a == bb ? 1.0 : 0.0);
+#pragma unroll
+                for (int r = 0; r < bb; ++r) s -= L[a][r] * L[bb][r];
+                if (a == bb) {
+                    if (s <= 0.0) {
+                        ok = false;
+                        s = 1.0;
+                    }
+                    L[a][a] = sqrt(s);
+                } else {
+                    L[a][bb] = s / L[bb][bb];
+                }
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < K; ++a) {
+            const bool fa = mask >> a & 1;
+            double sp = fa ? 1.0 : 0.0, sq = fa ? b[a] : 0.0;
+#pragma unroll
+            for (int r = 0; r < a; ++r) {
+                sp -= L[a][r] * yp[r];
+                sq -= L[a][r] * yq[r];
+            }
+            yp[a] = sp / L[a][a];
+            yq[a] = sq / L[a][a];
+        }
+#pragma unroll
+        for (int a = K - 1; a >= 0; --a) {
+            double sp = yp[a], sq = yq[a];
+#pragma unroll
+            for (int r = a + 1; r < K; ++r) {
+                sp -= L[r][a] * p[r];
+                sq -= L[r][a] * q[r];
+            }
+            p[a] = sp / L[a][a];
+            q[a] = sq / L[a][a];
+        }
+        double A = 0.0, B = 0.0, C = 0.0;
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+            if (mask >> i & 1) {
+                A += p[i];
+                B += q[i];
+                C += b[i] * q[i];
+            }
+        const double disc = B * B - A * (C - kappa * kappa);
+        ok = ok && disc >= 0.0 && A > 0.0;
+        const double lam = ok ? (B + sqrt(disc)) / A : 0.0, den = lam * A - B;
+        ok = ok && den > 0.0;
+#pragma unroll
+        for (int i = 0; i < K; ++i) w[i] = (ok && (mask >> i & 1)) ? (lam * p[i] - q[i]) / den : 0.0;
+        double Gw[K], wGw = 0.0;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < K; ++j) acc += G[i][j] * w[j];
+            Gw[i] = acc;
+            wGw += w[i] * acc;
+        }
+        const double t = sqrt(fmax(wGw, 0.0));
+        ok = ok && t > 0.0;
+        double viol = ok ? 0.0 : 1e200;
+        if (ok) {
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                if (mask >> i & 1) viol = fmax(viol, -w[i]);
+                else viol = fmax(viol, -(b[i] + kappa * Gw[i] / t - lam));
+            }
+        }
+        if (viol < best_viol) {
+            best_viol = viol;
+            best_mask = mask;
+#pragma unroll
+            for (int i = 0; i < K; ++i) best_w[i] = w[i];
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(best_viol, o, 64);
+        const int om = __shfl_xor(best_mask, o, 64);
+        double tmp[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) tmp[i] = __shfl_xor(best_w[i], o, 64);
+        if (ov < best_viol || (ov == best_viol && om < best_mask)) {
+            best_viol = ov;
+            best_mask = om;
+#pragma unroll
+            for (int i = 0; i < K; ++i) best_w[i] = tmp[i];
+        }
+    }
+    if (lane == 0) {
+        double wGw = 0.0;
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+#pragma unroll
+            for (int j = 0; j < K; ++j) wGw += best_w[i] * G[i][j] * best_w[j];
+        const double gw = sqrt(fmax(wGw, 0.0));
+        const bool mean = kappa <= (double)norm_eps || best_viol >= 1e199 || gw <= (double)norm_eps;
+#pragma unroll
+        for (int i = 0; i < K; ++i) wout[i] = (float)(mean ? 1.0 / K : 1.0 / K + kappa / gw * best_w[i]);
+    }
+}
+
+inline void launch_cagrad(const float* G, int k, float c, float norm_eps, float* w, hipStream_t st) {
+#define MOVAE_CAG(KV) hipLaunchKernelGGL((cagrad_k<KV>), dim3(1), dim3(64), 0, st, G, c, norm_eps, w)
+    switch (k) {
+        case 1: MOVAE_CAG(1); break;
+        case 2: MOVAE_CAG(2); break;
+        case 3: MOVAE_CAG(3); break;
+        case 4: MOVAE_CAG(4); break;
+        case 5: MOVAE_CAG(5); break;
+        case 6: MOVAE_CAG(6); break;
+        case 7: MOVAE_CAG(7); break;
+        default: MOVAE_CAG(8); break;
+    }
+#undef MOVAE_CAG
+}
+
 inline void launch_upgrad(const float* G, int k, int norm_mode, float norm_eps, float reg_eps, const float* pref, float* w, int dual,
                           hipStream_t st) {
 #define MOVAE_UPG(KV) \
@@ -639,6 +803,15 @@ int movae_weights_dualproj(const float* G, int k, float norm_eps, float reg_eps,
     MOVAE_CHECK_ARG(k >= 1 && k <= MAXK, "movae_weights_dualproj: k=%d outside 1..%d", k, MAXK);
     launch_upgrad(G, k, 0, norm_eps, reg_eps, pref, w, 1, (hipStream_t)stream);
     MOVAE_CHECK_LAUNCH("dualproj");
+    return MOVAE_OK;
+}
+
+int movae_weights_cagrad(const float* G, int k, float c, float norm_eps, float* w, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(G && w, "movae_weights_cagrad: null pointer");
+    MOVAE_CHECK_ARG(k >= 1 && k <= MAXK, "movae_weights_cagrad: k=%d outside 1..%d", k, MAXK);
+    MOVAE_CHECK_ARG(c >= 0.f, "Parameter `c` should be a non-negative float. Found `c = %g`.", (double)c);
+    launch_cagrad(G, k, c, norm_eps, w, (hipStream_t)stream);
+    MOVAE_CHECK_LAUNCH("cagrad");
     return MOVAE_OK;
 }
 

@@ -147,6 +147,56 @@ def imtlg_weights(G):
     return (torch.zeros_like(v) if vs.abs() < 1e-12 else v / vs).numpy()
 
 
+def cagrad_weights(G, c=1.0, norm_eps=1e-4):
+    """torchjd CAGrad (Liu et al. 2021; main.py:1216-1217 builds CAGrad(c=1.0, norm_eps)): with u = 1/K, g0 = sqrt(u'Gu),
+    w* = argmin over the simplex of (Gu)'w + c g0 sqrt(w'Gw); weights = u + (c g0 / sqrt(w*'Gw*)) w*, the mean weights when
+    c g0 <= norm_eps or sqrt(w*'Gw*) <= norm_eps.  torchjd hands the cone problem to cvxpy / CLARABEL; here the KKT system
+    is solved in closed form on every support S (G_S w = (t / kappa)(lambda 1 - b_S), a quadratic in lambda) and the
+    support with the least KKT violation wins -- checked against torchjd's documented example and scipy SLSQP.
+    parity unpinned."""
+    Gd = np.asarray(G.detach().cpu().numpy() if isinstance(G, torch.Tensor) else G, dtype=np.float64)
+    K = Gd.shape[0]
+    u = np.full(K, 1.0 / K)
+    kappa = c * np.sqrt(max(u @ Gd @ u, 0.0))
+    if kappa <= norm_eps:
+        return u
+    b = Gd @ u
+    best, best_viol = None, np.inf
+    jitter = 1e-14 * np.trace(Gd)
+    for r in range(1, K + 1):
+        for S in itertools.combinations(range(K), r):
+            S = list(S)
+            GS = Gd[np.ix_(S, S)] + jitter * np.eye(r)
+            try:
+                np.linalg.cholesky(GS)
+            except np.linalg.LinAlgError:
+                continue
+            p, q = np.linalg.solve(GS, np.ones(r)), np.linalg.solve(GS, b[S])
+            A, B, C = p.sum(), q.sum(), b[S] @ q
+            disc = B * B - A * (C - kappa ** 2)
+            if disc < 0 or A <= 0:
+                continue
+            lam = (B + np.sqrt(disc)) / A
+            den = lam * A - B
+            if den <= 0:
+                continue
+            w = np.zeros(K)
+            w[S] = (lam * p - q) / den
+            t = np.sqrt(max(w @ Gd @ w, 0.0))
+            if t <= 0:
+                continue
+            grad = b + kappa * (Gd @ w) / t - lam
+            viol = max([0.0] + [-w[i] for i in S] + [-grad[i] for i in range(K) if i not in S])
+            if viol < best_viol:
+                best, best_viol = w, viol
+    if best is None:
+        return u
+    gw = np.sqrt(max(best @ Gd @ best, 0.0))
+    if gw <= norm_eps:
+        return u
+    return u + (kappa / gw) * best
+
+
 # ---- MGDA (utils/torchmoo/mgda.py:221-367) ---------------------------------------------
 def mgda_weights(G, norm_type="none", losses=None, epsilon=1e-5, max_iters=250,
                  stable=False, min_eigenvalue_eps=1e-10, return_iters=False):
@@ -246,6 +296,8 @@ def make_weighting(name, **kw):
         return lambda G, losses=None: pcgrad_weights(G)
     if n == "imtlg":
         return lambda G, losses=None: imtlg_weights(G)
+    if n == "cagrad":
+        return lambda G, losses=None: cagrad_weights(G, kw.get("c", 1.0), kw.get("norm_eps", 1e-4))
     if n == "mean":
         return lambda G, losses=None: np.full(len(G), 1.0 / len(G))
     if n == "jd_sum":

@@ -136,10 +136,11 @@ def test_aggregator_factory_names(pkg):
     c.set_epoch(10, 10)
     assert abs(c._get_beta() - 1.0) < 1e-12
     assert isinstance(mk("pcgrad"), A.PCGrad) and isinstance(mk("imtlg"), A.IMTLG) and isinstance(mk("dualproj"), A.DualProj)
-    with pytest.raises(NotImplementedError):
-        mk("cagrad")
+    assert isinstance(mk("cagrad"), A.CAGrad) and mk("cagrad")._c == 1.0
     with pytest.raises(NotImplementedError):
         mk("nashmtl")
+    with pytest.raises(ValueError):
+        A.CAGrad(c=-1.0)
     with pytest.raises(ValueError):
         mk("bogus")
     with pytest.raises(ValueError):

@@ -474,6 +474,10 @@ def test_dualproj_pcgrad_imtlg_vs_oracle(M, case):
         want = OA.pcgrad_weights(G)
         torch.manual_seed(seed)
         np.testing.assert_allclose(agg.PCGradWeighting()(Gd).cpu().numpy(), want, rtol=1e-5, atol=1e-6)
+    for c in (0.5, 1.0):
+        want = OA.cagrad_weights(G, c)
+        got = agg.CAGradWeighting(c)(Gd).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=2e-4, atol=1e-5 * max(1.0, np.abs(want).max()), err_msg=f"cagrad c={c}")
     want = OA.imtlg_weights(G)
     got = agg.IMTLGWeighting()(Gd).cpu().numpy()
     if np.linalg.matrix_rank(G.astype(np.float64), tol=len(G) * 1.2e-7 * np.linalg.norm(G, 2) * 10) == len(G):
@@ -492,6 +496,7 @@ def test_aggregator_docstring_kats(M):
     np.testing.assert_allclose(agg.DualProj()(J).cpu().numpy(), [0.5563, 1.1109, 1.1109], atol=5e-5)
     np.testing.assert_allclose(agg.PCGrad()(J).cpu().numpy(), [0.5848, 3.8012, 3.8012], atol=5e-5)
     np.testing.assert_allclose(agg.IMTLG()(J).cpu().numpy(), [0.0767, 1.0, 1.0], atol=5e-5)
+    np.testing.assert_allclose(agg.CAGrad(c=0.5)(J).cpu().numpy(), [0.1835, 1.2041, 1.2041], atol=5e-5)
     np.testing.assert_allclose(agg.MGDA(norm_type="l2")(J).cpu().numpy(), [1.0, 1.0, 1.0], atol=1e-5)
     A = agg.MGDA(norm_type="loss")
     A.set_losses(torch.tensor([0.5, 2.0]).cuda())

@@ -329,7 +329,7 @@ def test_edge_matching_variants_match_reference_methods(case):
     assert seen >= (6 if case == "flat" else 10)
 
 
-def test_torchjd_dualproj_pcgrad_imtlg_usage_examples():
+def test_torchjd_dualproj_pcgrad_imtlg_cagrad_usage_examples():
     """torchjd's documented usage example J = [[-4, 1, 1], [6, 1, 1]] (the same matrix utils/torchmoo/mgda.py:54-86 and
     nupgrad.py:58-62 quote for MGDA / UPGrad): DualProj -> [0.5563, 1.1109, 1.1109], PCGrad -> [0.5848, 3.8012, 3.8012],
     IMTLG -> [0.0767, 1.0000, 1.0000].  The only published vectors for these three (torchjd is absent): parity unpinned
@@ -341,6 +341,10 @@ def test_torchjd_dualproj_pcgrad_imtlg_usage_examples():
     for w, want in ((OA.dualproj_weights(G), [0.5563, 1.1109, 1.1109]), (OA.pcgrad_weights(G), [0.5848, 3.8012, 3.8012]),
                     (OA.imtlg_weights(G), [0.0767, 1.0, 1.0])):
         np.testing.assert_allclose((torch.as_tensor(w, dtype=torch.float32) @ J).numpy(), want, atol=5e-5)
+    # CAGrad(c=0.5) on the same matrix: torchjd documents [0.1835, 1.2041, 1.2041]
+    np.testing.assert_allclose((torch.as_tensor(OA.cagrad_weights(G, 0.5), dtype=torch.float32) @ J).numpy(), [0.1835, 1.2041, 1.2041],
+                               atol=5e-5)
+    np.testing.assert_allclose(OA.cagrad_weights(np.zeros((3, 3)), 1.0), np.full(3, 1 / 3))  # c g0 <= norm_eps: mean weights
     # DualProj = the single-row case of the UPGrad projection; K = 1 degenerates to the mean weight
     np.testing.assert_allclose(OA.dualproj_weights(np.array([[2.0]])), [1.0])
     np.testing.assert_allclose(OA.imtlg_weights(np.zeros((3, 3))), np.zeros(3))
