@@ -275,7 +275,9 @@ def main():
     net, opt, agg, a, pool = build_workload(cfg, device, capturable=use_graph)
     if dp is not None:
         dp.attach(net)
-    graphed = GraphedTrainStep(net, opt, agg, a, pool[0], dp=dp, record_calls=(rank == 0 and not args.no_roofline)) if use_graph else None
+    # the roofline block (like the CPU baseline) belongs to the N = 1 line; the scaling runs report throughput only
+    want_roofline = rank == 0 and world == 1 and dp is None and not args.no_roofline
+    graphed = GraphedTrainStep(net, opt, agg, a, pool[0], dp=dp, record_calls=want_roofline) if use_graph else None
     if graphed is not None and dp is not None:
         # watchdog: if graph replay + collective misbehaves on this node (observed when several ranks share one
         # GPU under gloo), every rank falls back to the eager step together
@@ -314,7 +316,7 @@ def main():
     final_loss = float(ld["total_loss"].item())
 
     roofline = None
-    if rank == 0 and not args.no_roofline:
+    if want_roofline:
         live = graphed is not None and len(graphed.calls) > 0
         if live:
             recorded = graphed.calls  # operands owned by the captured graph's pool: re-issued in place

@@ -216,6 +216,31 @@ class GraphedTrainStep:
         # once the task-side bucket's exchange is longer than that, i.e. not for the 13 MB of the 32x32 VAEs
         mode = os.environ.get("MOVAE_DP_OVERLAP", "auto")
         overlap = mode == "1" or (mode == "auto" and self.flat.numel() * 4 >= DP_OVERLAP_MIN_BYTES)
+        # One bucket over RCCL: the collective is captured too, so the whole data-parallel step is ONE replay.  Three pieces
+        # (graph, eager all-reduce, graph) cost ~110 us per step in cross-queue hand-offs on MI355X (1.415 vs 1.306 ms with one
+        # hardware queue); inside one graph the collective is just another kernel node.  gloo cannot be captured, and
+        # MOVAE_DP_CAPTURE_COLLECTIVE=0 (or a failing capture) falls back to the pieces.
+        if not overlap and dp.backend == "nccl" and os.environ.get("MOVAE_DP_CAPTURE_COLLECTIVE", "1") != "0":
+            try:
+                ops.forget_nhwc()
+                whole = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(whole):
+                    self.loss_dict, self.outputs = forward_backward(net, self.static_x, optimizer, aggregator)
+                    self.flat_a = self.flat[: sum(p.numel() for p in params)]
+                    flatten_grads(params, out=self.flat_a)
+                    self.reduce(self.flat_a)
+                    unflatten_into_grads(self.flat_a, params)
+                    if getattr(args, "max_grad_norm", None) is not None:
+                        clip_grad_norm_(params, max_norm=args.max_grad_norm)
+                    optimizer.step()
+                ops.forget_nhwc()
+                self.graph, self.graph_b, self.flat_b = whole, None, None
+                return
+            except Exception as e:  # noqa: BLE001 -- any capture failure: rebuild as pieces below
+                print(f"[movae] capturing the all-reduce failed ({type(e).__name__}: {e}); using graph / all-reduce / graph", flush=True)
+                torch.cuda.synchronize()
+                optimizer.zero_grad(set_to_none=True)
+                self.graph = torch.cuda.CUDAGraph()
         ops.forget_nhwc()
         with torch.cuda.graph(self.graph):
             self.loss_dict, self.outputs, pending = forward_backward_begin(net, self.static_x, optimizer, aggregator)

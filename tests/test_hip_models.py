@@ -440,12 +440,13 @@ def test_hipgraph_replay_matches_eager_steps(case, gpu_device):
         assert 0.0 < float(gs.outputs["codebook_usage_percentage"]) <= 100.0
 
 
-@pytest.mark.parametrize("overlap", ["0", "1"])
+@pytest.mark.parametrize("overlap", ["0", "0-pieces", "1"])
 def test_data_parallel_graphed_step_single_rank_rccl(overlap, gpu_device, monkeypatch):
-    """The N>1 code path of GraphedTrainStep driven with ONE rank over the real RCCL backend, in both forms: one bucket
-    (graph 1 -> all-reduce -> graph 2 = gradient clipping + fused Adam) and the overlapped two-bucket form (graph 1 ->
-    all-reduce(task side) under graph 1b -> all-reduce(shared) -> graph 2).  The mean over one rank is the identity, so
-    losses and parameters must equal the eager single-device loop, clipping included."""
+    """The N>1 code path of GraphedTrainStep driven with ONE rank over the real RCCL backend, in its three forms: one bucket
+    with the all-reduce captured inside the step's single graph ("0"), one bucket as graph 1 -> eager all-reduce -> graph 2
+    ("0-pieces", the fallback and the gloo form), and the overlapped two-bucket form (graph 1 -> all-reduce(task side) under
+    graph 1b -> all-reduce(shared) -> graph 2).  The mean over one rank is the identity, so losses and parameters must equal
+    the eager single-device loop, clipping included."""
     import torch.distributed as dist
 
     import movae_amd  # noqa: F401
@@ -457,7 +458,8 @@ def test_data_parallel_graphed_step_single_rank_rccl(overlap, gpu_device, monkey
     if dist.is_initialized():
         pytest.skip("a process group is already up in this process")
     monkeypatch.setenv("MOVAE_FORCE_DP", "1")
-    monkeypatch.setenv("MOVAE_DP_OVERLAP", overlap)
+    monkeypatch.setenv("MOVAE_DP_OVERLAP", overlap[0])
+    monkeypatch.setenv("MOVAE_DP_CAPTURE_COLLECTIVE", "0" if overlap == "0-pieces" else "1")
     monkeypatch.setenv("WORLD_SIZE", "1")
     monkeypatch.setenv("RANK", "0")
     monkeypatch.setenv("LOCAL_RANK", "0")
@@ -477,7 +479,8 @@ def test_data_parallel_graphed_step_single_rank_rccl(overlap, gpu_device, monkey
     batches = [torch.rand(16, 3, 32, 32, generator=g).to(gpu_device) for _ in range(3)]
     net_e, a = make()
     opt_e, agg_e = make_optimizer(net_e, a, capturable=True), aggregation.make_aggregator(a)
-    for _ in range(4):  # the DP twin runs 3 warm-up steps plus one real step while it builds its two graphs
+    # the DP twin runs 3 warm-up steps, plus one real step while it builds the graph / all-reduce / graph pieces
+    for _ in range(3 if overlap == "0" else 4):
         train_step(net_e, batches[0], opt_e, agg_e, a)
     want = [train_step(net_e, b, opt_e, agg_e, a)[0]["total_loss"].item() for b in batches]
     dp = DataParallelGrads.from_env(backend="nccl")
@@ -487,7 +490,7 @@ def test_data_parallel_graphed_step_single_rank_rccl(overlap, gpu_device, monkey
         dp.attach(net_g)
         opt_g = make_optimizer(net_g, a2, capturable=True)
         gs = GraphedTrainStep(net_g, opt_g, aggregation.make_aggregator(a2), a2, batches[0], dp=dp)
-        assert gs.graph2 is not None and (gs.graph_b is not None) == (overlap == "1")
+        assert (gs.graph2 is None) == (overlap == "0") and (gs.graph_b is not None) == (overlap == "1")
         got = [gs.step(b)[0]["total_loss"].item() for b in batches]
         np.testing.assert_allclose(got, want, rtol=2e-5)
         for (n, p), (_, q) in zip(net_g.named_parameters(), net_e.named_parameters()):

@@ -35,16 +35,26 @@ def main():
 
     cfg = dict(bench.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "C2"])
     dev = torch.device("cuda:0")
-    net, opt, agg, a, pool = bench.build_workload(cfg, dev, capturable=True)
-    single = GraphedTrainStep(net, opt, agg, a, pool[0])
-    t_single = timed(lambda: single.step(pool[0]))
+    t_single = float("nan")
+    if "nosingle" not in sys.argv:  # (the single-device graph first: reference point, and it warms the allocator / kernels)
+        net, opt, agg, a, pool = bench.build_workload(cfg, dev, capturable=True)
+        single = GraphedTrainStep(net, opt, agg, a, pool[0])
+        t_single = timed(lambda: single.step(pool[0]))
     dp = DataParallelGrads.from_env()
     net2, opt2, agg2, a2, pool2 = bench.build_workload(cfg, dev, capturable=True)
     dp.attach(net2)
     gs = GraphedTrainStep(net2, opt2, agg2, a2, pool2[0], dp=dp)
-    out = {"single_graph_us": t_single, "dp_step_us": timed(lambda: gs.step(pool2[0])),
+    it = [0]
+
+    def rotating():
+        it[0] += 1
+        gs.step(pool2[it[0] % len(pool2)])
+
+    out = {"single_graph_us": t_single, "dp_step_us": timed(lambda: gs.step(pool2[0])), "dp_step_rotating_inputs_us": timed(rotating),
            "graph1_us": timed(gs.graph.replay), "all_reduce_a_us": timed(lambda: gs.reduce(gs.flat_a)),
-           "graph2_us": timed(gs.graph2.replay), "bucket_a_MB": gs.flat_a.numel() * 4 / 1e6}
+           "bucket_a_MB": gs.flat_a.numel() * 4 / 1e6}
+    if gs.graph2 is not None:  # (None: the collective and the optimizer are inside graph 1)
+        out["graph2_us"] = timed(gs.graph2.replay)
     if gs.graph_b is not None:
         out.update(graph1b_us=timed(gs.graph_b.replay), all_reduce_b_us=timed(lambda: gs.reduce(gs.flat_b)),
                    bucket_b_MB=gs.flat_b.numel() * 4 / 1e6)
