@@ -212,6 +212,10 @@ class GraphedTrainStep:
         self.flat = torch.zeros(sum(p.numel() for p in params) + 64, dtype=torch.float32, device=example.device)
         # RCCL averages inside the collective (ncclAvg); gloo (CPU rehearsal of the N>1 path) has no AVG: sum, then scale
         self._avg = dp.backend == "nccl"
+        # the process group's watchdog thread polls events of earlier collectives; under the default "global" capture mode
+        # such a query from another thread invalidates the capture (seen at C4, whose capture is long enough to collide)
+        cap = dict(capture_error_mode="thread_local")
+        torch.cuda.synchronize()
         # splitting the step costs one more graph launch and two cross-stream waits (~60 us measured on MI355X); it pays
         # once the task-side bucket's exchange is longer than that, i.e. not for the 13 MB of the 32x32 VAEs
         mode = os.environ.get("MOVAE_DP_OVERLAP", "auto")
@@ -224,7 +228,7 @@ class GraphedTrainStep:
             try:
                 ops.forget_nhwc()
                 whole = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(whole):
+                with torch.cuda.graph(whole, **cap):
                     self.loss_dict, self.outputs = forward_backward(net, self.static_x, optimizer, aggregator)
                     self.flat_a = self.flat[: sum(p.numel() for p in params)]
                     flatten_grads(params, out=self.flat_a)
@@ -242,7 +246,7 @@ class GraphedTrainStep:
                 optimizer.zero_grad(set_to_none=True)
                 self.graph = torch.cuda.CUDAGraph()
         ops.forget_nhwc()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, **cap):
             self.loss_dict, self.outputs, pending = forward_backward_begin(net, self.static_x, optimizer, aggregator)
             if pending is not None and overlap:
                 shared = {id(p) for p in pending.shared_params}
@@ -261,7 +265,7 @@ class GraphedTrainStep:
             off = (n_early + 63) // 64 * 64  # keep the second bucket 256-byte aligned
             self.flat_b = self.flat[off: off + sum(p.numel() for p in late)]
             self.graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_b, pool=self.graph.pool()):
+            with torch.cuda.graph(self.graph_b, pool=self.graph.pool(), **cap):
                 forward_backward_finish(pending)
                 flatten_grads(late, out=self.flat_b)
         # the capture passes recorded but did not execute: materialise real gradients once
@@ -270,7 +274,7 @@ class GraphedTrainStep:
         if late:
             unflatten_into_grads(self.flat_b, late)
         self.graph2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph2, pool=self.graph.pool()):
+        with torch.cuda.graph(self.graph2, pool=self.graph.pool(), **cap):
             if not self._avg:
                 self.flat.div_(dp.world_size)
             if getattr(args, "max_grad_norm", None) is not None:  # same tail as train_step: clip the averaged gradient
