@@ -39,6 +39,7 @@ CONFIGS = {
 CONV_CALLS = {"movae_conv2d_fwd", "movae_conv2d_dgrad", "movae_conv2d_wgrad", "movae_convT2d_fwd", "movae_convT2d_dgrad",
               "movae_convT2d_wgrad", "movae_conv2d_wgrad_grouped", "movae_convT2d_wgrad_grouped",
               "movae_conv2d_dgrad_wgrad_grouped", "movae_convT2d_dgrad_wgrad_grouped"}
+POOL_BATCHES = 24               # distinct synthetic batches cycled by the timed loop (>= 20)
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 HBM_PEAK_GBS = 8000.0
 
@@ -67,6 +68,25 @@ def conv_call_flops(name, a):
     return both * 2.0 * groups * n * pix * kh * kw * ci * co
 
 
+def _valid_taps_1d(n_from, n_to, k, stride, pad):
+    """#(position, tap) pairs of one axis whose partner position p * stride - pad + tap lies inside [0, n_to)."""
+    return sum(1 for p in range(n_from) for t in range(k) if 0 <= p * stride - pad + t < n_to)
+
+
+def conv_call_flops_executed(name, a):
+    """FLOPs of the multiply-adds that meet real data: taps that only ever multiply zero padding (or fall off the output of a
+    transposed conv) are not counted.  The nominal count above includes them; on the deep CIFAR layers they are a
+    large share (2x2 -> 1x1, k3 s2 p1: 4 of 9 taps execute)."""
+    off, groups = _geom_offset(name, a)
+    n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad = a[off: off + 11]
+    if "convT" in name:  # every input pixel scatters to hi * s - pad + tap
+        pairs = _valid_taps_1d(hi, ho, kh, stride, pad) * _valid_taps_1d(wi, wo, kw, stride, pad)
+    else:                # every output pixel gathers from ho * s - pad + tap
+        pairs = _valid_taps_1d(ho, hi, kh, stride, pad) * _valid_taps_1d(wo, wi, kw, stride, pad)
+    both = 2.0 if "dgrad_wgrad" in name else 1.0
+    return both * 2.0 * groups * n * pairs * ci * co
+
+
 def conv_call_bytes(name, a):
     """Algorithmic bytes of one conv-family call: each operand and the result touched once (fp32)."""
     off, groups = _geom_offset(name, a)
@@ -81,7 +101,7 @@ def conv_call_key(name, a):
     return (name,) + tuple(a[off: off + 11]) + ((groups,) if groups > 1 else ())
 
 
-def build_workload(cfg, device, seed=0, capturable=False):
+def build_workload(cfg, device, seed=0, capturable=False, pool=None):
     import movae_amd  # noqa: F401
     from movae_amd import aggregation
     from movae_amd.models import get_network
@@ -97,12 +117,15 @@ def build_workload(cfg, device, seed=0, capturable=False):
     opt = make_optimizer(net, a, capturable=capturable)
     agg = aggregation.make_aggregator(a)
     g = torch.Generator().manual_seed(seed + 1)
-    pool = [torch.rand(cfg["batch"], 3, cfg["size"], cfg["size"], generator=g).to(device) for _ in range(8)]
+    pool = [torch.rand(cfg["batch"], 3, cfg["size"], cfg["size"], generator=g).to(device)
+            for _ in range(POOL_BATCHES if pool is None else pool)]
     return net, opt, agg, a, pool
 
 
-def cpu_baseline(cfg, seconds):
-    """The CPU oracle ("port" of the reference step, oracle/step.py) timed on this box's host cores."""
+def cpu_baseline(cfg, seconds, device=None, check_steps=20):
+    """The CPU oracle ("port" of the reference step, oracle/step.py) timed on this box's host cores; with `device`, also the
+    ELBO check: a fresh HIP model and the oracle take the same `check_steps` optimisation steps (same init, same batches, same
+    CPU-drawn eps) and the loss dicts of the last step are reported side by side."""
     from oracle import nets
     from oracle.step import OracleTrainer
 
@@ -114,19 +137,43 @@ def cpu_baseline(cfg, seconds):
     ocfg = nets.make_cfg(cfg["arch"], cfg["size"], cfg["batch"], cfg["dataset_size"], **kw)
     tr = OracleTrainer(ocfg, seed=0, agg=cfg["agg"])
     g = torch.Generator().manual_seed(1)
-    x = torch.rand(cfg["batch"], 3, cfg["size"], cfg["size"], generator=g)
     need_eps = nets.ARCHS[cfg["arch"]]["needs_eps"]
-    eps = torch.randn(cfg["batch"], cfg.get("latent_dim", 1), generator=g) if need_eps else None
-    tr.step(x, eps)  # warm-up
+    nb = 4
+    xs = [torch.rand(cfg["batch"], 3, cfg["size"], cfg["size"], generator=g) for _ in range(nb)]
+    es = [torch.randn(cfg["batch"], cfg.get("latent_dim", 1), generator=g) if need_eps else None for _ in range(nb)]
+    check = None
+    if device is not None and check_steps > 0:
+        from movae_amd.models.betatc_vae import BetaTCVAE
+        from movae_amd.train import train_step
+
+        BetaTCVAE.num_iter = 0
+        net, opt, agg, a, _ = build_workload(cfg, device, seed=0, pool=0)
+        hip = ora = None
+        for i in range(check_steps):
+            if need_eps:
+                net.eps_override = es[i % nb].to(device)
+            ld, _ = train_step(net, xs[i % nb].to(device), opt, agg, a)
+            hip = {k: float(v) for k, v in ld.items()}
+            ora = tr.step(xs[i % nb], es[i % nb])
+        rel = {k: abs(hip[k] - ora[k]) / max(abs(ora[k]), 1e-12) for k in ora}
+        check = dict(steps=check_steps, hip_losses=hip, oracle_losses=ora, max_rel_diff=max(rel.values()),
+                     note="same init / batches / eps on both sides; eager HIP step vs oracle/step.py")
+        del net, opt
+        BetaTCVAE.num_iter = 0
+        tr = OracleTrainer(ocfg, seed=0, agg=cfg["agg"])
+    tr.step(xs[0], es[0])  # warm-up
     n, t0 = 0, time.perf_counter()
     while True:
-        tr.step(x, eps)
+        tr.step(xs[n % nb], es[n % nb])
         n += 1
         dt = time.perf_counter() - t0
         if dt >= seconds or n >= 2000:
             break
-    return dict(value=cfg["batch"] * n / dt, unit="images/sec", cores=torch.get_num_threads(), kind="port",
-                sample=f"{n} steps of {cfg['label']} (oracle/step.py, PyTorch-CPU fp32, {dt:.1f} s)")
+    out = dict(value=cfg["batch"] * n / dt, unit="images/sec", cores=torch.get_num_threads(), kind="port",
+               sample=f"{n} steps of {cfg['label']} (oracle/step.py, PyTorch-CPU fp32, {dt:.1f} s)")
+    if check is not None:
+        out["elbo_check"] = check
+    return out
 
 
 FAMILY = [("conv", "movae_conv"), ("batchnorm", "movae_bn_"), ("loss", "movae_recon"), ("loss", "movae_kl"), ("loss", "movae_tc"),
@@ -231,7 +278,8 @@ def measure_dominant_kernel(recorded, device, reps=20, live=False):
         finally:
             lib.movae_bench_main_kernel_only(0)
         rows.append(dict(call=name, kernel=kernel, shape=list(conv_call_key(name, a)[1:]), us=us, us_main=us_main,
-                         gflop=conv_call_flops(name, a) / 1e9, alg_bytes=conv_call_bytes(name, a)))
+                         gflop=conv_call_flops(name, a) / 1e9, gflop_executed=conv_call_flops_executed(name, a) / 1e9,
+                         alg_bytes=conv_call_bytes(name, a)))
     return rows, other
 
 
@@ -242,7 +290,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", type=str, default="C2", choices=sorted(CONFIGS))
     ap.add_argument("--agg", type=str, default=None)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps each (median reported)")
+    ap.add_argument("--min-gpu-seconds", type=float, default=6.0, help="keep repeating the timed block for at least this long")
+    ap.add_argument("--elbo-check-steps", type=int, default=20, help="HIP vs oracle loss check inside the cpu_baseline leg (0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
@@ -272,6 +323,12 @@ def main():
 
     dp = DataParallelGrads.from_env() if (world > 1 or os.environ.get("MOVAE_FORCE_DP")) else None
     use_graph = args.graph != "off"  # every hot-path model is capturable (no host reads inside the step)
+    # the CPU leg runs FIRST (rank 0, N = 1): the GPU then stays busy from here to the end of the run, which is what a coarse
+    # utilisation sampler around the process can see
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(cfg, args.cpu_seconds, device=device, check_steps=args.elbo_check_steps)
+        torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
     net, opt, agg, a, pool = build_workload(cfg, device, capturable=use_graph)
     if dp is not None:
         dp.attach(net)
@@ -299,20 +356,44 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    if dp is not None:
-        dp.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ld, _ = step(i)
-    torch.cuda.synchronize()
-    if dp is not None:
-        dp.barrier()
-    elapsed = time.perf_counter() - t0
-    if dp is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+
+    def timed_block(first):
+        """EXACTLY --steps steps between barrier + device synchronisation on both sides; max over ranks."""
+        if dp is not None:
+            dp.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ld = None
+        for i in range(args.steps):
+            ld, _ = step(first + i)
+        torch.cuda.synchronize()
+        if dp is not None:
+            dp.barrier()
+        dt = time.perf_counter() - t0
+        if dp is not None:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, ld
+
+    # the timed block is repeated (>= --repeats times, and until the GPU has been timed for --min-gpu-seconds): the reported
+    # value is the MEDIAN block, min / max are given beside it
+    times = []
+    first, ld = args.warmup, None
+    t_begin = time.perf_counter()
+    while True:
+        dt, ld = timed_block(first)
+        first += args.steps
+        times.append(dt)
+        enough = len(times) >= args.repeats and (time.perf_counter() - t_begin) >= args.min_gpu_seconds
+        if dp is not None:  # all ranks must leave the loop together
+            flag = torch.tensor([1 if enough else 0], device=device, dtype=torch.int32)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            enough = bool(flag.item())
+        if enough or len(times) >= 5000:
+            break
+    ts = sorted(times)
+    elapsed = ts[len(ts) // 2]
     final_loss = float(ld["total_loss"].item())
 
     roofline = None
@@ -334,29 +415,36 @@ def main():
         # the largest time per step; the whole conv family (all kernels + their epilogue launches) is given beside it
         groups = {}
         for r in rows:
-            gk = groups.setdefault(r["kernel"], dict(us=0.0, gflop=0.0, n=0))
+            gk = groups.setdefault(r["kernel"], dict(us=0.0, gflop=0.0, gflop_x=0.0, n=0))
             gk["us"] += r["us_main"]
             gk["gflop"] += r["gflop"]
+            gk["gflop_x"] += r["gflop_executed"]
             gk["n"] += 1
         mfma_groups = {k: v for k, v in groups.items() if k.startswith("igemm")} or groups
         dom = max(mfma_groups, key=lambda k: mfma_groups[k]["us"])
         d = groups[dom]
         # memory-side bytes per launch of that kernel from the committed PMC passes (profiles/pmc_traffic_<cfg>.json)
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.config}.json")
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get("kernels", {}).get(dom, {}).get("hbm_bytes_per_launch")
+            if traffic is not None:
+                traffic_source = f"profiles/pmc_traffic_{args.config}.json (rocprofv3 --pmc passes of tools/pmc_traffic.py, not this run)"
         alg_bytes = sum(r["alg_bytes"] for r in rows if r["kernel"] == dom) / d["n"]
         achieved = d["gflop"] * 1e9 / (d["us"] * 1e-6) / 1e12 if d["us"] > 0 else 0.0
+        achieved_x = d["gflop_x"] * 1e9 / (d["us"] * 1e-6) / 1e12 if d["us"] > 0 else 0.0
         fam = tot_gf * 1e9 / (tot_us * 1e-6) / 1e12 if tot_us > 0 else 0.0
         roofline = dict(bound="mfma", kernel=dom + " (implicit-GEMM conv, v_mfma_f32_32x32x2_f32)",
                         achieved=round(achieved, 3), peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
+                        frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_source,
+                        achieved_executed_taps=round(achieved_x, 3), frac_executed_taps=round(achieved_x / FP32_MFMA_PEAK_TFLOPS, 4),
+                        flop_counting="achieved: nominal 2*MACs incl. padding taps (SURVEY 8d); *_executed_taps: only taps that meet data",
                         launches_per_step=d["n"], avg_launch_us=round(d["us"] / d["n"], 2),
                         flop_per_launch=round(d["gflop"] * 1e9 / d["n"]), algorithmic_bytes_per_launch=round(alg_bytes),
                         kernel_us_per_step=round(d["us"], 1),
                         per_kernel={k: dict(launches=v["n"], avg_us=round(v["us"] / v["n"], 2),
-                                            tflops=round(v["gflop"] * 1e3 / v["us"], 2) if v["us"] > 0 else 0.0)
+                                            tflops=round(v["gflop"] * 1e3 / v["us"], 2) if v["us"] > 0 else 0.0,
+                                            tflops_executed_taps=round(v["gflop_x"] * 1e3 / v["us"], 2) if v["us"] > 0 else 0.0)
                                     for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["us"])},
                         conv_family=dict(launches_per_step=len(rows), us_per_step=round(tot_us, 1), tflops=round(fam, 3),
                                          frac=round(fam / FP32_MFMA_PEAK_TFLOPS, 4)),
@@ -364,10 +452,6 @@ def main():
         if args.kernel_table:
             with open(args.kernel_table, "w") as f:
                 json.dump(all_rows, f, indent=1)
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(cfg, args.cpu_seconds)
-
     if rank == 0:
         n_img = cfg["batch"] * world * args.steps
         out = {
@@ -377,7 +461,10 @@ def main():
             "config": {"workload": cfg["label"], "arch": cfg["arch"], "aggregator": cfg["agg"], "per_gpu_batch": cfg["batch"],
                        "global_batch": cfg["batch"] * world, "image": f"3x{cfg['size']}x{cfg['size']}",
                        "parallelism": f"dp{world}", "optimizer": "adam", "final_total_loss": final_loss,
-                       "launch": "hipGraph replay" if use_graph else "eager",
+                       "launch": ("hipGraph replay" + (f" ({graphed.dp_form})" if dp is not None else "")) if use_graph else "eager",
+                       "timed_blocks": {"n": len(ts), "steps_each": args.steps, "ms_per_step_min": ts[0] / args.steps * 1e3,
+                                        "ms_per_step_median": elapsed / args.steps * 1e3, "ms_per_step_max": ts[-1] / args.steps * 1e3},
+                       "distinct_batches": len(pool),
                        "step_gflop": cfg["flops_per_img"] * cfg["batch"] / 1e9},
             "roofline": roofline, "cpu_baseline": cpu,
         }

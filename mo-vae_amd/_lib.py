@@ -105,15 +105,29 @@ def load():
     with _lock:
         if _lib is not None:
             return _lib
-        if not os.path.exists(LIB_PATH):
-            try:
-                from . import build as _build
+        # with the toolchain present the build is always consulted: build.build() compares a digest of every source with the
+        # one each object was compiled from and recompiles what changed, so an edited csrc/ never runs against a stale .so;
+        # without hipcc (a box that only received the built library) the library must already exist
+        from . import build as _build
 
+        have_hipcc = False
+        try:
+            _build._hipcc()
+            have_hipcc = os.path.isdir(_build.CSRC)
+        except RuntimeError:
+            pass
+        if have_hipcc and os.environ.get("MOVAE_NO_REBUILD") != "1":
+            try:
                 _build.build(verbose=False)
             except Exception as e:  # noqa: BLE001
-                raise RuntimeError(
-                    f"libmovae_hip.so is missing at {LIB_PATH} and could not be built ({e}); "
-                    "the MI355X kernels are required -- there is no CPU fallback") from e
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        f"libmovae_hip.so is missing at {LIB_PATH} and could not be built ({e}); "
+                        "the MI355X kernels are required -- there is no CPU fallback") from e
+                raise RuntimeError(f"csrc/ changed but rebuilding libmovae_hip.so failed: {e}") from e
+        elif not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"libmovae_hip.so is missing at {LIB_PATH} and hipcc is not available to build it; "
+                               "the MI355X kernels are required -- there is no CPU fallback")
         try:
             lib = C.CDLL(LIB_PATH)
         except OSError as e:

@@ -14,17 +14,24 @@ import torch.distributed as dist
 
 
 def flatten_grads(params, out=None):
-    """All gradients in one contiguous buffer (memory order); params without grad contribute zeros."""
+    """All gradients in one contiguous buffer; params without grad contribute zeros.  Every chunk is laid out in the
+    PARAMETER's memory order (channels_last conv weights: [o][kh][kw][i]) because unflatten_into_grads re-views the bucket
+    with the parameter's strides: a gradient whose own strides differ (a contiguous gradient of a channels_last weight,
+    or the reverse) is first copied into the parameter's layout instead of being packed as it lies."""
     chunks = []
     for p in params:
         if p.grad is None:
             chunks.append(torch.zeros(p.numel(), dtype=p.dtype, device=p.device))
+            continue
+        g = p.grad
+        if g.shape != p.shape:
+            raise RuntimeError(f"gradient shape {tuple(g.shape)} does not match its parameter {tuple(p.shape)}")
+        if any(n > 1 and a != b for n, a, b in zip(p.shape, g.stride(), p.stride())):  # (strides of size-1 dims carry no layout)
+            g = torch.empty_like(p).copy_(g)  # empty_like preserves the parameter's (dense) strides
+        if g.dim() == 4 and not g.is_contiguous() and g.permute(0, 2, 3, 1).is_contiguous():
+            chunks.append(g.permute(0, 2, 3, 1).reshape(-1))
         else:
-            g = p.grad
-            if g.dim() == 4 and not g.is_contiguous() and g.permute(0, 2, 3, 1).is_contiguous():
-                chunks.append(g.permute(0, 2, 3, 1).reshape(-1))
-            else:
-                chunks.append(g.contiguous().reshape(-1))
+            chunks.append(g.contiguous().reshape(-1))
     if out is not None:
         return torch.cat(chunks, out=out)
     return torch.cat(chunks)

@@ -192,6 +192,7 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         self.graph2 = None
+        self.dp_form = "single device"
         optimizer.zero_grad(set_to_none=True)
         #: (name, args) of every C-ABI launch in the captured step; the pointers stay valid (graph-pool memory) for the
         #: life of this object, which lets bench.py re-issue and time each launch on the step's real operands
@@ -224,7 +225,13 @@ class GraphedTrainStep:
         # (graph, eager all-reduce, graph) cost ~110 us per step in cross-queue hand-offs on MI355X (1.415 vs 1.306 ms with one
         # hardware queue); inside one graph the collective is just another kernel node.  gloo cannot be captured, and
         # MOVAE_DP_CAPTURE_COLLECTIVE=0 (or a failing capture) falls back to the pieces.
-        if not overlap and dp.backend == "nccl" and os.environ.get("MOVAE_DP_CAPTURE_COLLECTIVE", "1") != "0":
+        # MOVAE_DP_CAPTURE_COLLECTIVE: "1" (default) capture the collective and RAISE if that fails; "auto" fall back to the
+        # pieces -- but only when EVERY rank agrees (a rank that fell back alone would issue collectives its peers never
+        # post: the pieces all-reduce while they are built); "0" never capture it
+        cc_mode = os.environ.get("MOVAE_DP_CAPTURE_COLLECTIVE", "1")
+        self.dp_form = "graph | all-reduce | graph"
+        if not overlap and dp.backend == "nccl" and cc_mode != "0":
+            err = None
             try:
                 ops.forget_nhwc()
                 whole = torch.cuda.CUDAGraph()
@@ -238,13 +245,23 @@ class GraphedTrainStep:
                         clip_grad_norm_(params, max_norm=args.max_grad_norm)
                     optimizer.step()
                 ops.forget_nhwc()
-                self.graph, self.graph_b, self.flat_b = whole, None, None
-                return
-            except Exception as e:  # noqa: BLE001 -- any capture failure: rebuild as pieces below
-                print(f"[movae] capturing the all-reduce failed ({type(e).__name__}: {e}); using graph / all-reduce / graph", flush=True)
+            except Exception as e:  # noqa: BLE001
+                if cc_mode != "auto":
+                    raise
+                err = e
+            ok = torch.tensor([0 if err is not None else 1], device=example.device, dtype=torch.int32)
+            if cc_mode == "auto":  # agree on ONE form: every rank takes the pieces if any rank's capture failed
                 torch.cuda.synchronize()
-                optimizer.zero_grad(set_to_none=True)
-                self.graph = torch.cuda.CUDAGraph()
+                torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                self.graph, self.graph_b, self.flat_b = whole, None, None
+                self.dp_form = "1 graph + captured all-reduce"
+                return
+            print(f"[movae] capturing the all-reduce failed on some rank ({type(err).__name__ if err else 'peer'}: {err}); "
+                  "all ranks use graph / all-reduce / graph", flush=True)
+            torch.cuda.synchronize()
+            optimizer.zero_grad(set_to_none=True)
+            self.graph = torch.cuda.CUDAGraph()
         ops.forget_nhwc()
         with torch.cuda.graph(self.graph, **cap):
             self.loss_dict, self.outputs, pending = forward_backward_begin(net, self.static_x, optimizer, aggregator)
@@ -262,6 +279,7 @@ class GraphedTrainStep:
         late = [p for p in params if id(p) not in taken]
         self.graph_b, self.flat_b = None, None
         if late:
+            self.dp_form = "3 graphs, two overlapped all-reduces"
             off = (n_early + 63) // 64 * 64  # keep the second bucket 256-byte aligned
             self.flat_b = self.flat[off: off + sum(p.numel() for p in late)]
             self.graph_b = torch.cuda.CUDAGraph()
@@ -343,24 +361,40 @@ def train_epoch(net, train_loader, optimizer, aggregator, step, device, args, dp
     meters["total_loss"] = AverageMeter()
     usage = AverageMeter()
     for images, _ in train_loader:
+        if getattr(args, "max_steps", None) is not None and step >= args.max_steps:
+            break
         images = images.to(device, non_blocking=True)
         _current_step = step + 1
         _hook_values.clear()
-        try:
-            if graphed is not None and graphed.get("step") is None and images.size(0) == graphed["batch"]:
+        # the capture sits OUTSIDE the skip-batch handler: a failing capture must not be mistaken for a bad batch (it would
+        # be retried and "skipped" on every batch while the run trains nothing); it is reported once and the loop goes eager
+        if graphed is not None and graphed.get("step") is None and not graphed.get("failed") and images.size(0) == graphed["batch"]:
+            try:
                 graphed["step"] = GraphedTrainStep(net, optimizer, aggregator, args, images, dp=dp, preserve_state=True)
                 graphed["hooks"] = dict(_hook_values)  # the weighting's forward hooks ran while capturing: static tensors
-            gs = graphed.get("step") if graphed is not None else None
-            if gs is not None and images.shape == gs.static_x.shape:
-                loss_dict, outputs = gs.step(images)
-                _hook_values.update(graphed["hooks"])
-            else:
+            except NotImplementedError as e:
+                graphed["failed"] = True
+                print(f"[movae] hipGraph capture not possible ({e}); running the eager step", flush=True)
+            except RuntimeError as e:
+                if dp is not None or getattr(args, "graph", "auto") == "on":
+                    raise  # ranks must not diverge in form; --graph on asked for the graph
+                graphed["failed"] = True
+                print(f"[movae] hipGraph capture failed ({type(e).__name__}: {e}); running the eager step", flush=True)
+                torch.cuda.synchronize()
+        gs = graphed.get("step") if graphed is not None else None
+        if gs is not None and images.shape == gs.static_x.shape:
+            loss_dict, outputs = gs.step(images)
+            _hook_values.update(graphed["hooks"])
+        else:
+            try:
                 loss_dict, outputs = train_step(net, images, optimizer, aggregator, args, dp)
-        except RuntimeError as e:  # main.py:197-208: skip the batch on device-side assertion errors
-            if "cuda" in str(e).lower() or "hip" in str(e).lower() or "assert" in str(e).lower():
+            except RuntimeError as e:  # main.py:197-208: skip the batch on device-side assertion errors
+                recoverable = "cuda" in str(e).lower() or "hip" in str(e).lower() or "assert" in str(e).lower()
+                if not recoverable or dp is not None:
+                    # under data parallelism a rank that skipped alone would leave its peers waiting in the all-reduce
+                    raise
                 print(f"Step {step}: device error during backward: {e}\n  Skipping this batch...")
                 continue
-            raise
         host = _host_values(loss_dict)
         if host["total_loss"] > 1e15:
             print(f"Step {step}: EXPLODING: Total loss: {host['total_loss']:.6e}")
@@ -464,6 +498,29 @@ def get_dataset(name, data_dir="./data", normalize=False, max_items=None):
 
 
 # ---- CLI -----------------------------------------------------------------------------------------
+#: main.py:1603-1623,1636-1640 -- options that only the out-of-scope architectures read
+IGNORED_FLAGS = {
+    "--recursive_kld_anneal_steps": dict(type=int, default=25000),
+    "--sigma_max_angle_deg": dict(type=float, default=80.0),
+    "--sigma_mix_prob": dict(type=float, default=0.0),
+    "--sigma_mix_angle_min_deg": dict(type=float, default=None),
+    "--sigma_mix_angle_max_deg": dict(type=float, default=None),
+    "--lambda_pix_recon": dict(type=float, default=1.0),
+    "--lambda_pix_con": dict(type=float, default=0.5),
+    "--lambda_lat_con": dict(type=float, default=0.1),
+    "--patch_size": dict(type=int, default=None),
+    "--vit_embed_dim": dict(type=int, default=1024),
+    "--vit_depth": dict(type=int, default=24),
+    "--vit_num_heads": dict(type=int, default=16),
+    "--vit_mixer_depth": dict(type=int, default=2),
+    "--num_classes": dict(type=int, default=0),
+    "--pixelsnail_num_blocks": dict(type=int, default=8),
+    "--pixelsnail_num_res_blocks": dict(type=int, default=2),
+    "--pixelsnail_num_heads": dict(type=int, default=8),
+    "--pixelsnail_dropout": dict(type=float, default=0.1),
+}
+
+
 def build_parser():
     """Flag names, aliases and defaults of main.py:1500-1651 (hot-path subset keeps every name)."""
     p = ArgumentParser()
@@ -521,7 +578,22 @@ def build_parser():
     p.add_argument("--wandb_tags", type=str, nargs="+", default=None)
     p.add_argument("--max_fid_samples", type=int, default=10000)
     p.add_argument("--max_gen_metrics_samples", type=int, default=10000)
+    # PixelCNN prior over the VQ codes (main.py:1625-1651; prior.py).  PixelSNAIL is outside SURVEY 8f.4's row: refused by name.
+    p.add_argument("--prior_type", type=str, default="pixelcnn", choices=["pixelcnn", "pixelsnail"])
     p.add_argument("--skip_pixelcnn", action="store_true")
+    p.add_argument("--pixelcnn_epochs", type=int, default=100)
+    p.add_argument("--pixelcnn_hidden_channels", type=int, default=128)
+    p.add_argument("--pixelcnn_num_layers", type=int, default=15)
+    p.add_argument("--pixelcnn_lr", type=float, default=3e-4)
+    p.add_argument("--pixelcnn_temperature", type=float, default=1.0)
+    p.add_argument("--prior_use_lmdb_codes", action="store_true", default=True)
+    p.add_argument("--no_prior_lmdb_codes", action="store_false", dest="prior_use_lmdb_codes")
+    p.add_argument("--prior_force_extract_codes", action="store_true")
+    p.add_argument("--prior_lmdb_map_size_gb", type=float, default=150)
+    # flags of architectures outside the hot path (recursive / sphere / ViT models, PixelSNAIL): accepted with the reference's
+    # types and defaults so that any reference YAML -> runner.py argv parses, ignored with one warning when given
+    for name, kw in IGNORED_FLAGS.items():
+        p.add_argument(name, **kw)
     # additions of this build (not in the reference)
     p.add_argument("--graph", choices=["auto", "off", "on"], default="auto",
                    help="auto / on: capture the step into a hipGraph on the first full batch and replay it (device-bound "
@@ -533,7 +605,14 @@ def build_parser():
 
 
 def parse_args(argv=None):
-    args = build_parser().parse_args(argv)
+    import sys
+
+    parser = build_parser()
+    args = parser.parse_args(argv)
+    given = [a.split("=", 1)[0] for a in (sys.argv[1:] if argv is None else argv) if isinstance(a, str) and a.startswith("--")]
+    ignored = sorted(set(given) & set(IGNORED_FLAGS))
+    if ignored:
+        print(f"[movae] ignoring options of architectures outside the MI355X hot path: {', '.join(ignored)}", flush=True)
     if args.loss_weights is not None and len(args.loss_weights) > 0:  # main.py:1655-1659
         if len(args.loss_weights) == 1 and args.loss_weights[0].strip().startswith("{"):
             args.loss_weights = json.loads(args.loss_weights[0])
@@ -632,22 +711,25 @@ def main(args):
     if hasattr(net, "print_model_summary") and args.device.endswith("0") and rank0:
         net.print_model_summary()
     step, history, best = 0, [], float("inf")
+    eval_rec = {}
     for epoch in range(1, args.epochs + 1):
         if sampler is not None:
             sampler.set_epoch(epoch)
         if isinstance(aggregator, COMFORT):  # main.py:1290-1291
             aggregator.set_epoch(epoch, args.epochs)
         t0 = time.time()
+        step0 = step
         meters, step = train_epoch(net, train_loader, optimizer, aggregator, step, device, args, dp, log, graphed)
         torch.cuda.synchronize()
         dt = time.time() - t0
         rec = {k: m.avg for k, m in meters.items()}
         history.append(rec)
         if rank0:
-            n_img = len(train_ds)
+            n_img = (step - step0) * per_rank_bs * (1 if dp is None else dp.world_size)
             print(f"epoch {epoch}: " + ", ".join(f"{k}: {v:.6e}" for k, v in rec.items()) + f"  [{n_img / dt:.0f} img/s]")
         if args.eval_freq and epoch % args.eval_freq == 0:
             ev = evaluate(net, test_loader, device, args)
+            eval_rec = {k: m.avg for k, m in ev.items()}
             best = min(best, ev["total_loss"].avg)
             if rank0:
                 print(f"  eval: " + ", ".join(f"{k}: {m.avg:.6e}" for k, m in ev.items()))
@@ -655,15 +737,26 @@ def main(args):
             scheduler.step()
         if args.max_steps is not None and step >= args.max_steps:
             break
-    if rank0:  # main.py:1422-1436: save-only checkpoint with the reference's keys
-        ckpt = {"epoch": epoch, "model_state_dict": {k: v.contiguous() for k, v in net.state_dict().items()},
-                "args": vars(args), "train_losses": history, "best_eval_loss": best}
+    if rank0:  # main.py:1422-1436: save-only checkpoint with the reference's keys and value shapes
+        ckpt = {"epoch": args.epochs, "model_state_dict": {k: v.contiguous() for k, v in net.state_dict().items()},
+                "args": vars(args), "train_losses": dict(history[-1]) if history else {}, "eval_losses": dict(eval_rec),
+                "best_eval_loss": best,
+                "train_history": history}  # addition of this build: every epoch's averages (the reference keeps the last only)
         if scheduler is not None:
             ckpt["scheduler_state_dict"] = scheduler.state_dict()
         torch.save(ckpt, os.path.join(save_root, "checkpoints", "final_checkpoint.pth"))
+    if rank0 and _is_vq_arch(args.arch) and not getattr(args, "skip_pixelcnn", False):  # main.py:1438-1497
+        from . import prior as _prior
+
+        _prior.train_pixelcnn_prior(net, train_loader, device, args, save_root)
     if dp is not None:
         dp.shutdown()
     return history
+
+
+def _is_vq_arch(arch):
+    a = (arch or "").lower()
+    return a in ("vq_vae", "vq_vae2", "gg_vq_vae2") or a.startswith("gg_vq_vae")
 
 
 def cli(argv=None):

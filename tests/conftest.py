@@ -16,6 +16,32 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+#: child processes of tests/test_dp_two_ranks_gpu.py, started at the end of collection -- i.e. before any test (and so
+#: before anything in this process) has touched the GPU: a process that has initialised HIP must not start GPU children
+DP_CHILDREN = {}
+
+
+def pytest_collection_finish(session):
+    import socket
+    import subprocess
+    import tempfile
+
+    if not any(it.name.startswith("test_two_rank_data_parallel") for it in session.items) or not os.path.exists("/dev/kfd"):
+        return
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = tempfile.mkdtemp(prefix="movae_dp2_")
+    worker = os.path.join(ROOT, "tests", "dp_worker.py")
+    procs = []
+    for r in range(2):
+        log = open(os.path.join(out, f"rank{r}.log"), "w")
+        procs.append(subprocess.Popen([sys.executable, worker, "--rank", str(r), "--world", "2", "--port", str(port), "--out", out],
+                                      stdout=log, stderr=subprocess.STDOUT))
+    DP_CHILDREN.update(out=out, procs=procs)
+
+
 def load_golden(name):
     """npz fixtures are plain arrays (allow_pickle stays False)."""
     return np.load(os.path.join(GOLDEN, name + ".npz"))

@@ -148,3 +148,80 @@ def test_aggregator_factory_names(pkg):
     a = Args(aggregator=None)
     A.make_aggregator(a)
     assert a.aggregator == "sum"  # main.py:1245-1246
+
+
+#: configs/celeba-hq/vq_vae2/mgda_ln/bce/config_1.yaml of the reference, as data (keys and values, in file order)
+REF_YAML_VQVAE2 = {
+    "dataset": "celeba-hq", "data_dir": "../data", "normalize_inputs": False, "arch": "vq_vae2", "embedding_dim": 64,
+    "num_embeddings": 512, "hidden_dims": [128, 256],
+    "loss_weights": {"reconstruction_loss": 1.0, "embedding_loss": 1.0, "commitment_loss": 0.25}, "recons_objective": "bce",
+    "recons_activation": "sigmoid", "epochs": 400, "batch_size": 128, "optimizer": "adam", "lr": "1e-4", "scheduler": "cosine",
+    "scheduler_lr_min": "1e-6", "wd": 0.0, "aggregator": "mgda_ln", "seed": 42, "save_path": "logs/", "save_freq": 50,
+    "eval_freq": 50, "num_vis_samples": 4,
+    "hv_ref": {"reconstruction_loss": 1.1, "commitment_loss": 1.1, "embedding_loss": 1.1}, "use_wandb": True,
+    "wandb_project": "mo-vae", "wandb_entity": "rasa_research", "wandb_name": "celeba_hq-vq_vae2-512k-64d-bce-mgda_ln-seed42",
+    "wandb_group": "celeba_hq-vq_vae2-512k-64d-bce-mgda_ln",
+}
+
+
+def _yaml_to_argv(config):
+    """The conversion runner.py:32-85 applies to a YAML dict (aliases, bool -> flag, dict -> JSON, list -> tokens)."""
+    import json
+
+    aliases = {"agg": "aggregator", "wd": "weight_decay", "normalize": "normalize_inputs", "num_samples": "num_vis_samples",
+               "norm_eps": "agg_norm_eps", "reg_eps": "agg_reg_eps"}
+    argv = []
+    for key, value in config.items():
+        if key in ("device", "num_workers") or value is None:
+            continue
+        name = "--" + aliases.get(key, key)
+        if isinstance(value, bool):
+            if value:
+                argv.append(name)
+        elif isinstance(value, dict):
+            argv += [name, json.dumps(value)]
+        elif isinstance(value, list):
+            argv += [name] + [str(v) for v in value]
+        else:
+            argv += [name, str(value)]
+    return argv
+
+
+def test_reference_yaml_argv_parses(pkg, capsys):
+    """Any reference YAML -> runner.py argv must parse: the prior / PixelSNAIL / sphere / ViT flags of main.py:1603-1651 are
+    accepted with the reference's defaults; the ones only out-of-scope architectures read are ignored with one warning."""
+    from movae_amd import train
+
+    a = train.parse_args(_yaml_to_argv(REF_YAML_VQVAE2))
+    assert (a.arch, a.aggregator, a.embedding_dim, a.num_embeddings, a.hidden_dims) == ("vq_vae2", "mgda_ln", 64, 512, [128, 256])
+    assert a.loss_weights == {"reconstruction_loss": 1.0, "embedding_loss": 1.0, "commitment_loss": 0.25}
+    assert a.hv_ref == {"reconstruction_loss": 1.1, "commitment_loss": 1.1, "embedding_loss": 1.1}
+    assert (a.lr, a.scheduler_lr_min, a.wd, a.recons_objective, a.recons_activation) == (1e-4, 1e-6, 0.0, "bce", "sigmoid")
+    assert a.use_wandb and not a.normalize_inputs and a.seed == 42
+    # defaults of the prior stage (main.py:1625-1651)
+    assert (a.prior_type, a.pixelcnn_epochs, a.pixelcnn_hidden_channels, a.pixelcnn_num_layers, a.pixelcnn_lr, a.pixelcnn_temperature,
+            a.prior_use_lmdb_codes, a.skip_pixelcnn) == ("pixelcnn", 100, 128, 15, 3e-4, 1.0, True, False)
+    assert "ignoring" not in capsys.readouterr().out
+    b = train.parse_args(["--arch", "vae", "--vit_depth", "12", "--sigma_mix_prob", "0.1", "--patch_size", "2", "--num_classes", "10",
+                          "--recursive_kld_anneal_steps", "5", "--pixelsnail_dropout", "0.2", "--no_prior_lmdb_codes",
+                          "--lambda_pix_con", "0.3", "--prior_lmdb_map_size_gb", "1", "--prior_force_extract_codes"])
+    out = capsys.readouterr().out
+    assert "ignoring options of architectures outside the MI355X hot path" in out and "--vit_depth" in out and "--pixelsnail_dropout" in out
+    assert b.vit_depth == 12 and b.prior_use_lmdb_codes is False and b.prior_force_extract_codes
+    # every option string of the reference's parser is known here
+    ref_flags = """--seed --device --data_dir --save_path --epochs --dataset --normalize_inputs --batch_size --num_workers --aggregator --agg
+        --agg_norm_eps --agg-norm-eps --norm_eps --norm-eps --agg_reg_eps --agg-reg-eps --reg_eps --reg-eps --mgda_epsilon --mgda-epsilon
+        --mgda_max_iters --mgda-max-iters --mgda_min_eigenvalue_eps --mgda-min-eigenvalue-eps --comfort_mgda_norm_type
+        --comfort-mgda-norm-type --comfort_mgda_stable --comfort-mgda-stable --comfort_beta_k --comfort_beta_a --comfort_beta_l
+        --comfort_beta_u --arch --layer_norm --latent_dim --hidden_dims --num_residual_layers --recons_objective --recons_activation
+        --loss_weights --pref_weights --optimizer --momentum --max_grad_norm --lr --wd --weight_decay --scheduler --scheduler_lr_min
+        --scheduler_gamma --scheduler_milestones --embedding_dim --num_embeddings --anneal_steps --recursive_kld_anneal_steps
+        --sigma_max_angle_deg --sigma_mix_prob --sigma_mix_angle_min_deg --sigma_mix_angle_max_deg --lambda_pix_recon --lambda_pix_con
+        --lambda_lat_con --patch_size --vit_embed_dim --vit_depth --vit_num_heads --vit_mixer_depth --num_classes --hv_ref
+        --num_vis_samples --save_freq --eval_freq --use_wandb --wandb_project --wandb_entity --wandb_name --wandb_group --wandb_tags
+        --max_fid_samples --max_gen_metrics_samples --prior_type --skip_pixelcnn --pixelcnn_epochs --pixelcnn_hidden_channels
+        --pixelcnn_num_layers --pixelcnn_lr --pixelcnn_temperature --pixelsnail_num_blocks --pixelsnail_num_res_blocks
+        --pixelsnail_num_heads --pixelsnail_dropout --prior_use_lmdb_codes --no_prior_lmdb_codes --prior_force_extract_codes
+        --prior_lmdb_map_size_gb""".split()
+    known = {s for act in train.build_parser()._actions for s in act.option_strings}
+    assert len(ref_flags) == 96 and not [f for f in ref_flags if f not in known]

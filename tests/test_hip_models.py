@@ -440,13 +440,15 @@ def test_hipgraph_replay_matches_eager_steps(case, gpu_device):
         assert 0.0 < float(gs.outputs["codebook_usage_percentage"]) <= 100.0
 
 
-@pytest.mark.parametrize("overlap", ["0", "0-pieces", "1"])
+@pytest.mark.parametrize("overlap", ["0", "0-pieces", "1", "0-long"])
 def test_data_parallel_graphed_step_single_rank_rccl(overlap, gpu_device, monkeypatch):
     """The N>1 code path of GraphedTrainStep driven with ONE rank over the real RCCL backend, in its three forms: one bucket
     with the all-reduce captured inside the step's single graph ("0"), one bucket as graph 1 -> eager all-reduce -> graph 2
     ("0-pieces", the fallback and the gloo form), and the overlapped two-bucket form (graph 1 -> all-reduce(task side) under
     graph 1b -> all-reduce(shared) -> graph 2).  The mean over one rank is the identity, so losses and parameters must equal
-    the eager single-device loop, clipping included."""
+    the eager single-device loop, clipping included.  "0-long": the same one-graph form for VQ-VAE-2, whose capture is several
+    hundred launches long -- long enough for the process group's watchdog thread to poll events while it is in progress, which
+    is what capture_error_mode="thread_local" is there for (it invalidated the C4 capture under the default mode)."""
     import torch.distributed as dist
 
     import movae_amd  # noqa: F401
@@ -466,13 +468,18 @@ def test_data_parallel_graphed_step_single_rank_rccl(overlap, gpu_device, monkey
     monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
     monkeypatch.setenv("MASTER_PORT", "29577")
 
+    long_capture = overlap == "0-long"
+    model_kw = (dict(arch="vq_vae2", embedding_dim=8, num_embeddings=32, hidden_dims=[16, 32], num_residual_layers=2, aggregator="mgda_ln")
+                if long_capture else dict(arch="vae", latent_dim=16, hidden_dims=[16, 32, 64], aggregator="upgrad"))
+
     def make():
-        a = Args(arch="vae", batch_size=16, dataset_size=1000, recons_objective="mse", recons_activation=None, loss_weights=None,
+        a = Args(batch_size=16, dataset_size=1000, recons_objective="mse", recons_activation=None, loss_weights=None,
                  agg_norm_eps=1e-4, agg_reg_eps=1e-4, mgda_epsilon=1e-5, mgda_max_iters=250, pref_weights=None, optimizer="adam",
-                 lr=1e-3, wd=0, momentum=0.9, latent_dim=16, hidden_dims=[16, 32, 64], aggregator="upgrad", max_grad_norm=0.5)
+                 lr=1e-3, wd=0, momentum=0.9, max_grad_norm=0.5, **model_kw)
         torch.manual_seed(3)
         net = get_network(32, 3, a, gpu_device).to(gpu_device).train()
-        net.eps_override = torch.randn(16, net.latent_dim, generator=torch.Generator().manual_seed(5)).to(gpu_device)
+        if hasattr(net, "latent_dim"):
+            net.eps_override = torch.randn(16, net.latent_dim, generator=torch.Generator().manual_seed(5)).to(gpu_device)
         return net, a
 
     g = torch.Generator().manual_seed(11)
@@ -480,7 +487,7 @@ def test_data_parallel_graphed_step_single_rank_rccl(overlap, gpu_device, monkey
     net_e, a = make()
     opt_e, agg_e = make_optimizer(net_e, a, capturable=True), aggregation.make_aggregator(a)
     # the DP twin runs 3 warm-up steps, plus one real step while it builds the graph / all-reduce / graph pieces
-    for _ in range(3 if overlap == "0" else 4):
+    for _ in range(3 if overlap[0] == "0" and overlap != "0-pieces" else 4):
         train_step(net_e, batches[0], opt_e, agg_e, a)
     want = [train_step(net_e, b, opt_e, agg_e, a)[0]["total_loss"].item() for b in batches]
     dp = DataParallelGrads.from_env(backend="nccl")
@@ -490,7 +497,9 @@ def test_data_parallel_graphed_step_single_rank_rccl(overlap, gpu_device, monkey
         dp.attach(net_g)
         opt_g = make_optimizer(net_g, a2, capturable=True)
         gs = GraphedTrainStep(net_g, opt_g, aggregation.make_aggregator(a2), a2, batches[0], dp=dp)
-        assert (gs.graph2 is None) == (overlap == "0") and (gs.graph_b is not None) == (overlap == "1")
+        assert (gs.graph2 is None) == (overlap in ("0", "0-long")) and (gs.graph_b is not None) == (overlap == "1")
+        assert gs.dp_form == {"0": "1 graph + captured all-reduce", "0-long": "1 graph + captured all-reduce",
+                              "0-pieces": "graph | all-reduce | graph", "1": "3 graphs, two overlapped all-reduces"}[overlap]
         got = [gs.step(b)[0]["total_loss"].item() for b in batches]
         np.testing.assert_allclose(got, want, rtol=2e-5)
         for (n, p), (_, q) in zip(net_g.named_parameters(), net_e.named_parameters()):
