@@ -49,8 +49,15 @@ class Args:
         self.__dict__.update(kw)
 
 
+def _base(name):
+    """movae_conv2d_fwd_f -> movae_conv2d_fwd: the *_f entry points (BatchNorm fused into the conv, include/movae.h) take the
+    plain argument list plus one trailing movae_fuse_t pointer."""
+    return name[:-2] if name.endswith("_f") else name
+
+
 def _geom_offset(name, a):
     """(index of `n` in the C-ABI argument tuple, cotangent groups) -- the grouped wgrads carry `groups` first."""
+    name = _base(name)
     if "dgrad_wgrad" in name:  # (groups, dy, w, x, dx, dw[], dbias[], n, ...)
         return 7, int(a[0])
     if name.endswith("_grouped"):
@@ -176,7 +183,7 @@ def cpu_baseline(cfg, seconds, device=None, check_steps=20):
     return out
 
 
-FAMILY = [("conv", "movae_conv"), ("batchnorm", "movae_bn_"), ("loss", "movae_recon"), ("loss", "movae_kl"), ("loss", "movae_tc"),
+FAMILY = [("conv", "movae_conv"), ("batchnorm", "movae_bn_"), ("batchnorm", "movae_scale_shift"), ("loss", "movae_recon"), ("loss", "movae_kl"), ("loss", "movae_tc"),
           ("vq", "movae_vq"), ("aggregation", "movae_gram"), ("aggregation", "movae_weights"), ("aggregation", "movae_combine"),
           ("aggregation", "movae_gd_"), ("optimizer", "movae_adam"), ("optimizer", "movae_sumsq"), ("optimizer", "movae_scale_by"),
           ("elementwise", "movae_")]
@@ -234,15 +241,20 @@ def measure_dominant_kernel(recorded, device, reps=20, live=False):
         # on the stream the graph is launched on
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
+        si = len(a) - 2 if getattr(fn, "__name__", "").endswith("_f") else len(a) - 1  # *_f: (..., stream, fuse)
+
+        def with_stream(sp):
+            return a[:si] + (sp,) + a[si + 1:]
+
         with torch.cuda.stream(side):
-            a_side = a[:-1] + (side.cuda_stream,)
+            a_side = with_stream(side.cuda_stream)
             for _ in range(2):
                 fn(*a_side)
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            a_cap = a[:-1] + (torch.cuda.current_stream(device).cuda_stream,)
+            a_cap = with_stream(torch.cuda.current_stream(device).cuda_stream)
             for _ in range(reps):
                 fn(*a_cap)
         graph.replay()
@@ -257,7 +269,7 @@ def measure_dominant_kernel(recorded, device, reps=20, live=False):
     other = {}
     for name, rec in recorded:
         fn = getattr(lib, name)
-        if name not in CONV_CALLS:
+        if _base(name) not in CONV_CALLS:
             if live:
                 fam = family_of(name)
                 us = timed(fn, tuple(rec))
@@ -408,7 +420,7 @@ def main():
             L.TRACE = None
         torch.cuda.synchronize()
         all_rows, other = measure_dominant_kernel(recorded, device, live=live)
-        rows = [r for r in all_rows if r["call"] in CONV_CALLS]
+        rows = [r for r in all_rows if _base(r["call"]) in CONV_CALLS]
         tot_us = sum(r["us"] for r in rows)
         tot_gf = sum(r["gflop"] for r in rows)
         # group the main-kernel timings by kernel symbol (the way rocprofv3 --stats does) and report the one with

@@ -283,6 +283,85 @@ const char* movae_bench_last_kernel(void);
  * Returns the previous value. */
 int movae_bench_force_split(int s);
 
+/* ---- BatchNorm fused into its neighbouring convolutions -----------------------------------------
+ * models/vae.py:119-126,149-158: Conv2d / ConvTranspose2d -> BatchNorm2d (training statistics) -> LeakyReLU chains.  Instead of
+ * a statistics pass and an apply pass per BatchNorm, (1) the conv that PRODUCES y emits the per-channel partial sums of y from
+ * its epilogue (or from its split-K reduction), (2) movae_bn_finalize turns them into the saved statistics, the running
+ * statistics and the folded map scale = gamma * rstd, shift = beta - mean * scale, and (3) the conv that CONSUMES the
+ * normalised activation applies act(scale[c] * y + shift[c]) between its global load and its LDS store (forward and weight
+ * gradient alike): the normalised tensor is never written.
+ * movae_fuse_t asks one *_f call for (1) and / or (3).  in_scale == NULL: plain input.  stats == NULL: no statistics.  On return
+ * stats_parts is the number of partial pairs written per channel, stats[(p * 2 + {0: sum, 1: sum of squares}) * co + c]; 0 when
+ * the dispatched kernel cannot emit them (use movae_bn_stats).  A requested input transform that the dispatched kernel cannot
+ * apply returns -2 (unsupported) BEFORE anything is launched: materialise with movae_scale_shift_act and call the plain entry.
+ * in_slope: leaky-ReLU slope of the fused activation (1 = none, 0 = ReLU).  The *_f entry points are otherwise identical to
+ * their plain namesakes (which call them with fuse == NULL). */
+typedef struct movae_fuse {
+    const float* in_scale; /* [ci] device pointers, 16-byte aligned, ci % 4 == 0 */
+    const float* in_shift;
+    float in_slope;
+    float* stats;          /* device buffer for the partial sums (fwd entry points, act == none, no fused activation) */
+    size_t stats_cap;      /* floats available at stats */
+    int stats_parts;       /* OUT */
+} movae_fuse_t;
+int movae_conv2d_fwd_f(const float* x, const float* w, const float* bias, float* y,
+                       int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad,
+                       int act, float slope, void* ws, size_t ws_bytes, movae_stream_t stream, movae_fuse_t* fuse);
+int movae_convT2d_fwd_f(const float* x, const float* w, const float* bias, float* y,
+                        int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad,
+                        int act, float slope, void* ws, size_t ws_bytes, movae_stream_t stream, movae_fuse_t* fuse);
+/* backward passes: `fuse` describes the activation operand x (only in_scale / in_shift / in_slope are read) */
+int movae_conv2d_wgrad_grouped_f(int groups, const float* dy, const float* x, float* const* dw, float* const* dbias,
+                                 int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad,
+                                 int accumulate, void* ws, size_t ws_bytes, movae_stream_t stream, const movae_fuse_t* fuse);
+int movae_convT2d_wgrad_grouped_f(int groups, const float* dy, const float* x, float* const* dw, float* const* dbias,
+                                  int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad,
+                                  int accumulate, void* ws, size_t ws_bytes, movae_stream_t stream, const movae_fuse_t* fuse);
+int movae_conv2d_dgrad_wgrad_grouped_f(int groups, const float* dy, const float* w, const float* x, float* dx,
+                                       float* const* dw, float* const* dbias,
+                                       int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad,
+                                       int accumulate, void* ws, size_t ws_bytes, movae_stream_t stream, const movae_fuse_t* fuse);
+int movae_convT2d_dgrad_wgrad_grouped_f(int groups, const float* dy, const float* w, const float* x, float* dx,
+                                        float* const* dw, float* const* dbias,
+                                        int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad,
+                                        int accumulate, void* ws, size_t ws_bytes, movae_stream_t stream, const movae_fuse_t* fuse);
+/* partial sums -> mean / rstd (saved for movae_bn_act_bwd), scale / shift (for the consumers), running statistics with
+ * nn.BatchNorm2d's momentum rule and unbiased variance, num_batches_tracked += 1 (each may be NULL).  rows = n * h * w. */
+int movae_bn_finalize(const float* stats, int parts, int rows, int c, const float* gamma, const float* beta, float eps, float momentum,
+                      float* save_mean, float* save_rstd, float* scale, float* shift, float* running_mean, float* running_var,
+                      long long* num_batches_tracked, movae_stream_t stream);
+/* the same partial sums from one read of y, for producers whose kernel cannot emit them; *parts_out is a HOST int */
+int movae_bn_stats(const float* y, int rows, int c, float* stats, size_t stats_cap, int* parts_out, movae_stream_t stream);
+/* out = leaky_relu(scale[c] * y + shift[c], slope): materialises a fused BatchNorm output */
+int movae_scale_shift_act(const float* y, const float* scale, const float* shift, float* out, size_t rows, int c, float slope,
+                          movae_stream_t stream);
+
+/* ---- PixelCNN prior over the VQ code grids (models/pixelcnn_prior.py, trained by main.py:890-1085) -------
+ * The prior's convolutions are movae_conv2d_* calls; MaskedConv2d (pixelcnn_prior.py:25-54) multiplies its weight by the
+ * mask IN PLACE before every forward (movae_mul with y == a).
+ *   movae_embedding_fwd    nn.Embedding forward of the code grid     pixelcnn_prior.py:306 (x = self.embedding(x)), :371
+ *                          y[r][:] = weight[idx[r]][:]; idx int64 [rows] (a [B,H,W] grid gives NHWC activations directly)
+ *   movae_embedding_bwd    its gradient: dweight[k][:] = sum_{r: idx[r]==k} dy[r][:] -- rows sorted by (code, row) and summed in
+ *                          fixed order (no float atomics, bit-reproducible); ws >= movae_vq_bwd_ws_bytes(rows, k, d)
+ *   movae_gated_residual_* GatedResBlock's combine: out = res + gate * feat with gate = sigmoid(conv_gate), feat = tanh(conv_feature)
+ *                          already activated by the conv epilogues            pixelcnn_prior.py:85-90; n %% 4 == 0
+ *   movae_cross_entropy_*  F.cross_entropy(logits.permute(0,2,3,1).reshape(-1,K), z.reshape(-1)) (mean reduction)
+ *                          main.py:1003-1006,1026-1029; pixelcnn_prior.py:392-395.  logits [rows][k] (NHWC logits are that
+ *                          matrix as they lie), lse [rows] is kept for the backward; gscale_dev: device scalar upstream gradient
+ *                          or NULL (= 1). */
+int movae_embedding_fwd(const float* weight, const int64_t* idx, float* y, size_t rows, int k, int d, movae_stream_t stream);
+int movae_embedding_bwd(const float* dy, const int64_t* idx, float* dweight, int rows, int k, int d,
+                        void* ws, size_t ws_bytes, movae_stream_t stream);
+int movae_gated_residual_fwd(const float* res, const float* gate, const float* feat, float* out, size_t n, movae_stream_t stream);
+int movae_gated_residual_bwd(const float* dout, const float* gate, const float* feat, float* dgate, float* dfeat, size_t n,
+                             movae_stream_t stream);
+int movae_mul(const float* a, const float* b, float* y, size_t n, movae_stream_t stream);
+size_t movae_cross_entropy_ws_bytes(size_t rows);
+int movae_cross_entropy_fwd(const float* logits, const int64_t* target, float* loss, float* lse, size_t rows, int k,
+                            void* ws, size_t ws_bytes, movae_stream_t stream);
+int movae_cross_entropy_bwd(const float* logits, const int64_t* target, const float* lse, const float* gscale_dev, float* dlogits,
+                            size_t rows, int k, movae_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

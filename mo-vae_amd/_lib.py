@@ -21,6 +21,12 @@ MAX_K = 8
 
 _p, _i, _f, _z, _l = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_long
 
+class MovaeFuse(C.Structure):
+    """movae_fuse_t (include/movae.h): BatchNorm fused into the neighbouring convolutions."""
+    _fields_ = [("in_scale", C.c_void_p), ("in_shift", C.c_void_p), ("in_slope", C.c_float), ("stats", C.c_void_p),
+                ("stats_cap", C.c_size_t), ("stats_parts", C.c_int)]
+
+
 _conv_fwd = [_p, _p, _p, _p] + [_i] * 11 + [_i, _f, _p, _z, _p]
 _conv_dgrad = [_p, _p, _p] + [_i] * 11 + [_p, _z, _p]
 _conv_wgrad = [_p, _p, _p, _p] + [_i] * 11 + [_i, _p, _z, _p]
@@ -87,6 +93,23 @@ SIGNATURES = {
     "movae_clip_grad_norm_multi": ([_i, _p, _p, _f, _p, _p, _z, _p], _i),
     "movae_sumsq": ([_p, _z, _p, _p, _z, _p], _i),
     "movae_scale_by_clip": ([_p, _z, _p, _f, _p], _i),
+    "movae_conv2d_fwd_f": (_conv_fwd + [_p], _i),
+    "movae_convT2d_fwd_f": (_conv_fwd + [_p], _i),
+    "movae_conv2d_wgrad_grouped_f": ([_i] + _conv_wgrad + [_p], _i),
+    "movae_convT2d_wgrad_grouped_f": ([_i] + _conv_wgrad + [_p], _i),
+    "movae_conv2d_dgrad_wgrad_grouped_f": ([_i, _p, _p, _p, _p, _p, _p] + [_i] * 11 + [_i, _p, _z, _p, _p], _i),
+    "movae_convT2d_dgrad_wgrad_grouped_f": ([_i, _p, _p, _p, _p, _p, _p] + [_i] * 11 + [_i, _p, _z, _p, _p], _i),
+    "movae_bn_finalize": ([_p, _i, _i, _i, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p], _i),
+    "movae_bn_stats": ([_p, _i, _i, _p, _z, _p, _p], _i),
+    "movae_scale_shift_act": ([_p, _p, _p, _p, _z, _i, _f, _p], _i),
+    "movae_embedding_fwd": ([_p, _p, _p, _z, _i, _i, _p], _i),
+    "movae_embedding_bwd": ([_p, _p, _p, _i, _i, _i, _p, _z, _p], _i),
+    "movae_gated_residual_fwd": ([_p, _p, _p, _p, _z, _p], _i),
+    "movae_gated_residual_bwd": ([_p, _p, _p, _p, _p, _z, _p], _i),
+    "movae_mul": ([_p, _p, _p, _z, _p], _i),
+    "movae_cross_entropy_ws_bytes": ([_z], _z),
+    "movae_cross_entropy_fwd": ([_p, _p, _p, _p, _z, _i, _p, _z, _p], _i),
+    "movae_cross_entropy_bwd": ([_p, _p, _p, _p, _p, _z, _i, _p], _i),
     "movae_bench_main_kernel_only": ([_i], _i),
     "movae_bench_last_kernel": ([], C.c_char_p),
     "movae_bench_force_split": ([_i], _i),
@@ -150,7 +173,13 @@ def call(name, *args):
     check(getattr(load(), name)(*args), name)
 
 
+class Unsupported(RuntimeError):
+    """rc == -2: the shape dispatches to a kernel without the requested fusion; nothing was launched (movae_fuse_t)."""
+
+
 def check(rc, what=""):
+    if rc == -2:
+        raise Unsupported(f"{what or 'movae'}: {load().movae_last_error().decode(errors='replace')}")
     if rc != 0:
         msg = load().movae_last_error().decode(errors="replace")
         raise RuntimeError(f"{what or 'movae'} failed (rc={rc}): {msg}")

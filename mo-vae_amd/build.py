@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libmovae_hip.so")
-SOURCES = ["conv_igemm.hip", "bn_act.hip", "eltwise.hip", "losses.hip", "edge.hip", "agg.hip", "vq.hip", "optim.hip", "api.cpp"]
+SOURCES = ["conv_igemm.hip", "bn_act.hip", "eltwise.hip", "losses.hip", "edge.hip", "agg.hip", "vq.hip", "optim.hip", "prior.hip", "api.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 

@@ -543,6 +543,63 @@ __global__ __launch_bounds__(256) void bn_bwd_small(const float* __restrict__ do
     }
 }
 
+
+// ---- fused BatchNorm: the producer conv's epilogue (or its split-K reduce) wrote per-column partial
+// sums; this finishes them.  One wave per channel: lanes stride over the partials, fp64 shuffle fold; then everything the
+// consumers need: the saved statistics for the backward, the folded affine map x_hat*gamma+beta = scale*y + shift that the next
+// conv applies while it loads y, and nn.BatchNorm2d's running statistics / num_batches_tracked.
+__global__ __launch_bounds__(64) void bn_finalize_k(const float* __restrict__ part, int parts, int rows, int C,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                    float momentum, float* __restrict__ save_mean, float* __restrict__ save_rstd,
+                                                    float* __restrict__ scale, float* __restrict__ shift,
+                                                    float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                    long long* __restrict__ nbt) {
+    const int c = blockIdx.x;
+    if (nbt && c == 0 && threadIdx.x == 0) nbt[0] += 1;
+    double s = 0.0, q = 0.0;
+    for (int p = threadIdx.x; p < parts; p += 64) {
+        s += (double)part[((long)p * 2 + 0) * C + c];
+        q += (double)part[((long)p * 2 + 1) * C + c];
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if (threadIdx.x != 0) return;
+    const double mean = s / rows;
+    double var = q / rows - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float m = (float)mean, r = (float)(1.0 / sqrt(var + (double)eps));
+    save_mean[c] = m;
+    save_rstd[c] = r;
+    // the same fp32 arithmetic as the stand-alone apply kernel: (y - mean) * rstd * gamma + beta, folded
+    const float a = r * gamma[c];
+    scale[c] = a;
+    shift[c] = fmaf(-m, a, beta[c]);
+    if (running_mean) {
+        const double unb = rows > 1 ? var * ((double)rows / (rows - 1)) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+    }
+}
+
+// out = act(scale[c] * y + shift[c]): materialises a fused BatchNorm output where a consumer cannot apply it on load
+__global__ __launch_bounds__(256) void scale_shift_act_k(const float* __restrict__ y, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, float* __restrict__ out, long nv, int C,
+                                                         float slope) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+        const int c = (int)((i * 4) % C);
+        const f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
+        const f32x4 a = *reinterpret_cast<const f32x4*>(scale + c), b = *reinterpret_cast<const f32x4*>(shift + c);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float z = fmaf(v[j], a[j], b[j]);
+            o[j] = z > 0.f ? z : z * slope;
+        }
+        reinterpret_cast<f32x4*>(out)[i] = o;
+    }
+}
+
 inline int small_rows() {  // MOVAE_BN_SMALL_ROWS: largest row count served by the one-launch kernels (0 disables them)
     static const int v = getenv("MOVAE_BN_SMALL_ROWS") ? atoi(getenv("MOVAE_BN_SMALL_ROWS")) : 1024;
     return v < 1024 ? v : 1024;  // the kernels hold the whole column in registers: 4 rows per thread
@@ -696,6 +753,27 @@ int movae_bn_act_bwd(const float* dout, const float* y, const float* gamma, cons
     float* db[1] = {dbeta};
     return movae_bn_act_bwd_grouped(1, dout, y, gamma, beta, save_mean, save_rstd, dy, dg, db, rows, c, act, slope, accumulate, ws,
                                     ws_bytes, stream);
+}
+
+int movae_bn_finalize(const float* stats, int parts, int rows, int c, const float* gamma, const float* beta, float eps, float momentum,
+                      float* save_mean, float* save_rstd, float* scale, float* shift, float* running_mean, float* running_var,
+                      long long* num_batches_tracked, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(stats && gamma && beta && save_mean && save_rstd && scale && shift, "movae_bn_finalize: null pointer");
+    MOVAE_CHECK_ARG(parts > 0 && rows > 0 && c > 0, "movae_bn_finalize: bad shape parts=%d rows=%d c=%d", parts, rows, c);
+    hipLaunchKernelGGL(bn_finalize_k, dim3(c), dim3(64), 0, (hipStream_t)stream, stats, parts, rows, c, gamma, beta, eps, momentum,
+                       save_mean, save_rstd, scale, shift, running_mean, running_var, num_batches_tracked);
+    MOVAE_CHECK_LAUNCH("bn_finalize");
+    return MOVAE_OK;
+}
+
+int movae_scale_shift_act(const float* y, const float* scale, const float* shift, float* out, size_t rows, int c, float slope,
+                          movae_stream_t stream) {
+    MOVAE_CHECK_ARG(y && scale && shift && out && rows > 0 && c > 0, "movae_scale_shift_act: bad argument");
+    MOVAE_CHECK_ARG(c % 4 == 0 && al16(y, out) && al16(scale, shift), "movae_scale_shift_act: needs c %% 4 == 0 and 16-byte aligned operands");
+    const long nv = (long)rows * c / 4;
+    hipLaunchKernelGGL(scale_shift_act_k, dim3(grid_for(nv / 4 + 1)), dim3(256), 0, (hipStream_t)stream, y, scale, shift, out, nv, c, slope);
+    MOVAE_CHECK_LAUNCH("scale_shift_act");
+    return MOVAE_OK;
 }
 
 }  // extern "C"

@@ -35,6 +35,58 @@ struct Epilogue {
     float slope;
 };
 
+// Fusion of a training-mode BatchNorm (+ LeakyReLU / ReLU) into its neighbours:
+//  * Norm -- the gathered activation operand is VIRTUAL: the kernel reads the producer's raw conv output y and applies
+//    x = act(scale[c] * y + shift[c]) (scale = gamma * rstd, shift = beta - mean * scale, act = leaky-ReLU with `slope`;
+//    slope 1 = none, 0 = ReLU) between the global load and the LDS store; padding stays exactly zero.  The normalised
+//    activation is never written to memory.
+//  * stats -- the epilogue also emits, per column (output channel), the partial sums (sum v, sum v^2) of the values it
+//    stores, one pair per (row block, wave): the statistics pass of the BatchNorm that follows reads no activation.
+struct Norm {
+    const float* scale;  // [C] or null: plain operand
+    const float* shift;
+    float slope;
+};
+
+__device__ __forceinline__ f32x4 norm_apply(f32x4 v, const f32x4 sc, const f32x4 sh, float slope) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float z = fmaf(v[e], sc[e], sh[e]);
+        v[e] = z > 0.f ? z : z * slope;
+    }
+    return v;
+}
+
+
+// What the *_f entry points ask of the next conv-family dispatch of the calling thread (cleared by the entry point on return).
+// The launchers that can honour a request mark it: an operand transform that the dispatched kernel cannot apply is an
+// error raised BEFORE anything is launched (MOVAE_EUNSUPPORTED: the caller materialises the activation and calls the plain
+// entry point); statistics that the dispatched kernel cannot emit leave stats_parts at 0 (the caller runs the stand-alone
+// statistics pass instead).
+struct FuseCtx {
+    Norm nrm{nullptr, nullptr, 1.f};  // virtual activation operand (x of fwd / wgrad)
+    int nrm_side = 0;                 // wgrad: which operand is the activation -- 1 small side Sm, 2 gathered side Bg
+    float* stats = nullptr;           // column partial sums of the forward result
+    size_t stats_cap = 0;             // floats available at `stats`
+    int stats_parts = 0;              // out: partial pairs written per column (0 = none)
+};
+static thread_local FuseCtx g_fuse;
+
+inline bool fuse_norm() { return g_fuse.nrm.scale != nullptr; }
+// claims the statistics slot for `parts` partials of `n` columns; false (and no statistics) when they do not fit
+inline float* fuse_stats_claim(long parts, int n) {
+    if (!g_fuse.stats || parts <= 0 || (size_t)parts * 2 * (size_t)n > g_fuse.stats_cap) return nullptr;
+    g_fuse.stats_parts = (int)parts;
+    return g_fuse.stats;
+}
+#define MOVAE_NO_NORM(what)                                                                                 \
+    do {                                                                                                    \
+        if (fuse_norm()) {                                                                                  \
+            movae_set_error("%s: this shape dispatches to a kernel without the fused input transform", what); \
+            return MOVAE_EUNSUPPORTED;                                                                      \
+        }                                                                                                   \
+    } while (0)
+
 template <int TM>
 __device__ __forceinline__ void mma_tile(const float* __restrict__ As, const float* __restrict__ Bs, int lda, int ldb,
                                          int a_off, int b_off, f32x16 (&acc)[TM]) {
@@ -572,6 +624,50 @@ __global__ __launch_bounds__(256) void splitk_reduce_cls(const float* __restrict
     }
 }
 
+// Split-K reduction that also emits the column statistics of its result (the BatchNorm that follows a split-K layer needs no
+// pass of its own): out[m][n] = sum_z slab[z][m][n] + bias[n]; part[(blk * 2 + {0,1}) * N + n] = sum / sum of squares over the
+// block's rows.  Thread t owns column quad t %% NQ (NQ = N / 4 divides 256) and every (256 / NQ)-th row of the block's
+// rows_per_block rows.  stride > 0: BWD-form slabs with per-class split counts (splitk_reduce_cls); else S slabs everywhere.
+__global__ __launch_bounds__(256) void splitk_reduce_stats(const float* __restrict__ slab, float* __restrict__ out, int M, int N, int S,
+                                                           ClsSplit scls, int Ho, int Wo, int stride, const float* __restrict__ bias,
+                                                           float* __restrict__ part, int rows_per_block) {
+    __shared__ float sh[2][4][256];
+    const int t = threadIdx.x, NQ = N >> 2, RG = 256 / NQ;
+    const int cq = t % NQ, rg = t / NQ;
+    const long total = (long)M * N;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    const f32x4 b4 = bias ? *reinterpret_cast<const f32x4*>(bias + cq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f}, q4 = s4;
+    for (int r = r0 + rg; r < r1; r += RG) {
+        int Sr = S;
+        if (stride > 0) {
+            const int wo = r % Wo, ho = (r / Wo) % Ho;
+            Sr = scls.s[(ho % stride) * stride + (wo % stride)];
+        }
+        const long i = (long)r * N + cq * 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(slab + i);
+        for (int z = 1; z < Sr; ++z) v += *reinterpret_cast<const f32x4*>(slab + (long)z * total + i);
+        v += b4;
+        if (out) *reinterpret_cast<f32x4*>(out + i) = v;
+        s4 += v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q4[j] = fmaf(v[j], v[j], q4[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sh[0][j][t] = s4[j], sh[1][j][t] = q4[j];
+    __syncthreads();
+    if (t < NQ) {  // fixed-order fold over the row groups
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s = 0.f, q = 0.f;
+            for (int i = 0; i < RG; ++i) s += sh[0][j][i * NQ + t], q += sh[1][j][i * NQ + t];
+            s4[j] = s, q4[j] = q;
+        }
+        *reinterpret_cast<f32x4*>(part + ((long)blockIdx.x * 2 + 0) * N + t * 4) = s4;
+        *reinterpret_cast<f32x4*>(part + ((long)blockIdx.x * 2 + 1) * N + t * 4) = q4;
+    }
+}
+
 const char* g_last_kernel = "";  // movae_bench_last_kernel(): main kernel chosen by the most recent conv-family dispatch
 int g_force_split = 0;           // movae_bench_force_split(): > 0 pins the split-K factor (tuning sweeps)
 bool g_bench_main_only = false;  // movae_bench_main_kernel_only(): time the MFMA kernel without its epilogue launches
@@ -594,6 +690,26 @@ inline int launch_reduce(const float* slab, float* out, long total, int S, int N
     }
     MOVAE_CHECK_LAUNCH("splitk_reduce");
     return MOVAE_OK;
+}
+
+// The reduce of a split-K forward whose result feeds a BatchNorm: sums, adds the bias and emits the column statistics.
+// Returns false when the shape does not fit the kernel (the caller then reduces plainly and no statistics are produced).
+inline bool launch_reduce_stats(const float* slab, float* out, long M, int N, int S, const ClsSplit* scls, int Ho, int Wo, int stride,
+                                const float* bias, hipStream_t st) {
+    if (!g_fuse.stats || N % 4 != 0 || N > 1024 || 256 % (N / 4) != 0 || M > 0x7fffffffL ||
+        ((reinterpret_cast<uintptr_t>(slab) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(g_fuse.stats)) & 15) != 0 ||
+        (bias && (reinterpret_cast<uintptr_t>(bias) & 15) != 0))
+        return false;
+    const int RG = 256 / (N / 4);
+    long rpb = 4L * RG;                                  // four rows per thread ...
+    if ((M + rpb - 1) / rpb > 1024) rpb = ((M + 1023) / 1024 + RG - 1) / RG * RG;  // ... at most 1024 partials
+    const long nblk = (M + rpb - 1) / rpb;
+    float* part = fuse_stats_claim(nblk, N);
+    if (!part) return false;
+    ClsSplit one{{S, S, S, S}};
+    hipLaunchKernelGGL(splitk_reduce_stats, dim3((unsigned)nblk), dim3(256), 0, st, slab, out, (int)M, N, S, scls ? *scls : one, Ho, Wo,
+                       scls ? stride : 0, bias, part, (int)rpb);
+    return true;
 }
 
 // split-K factor from a small cost model fitted to tools/conv_microbench.py --sweep-split on MI355X (tools/split_model.py
@@ -708,17 +824,24 @@ int launch_fwd(const float* X, const float* W, float* Y, const Geom& g_in, const
     }
     const int M = (int)Ml, K = (int)Kl;
     if (is_linear(g) && lin::linear_small_ok(Ml, g.Nn, Kl) && aligned16(X) && aligned16(W)) {
+        MOVAE_NO_NORM("linear (fwd)");
         float* ys[1] = {Y};
         return (g_last_kernel = "linear_small_k<NT>",
                 lin::launch_linear_small<0>(X, W, ys, nullptr, 1, 0, ep.bias, M, g.Nn, K, ep.act, ep.slope, 0, st));
     }
-    if (thin::thin_in_ok(g)) return (g_last_kernel = "thin_in_k<fwd>", thin::launch_thin_in<false>(X, W, Y, g, ep, st));
-    if (g.Nn <= 4) {  // 3-channel output: LDS-tiled direct kernel
+    if (thin::thin_in_ok(g)) {
+        MOVAE_NO_NORM("thin-channel input conv");
+        return (g_last_kernel = "thin_in_k<fwd>", thin::launch_thin_in<false>(X, W, Y, g, ep, st));
+    }
+    if (g.Nn <= 4) {  // 3-channel output: LDS-tiled direct kernel (applies the fused input transform while staging)
         bool handled = false;
         if (int rc = thin::launch_thin_out_tile<false>(X, W, Y, g, ep, st, &handled)) return rc;
         if (handled) return (g_last_kernel = "thin_out_tile_k<fwd>", MOVAE_OK);
     }
-    if (thin::thin_out_ok(g, X)) return (g_last_kernel = "thin_out_fwd_k", thin::launch_thin_out_fwd(X, W, Y, g, ep, st));
+    if (thin::thin_out_ok(g, X)) {
+        MOVAE_NO_NORM("thin-channel output conv");
+        return (g_last_kernel = "thin_out_fwd_k", thin::launch_thin_out_fwd(X, W, Y, g, ep, st));
+    }
     if (g.Cr % 4 == 0 && aligned16(X) && aligned16(W)) {  // fast path (igemm_v2.h)
         if (g.Nn <= 32) return (g_last_kernel = "igemm2_fwd<128,32>", v2::launch_fwd2<128, 32>(X, W, Y, g, ep, M, K, ws, ws_bytes, st));
         // 2x2 register tiling (64x64 per wave) once the 128x128 grid alone fills the chip
@@ -726,6 +849,7 @@ int launch_fwd(const float* X, const float* W, float* Y, const Geom& g_in, const
         if (Ml >= 128 * 512) return (g_last_kernel = "igemm2_fwd<128,64>", v2::launch_fwd2<128, 64>(X, W, Y, g, ep, M, K, ws, ws_bytes, st));
         return (g_last_kernel = "igemm2_fwd<64,64>", v2::launch_fwd2<64, 64>(X, W, Y, g, ep, M, K, ws, ws_bytes, st));
     }
+    MOVAE_NO_NORM("generic conv (fwd form)");
     const bool vec = (g.Cr % BK == 0) && aligned16(X) && aligned16(W);
     if (g.Nn <= 32) return (g_last_kernel = "igemm_fwd<128,32>", launch_fwd_t<128, 32>(X, W, Y, g, ep, M, K, vec, ws, ws_bytes, st));
     if (Ml >= 128 * 512) return (g_last_kernel = "igemm_fwd<128,64>", launch_fwd_t<128, 64>(X, W, Y, g, ep, M, K, vec, ws, ws_bytes, st));
@@ -765,11 +889,15 @@ int launch_bwd(const float* X, const float* W, float* Y, const Geom& g, const Ep
     }
     const long Mc = Ml / (g.stride * g.stride);
     if (is_linear(g) && lin::linear_small_ok(Ml, g.Nn, g.Cr) && g.Nn % 4 == 0 && aligned16(X) && aligned16(W)) {
+        MOVAE_NO_NORM("linear (bwd form)");
         float* ys[1] = {Y};
         return (g_last_kernel = "linear_small_k<NN>",
                 lin::launch_linear_small<1>(X, W, ys, nullptr, 1, 0, ep.bias, (int)Ml, g.Nn, g.Cr, ep.act, ep.slope, 0, st));
     }
-    if (thin::thin_in_ok(g)) return (g_last_kernel = "thin_in_k<bwd>", thin::launch_thin_in<true>(X, W, Y, g, ep, st));
+    if (thin::thin_in_ok(g)) {
+        MOVAE_NO_NORM("thin-channel input (bwd form)");
+        return (g_last_kernel = "thin_in_k<bwd>", thin::launch_thin_in<true>(X, W, Y, g, ep, st));
+    }
     if (g.Nn <= 4) {  // 3-channel output of a transposed conv: LDS-tiled direct kernel
         bool handled = false;
         if (int rc = thin::launch_thin_out_tile<true>(X, W, Y, g, ep, st, &handled)) return rc;
@@ -782,6 +910,7 @@ int launch_bwd(const float* X, const float* W, float* Y, const Geom& g, const Ep
         if (Mc >= 128 * 512) return (g_last_kernel = "igemm2_bwd<128,64>", v2::launch_bwd2<128, 64>(X, W, Y, g, ep, ws, ws_bytes, st));
         return (g_last_kernel = "igemm2_bwd<64,64>", v2::launch_bwd2<64, 64>(X, W, Y, g, ep, ws, ws_bytes, st));
     }
+    MOVAE_NO_NORM("generic conv (bwd form)");
     const bool vec = (g.Cr % BK == 0) && (g.Nn % 4 == 0) && aligned16(X) && aligned16(W);
     if (g.Nn <= 32) return (g_last_kernel = "igemm_bwd<128,32>", launch_bwd_t<128, 32>(X, W, Y, g, ep, vec, ws, ws_bytes, st));
     if (Mc >= 128 * 512) return (g_last_kernel = "igemm_bwd<128,64>", launch_bwd_t<128, 64>(X, W, Y, g, ep, vec, ws, ws_bytes, st));
@@ -844,6 +973,7 @@ int launch_wgrad(const float* S, const float* Bg, float* const* dW, int G, long 
     if (colsum_done) *colsum_done = false;
     if (g.KH == 1 && g.KW == 1 && g.Hs == 1 && g.Ws == 1 && g.Hb == 1 && g.Wb == 1 && b_gs == 0 &&
         lin::linear_small_ok(g.Cs, g.Cb, (Kl + 3) / 4 * 4) && !g_bench_main_only) {  // reduction = batch rows, any count
+        MOVAE_NO_NORM("linear (wgrad)");
         if (colsum_done) *colsum_done = colsum_S != nullptr;
         return (g_last_kernel = "linear_small_k<TN>",
                 lin::launch_linear_small<2>(S, Bg, dW, colsum_S, G, s_gs, nullptr, g.Cs, g.Cb, (int)Kl, 0, 0.f, accumulate, st));
@@ -860,6 +990,7 @@ int launch_wgrad(const float* S, const float* Bg, float* const* dW, int G, long 
     }
     if (thin::thin_wgrad_ok(g) && ws)
         return (g_last_kernel = "thin_wgrad", thin::launch_thin_wgrad_grouped(S, Bg, dW, G, s_gs, b_gs, g, (int)Kl, accumulate, ws, ws_bytes, st));
+    MOVAE_NO_NORM("generic wgrad");
     for (int i = 0; i < G; ++i)
         if (int rc = launch_wgrad1(S + i * s_gs, Bg + i * b_gs, dW[i], g, accumulate, ws, ws_bytes, st)) return rc;
     return MOVAE_OK;
@@ -891,6 +1022,26 @@ int check_conv_shape(const char* who, int n, int hi, int wi, int ci, int ho, int
 
 }  // namespace
 
+// installs a movae_fuse_t for the dispatch made inside the scope; on exit reports the statistics partial count and clears it
+struct FuseScope {
+    movae_fuse_t* f;
+    explicit FuseScope(movae_fuse_t* fuse, int nrm_side) : f(fuse) {
+        g_fuse = FuseCtx();
+        if (!f) return;
+        f->stats_parts = 0;
+        if (f->in_scale && f->in_shift) g_fuse.nrm = Norm{f->in_scale, f->in_shift, f->in_slope}, g_fuse.nrm_side = nrm_side;
+        if (f->stats && f->stats_cap > 0) g_fuse.stats = f->stats, g_fuse.stats_cap = f->stats_cap;
+    }
+    ~FuseScope() {
+        if (f) f->stats_parts = g_fuse.stats_parts;
+        g_fuse = FuseCtx();
+    }
+};
+#define MOVAE_CHECK_FUSE(f, c)                                                                                                   \
+    MOVAE_CHECK_ARG(!(f) || !(f)->in_scale ||                                                                                    \
+                        ((f)->in_shift && (c) % 4 == 0 && ((reinterpret_cast<uintptr_t>((f)->in_scale) | reinterpret_cast<uintptr_t>((f)->in_shift)) & 15) == 0), \
+                    "fused input transform: needs scale AND shift, 16-byte aligned, channels %% 4 == 0")
+
 extern "C" {
 
 const char* movae_bench_last_kernel(void) { return g_last_kernel; }
@@ -907,14 +1058,22 @@ int movae_bench_main_kernel_only(int on) {
     return prev;
 }
 
-int movae_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int n, int hi, int wi, int ci, int ho,
-                     int wo, int co, int kh, int kw, int stride, int pad, int act, float slope, void* ws, size_t ws_bytes,
-                     movae_stream_t stream) {
+int movae_conv2d_fwd_f(const float* x, const float* w, const float* bias, float* y, int n, int hi, int wi, int ci, int ho,
+                       int wo, int co, int kh, int kw, int stride, int pad, int act, float slope, void* ws, size_t ws_bytes,
+                       movae_stream_t stream, movae_fuse_t* fuse) {
     MOVAE_WS_SCRATCH(ws, ws_bytes);
     MOVAE_CHECK_ARG(x && w && y, "movae_conv2d_fwd: null pointer");
     if (int rc = check_conv_shape("movae_conv2d_fwd", n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, false)) return rc;
+    MOVAE_CHECK_FUSE(fuse, ci);
+    FuseScope scope(fuse, 0);
     Geom g{n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad};
     return launch_fwd(x, w, y, g, Epilogue{bias, act, slope}, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int movae_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int n, int hi, int wi, int ci, int ho,
+                     int wo, int co, int kh, int kw, int stride, int pad, int act, float slope, void* ws, size_t ws_bytes,
+                     movae_stream_t stream) {
+    return movae_conv2d_fwd_f(x, w, bias, y, n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, act, slope, ws, ws_bytes, stream, nullptr);
 }
 
 int movae_conv2d_dgrad(const float* dy, const float* w, float* dx, int n, int hi, int wi, int ci, int ho, int wo, int co,
@@ -927,9 +1086,11 @@ int movae_conv2d_dgrad(const float* dy, const float* w, float* dx, int n, int hi
     return launch_bwd(dy, w, dx, g, Epilogue{nullptr, MOVAE_ACT_NONE, 0.f}, ws, ws_bytes, (hipStream_t)stream);
 }
 
-int movae_conv2d_wgrad_grouped(int groups, const float* dy, const float* x, float* const* dw, float* const* dbias, int n, int hi,
+int movae_conv2d_wgrad_grouped_f(int groups, const float* dy, const float* x, float* const* dw, float* const* dbias, int n, int hi,
                                int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad, int accumulate,
-                               void* ws, size_t ws_bytes, movae_stream_t stream) {
+                               void* ws, size_t ws_bytes, movae_stream_t stream, const movae_fuse_t* fuse) {
+    MOVAE_CHECK_FUSE(fuse, ci);
+    FuseScope scope(const_cast<movae_fuse_t*>(fuse), 2);
     void* ws_full = ws;
     const size_t ws_full_bytes = ws_bytes;
     MOVAE_WS_SCRATCH(ws, ws_bytes);
@@ -947,6 +1108,12 @@ int movae_conv2d_wgrad_grouped(int groups, const float* dy, const float* x, floa
     return MOVAE_OK;
 }
 
+int movae_conv2d_wgrad_grouped(int groups, const float* dy, const float* x, float* const* dw, float* const* dbias, int n, int hi,
+                               int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad, int accumulate,
+                               void* ws, size_t ws_bytes, movae_stream_t stream) {
+    return movae_conv2d_wgrad_grouped_f(groups, dy, x, dw, dbias, n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, accumulate, ws, ws_bytes, stream, nullptr);
+}
+
 int movae_conv2d_wgrad(const float* dy, const float* x, float* dw, float* dbias, int n, int hi, int wi, int ci, int ho,
                        int wo, int co, int kh, int kw, int stride, int pad, int accumulate, void* ws, size_t ws_bytes,
                        movae_stream_t stream) {
@@ -956,14 +1123,22 @@ int movae_conv2d_wgrad(const float* dy, const float* x, float* dw, float* dbias,
                                       ws, ws_bytes, stream);
 }
 
-int movae_convT2d_fwd(const float* x, const float* w, const float* bias, float* y, int n, int hi, int wi, int ci, int ho,
-                      int wo, int co, int kh, int kw, int stride, int pad, int act, float slope, void* ws, size_t ws_bytes,
-                      movae_stream_t stream) {
+int movae_convT2d_fwd_f(const float* x, const float* w, const float* bias, float* y, int n, int hi, int wi, int ci, int ho,
+                        int wo, int co, int kh, int kw, int stride, int pad, int act, float slope, void* ws, size_t ws_bytes,
+                        movae_stream_t stream, movae_fuse_t* fuse) {
     MOVAE_WS_SCRATCH(ws, ws_bytes);
     MOVAE_CHECK_ARG(x && w && y, "movae_convT2d_fwd: null pointer");
     if (int rc = check_conv_shape("movae_convT2d_fwd", n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, true)) return rc;
+    MOVAE_CHECK_FUSE(fuse, ci);
+    FuseScope scope(fuse, 0);
     Geom g{n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad};
     return launch_bwd(x, w, y, g, Epilogue{bias, act, slope}, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int movae_convT2d_fwd(const float* x, const float* w, const float* bias, float* y, int n, int hi, int wi, int ci, int ho,
+                      int wo, int co, int kh, int kw, int stride, int pad, int act, float slope, void* ws, size_t ws_bytes,
+                      movae_stream_t stream) {
+    return movae_convT2d_fwd_f(x, w, bias, y, n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, act, slope, ws, ws_bytes, stream, nullptr);
 }
 
 int movae_convT2d_dgrad(const float* dy, const float* w, float* dx, int n, int hi, int wi, int ci, int ho, int wo, int co,
@@ -976,9 +1151,11 @@ int movae_convT2d_dgrad(const float* dy, const float* w, float* dx, int n, int h
     return launch_fwd(dy, w, dx, g, Epilogue{nullptr, MOVAE_ACT_NONE, 0.f}, ws, ws_bytes, (hipStream_t)stream);
 }
 
-int movae_convT2d_wgrad_grouped(int groups, const float* dy, const float* x, float* const* dw, float* const* dbias, int n, int hi,
+int movae_convT2d_wgrad_grouped_f(int groups, const float* dy, const float* x, float* const* dw, float* const* dbias, int n, int hi,
                                 int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad, int accumulate,
-                                void* ws, size_t ws_bytes, movae_stream_t stream) {
+                                void* ws, size_t ws_bytes, movae_stream_t stream, const movae_fuse_t* fuse) {
+    MOVAE_CHECK_FUSE(fuse, ci);
+    FuseScope scope(const_cast<movae_fuse_t*>(fuse), 1);
     void* ws_full = ws;
     const size_t ws_full_bytes = ws_bytes;
     MOVAE_WS_SCRATCH(ws, ws_bytes);
@@ -995,6 +1172,12 @@ int movae_convT2d_wgrad_grouped(int groups, const float* dy, const float* x, flo
     return MOVAE_OK;
 }
 
+int movae_convT2d_wgrad_grouped(int groups, const float* dy, const float* x, float* const* dw, float* const* dbias, int n, int hi,
+                                int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad, int accumulate,
+                                void* ws, size_t ws_bytes, movae_stream_t stream) {
+    return movae_convT2d_wgrad_grouped_f(groups, dy, x, dw, dbias, n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, accumulate, ws, ws_bytes, stream, nullptr);
+}
+
 int movae_convT2d_wgrad(const float* dy, const float* x, float* dw, float* dbias, int n, int hi, int wi, int ci, int ho,
                         int wo, int co, int kh, int kw, int stride, int pad, int accumulate, void* ws, size_t ws_bytes,
                         movae_stream_t stream) {
@@ -1008,7 +1191,7 @@ int movae_convT2d_wgrad(const float* dy, const float* x, float* dw, float* dbias
 // MFMA kernels (igemm2_pair); otherwise exactly the two calls above, in that order.
 static int pair_calls(bool transposed, int groups, const float* dy, const float* w, const float* x, float* dx, float* const* dw,
                       float* const* dbias, int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad,
-                      int accumulate, void* ws, size_t ws_bytes, movae_stream_t stream) {
+                      int accumulate, void* ws, size_t ws_bytes, movae_stream_t stream, const movae_fuse_t* fuse) {
     static const bool enabled = !getenv("MOVAE_NO_PAIR");
     v2::g_pending.active = false;
     v2::g_pair_collect = enabled;
@@ -1025,10 +1208,11 @@ static int pair_calls(bool transposed, int groups, const float* dy, const float*
         used = 0;
     }
     void* ws2 = ws ? static_cast<char*>(ws) + used : nullptr;
-    rc = transposed ? movae_convT2d_wgrad_grouped(groups, dy, x, dw, dbias, n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, accumulate, ws2,
-                                                  ws_bytes - used, stream)
-                    : movae_conv2d_wgrad_grouped(groups, dy, x, dw, dbias, n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, accumulate, ws2,
-                                                 ws_bytes - used, stream);
+    // (`fuse` describes the activation operand x, which only the weight gradient reads)
+    rc = transposed ? movae_convT2d_wgrad_grouped_f(groups, dy, x, dw, dbias, n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, accumulate, ws2,
+                                                    ws_bytes - used, stream, fuse)
+                    : movae_conv2d_wgrad_grouped_f(groups, dy, x, dw, dbias, n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, accumulate, ws2,
+                                                   ws_bytes - used, stream, fuse);
     if (v2::g_pending.active) {  // the wgrad took a kernel that does not pair (thin / linear / generic)
         const int rc2 = v2::flush_pending((hipStream_t)stream);
         if (!rc) rc = rc2;
@@ -1036,20 +1220,53 @@ static int pair_calls(bool transposed, int groups, const float* dy, const float*
     return rc;
 }
 
+int movae_conv2d_dgrad_wgrad_grouped_f(int groups, const float* dy, const float* w, const float* x, float* dx, float* const* dw,
+                                       float* const* dbias, int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw,
+                                       int stride, int pad, int accumulate, void* ws, size_t ws_bytes, movae_stream_t stream,
+                                       const movae_fuse_t* fuse) {
+    MOVAE_CHECK_ARG(dx && w, "movae_conv2d_dgrad_wgrad: null pointer");
+    return pair_calls(false, groups, dy, w, x, dx, dw, dbias, n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, accumulate, ws, ws_bytes,
+                      stream, fuse);
+}
+
 int movae_conv2d_dgrad_wgrad_grouped(int groups, const float* dy, const float* w, const float* x, float* dx, float* const* dw,
                                      float* const* dbias, int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw,
                                      int stride, int pad, int accumulate, void* ws, size_t ws_bytes, movae_stream_t stream) {
-    MOVAE_CHECK_ARG(dx && w, "movae_conv2d_dgrad_wgrad: null pointer");
-    return pair_calls(false, groups, dy, w, x, dx, dw, dbias, n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, accumulate, ws, ws_bytes,
-                      stream);
+    return movae_conv2d_dgrad_wgrad_grouped_f(groups, dy, w, x, dx, dw, dbias, n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, accumulate,
+                                              ws, ws_bytes, stream, nullptr);
+}
+
+int movae_convT2d_dgrad_wgrad_grouped_f(int groups, const float* dy, const float* w, const float* x, float* dx, float* const* dw,
+                                        float* const* dbias, int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw,
+                                        int stride, int pad, int accumulate, void* ws, size_t ws_bytes, movae_stream_t stream,
+                                        const movae_fuse_t* fuse) {
+    MOVAE_CHECK_ARG(dx && w, "movae_convT2d_dgrad_wgrad: null pointer");
+    return pair_calls(true, groups, dy, w, x, dx, dw, dbias, n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, accumulate, ws, ws_bytes,
+                      stream, fuse);
 }
 
 int movae_convT2d_dgrad_wgrad_grouped(int groups, const float* dy, const float* w, const float* x, float* dx, float* const* dw,
                                       float* const* dbias, int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw,
                                       int stride, int pad, int accumulate, void* ws, size_t ws_bytes, movae_stream_t stream) {
-    MOVAE_CHECK_ARG(dx && w, "movae_convT2d_dgrad_wgrad: null pointer");
-    return pair_calls(true, groups, dy, w, x, dx, dw, dbias, n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, accumulate, ws, ws_bytes,
-                      stream);
+    return movae_convT2d_dgrad_wgrad_grouped_f(groups, dy, w, x, dx, dw, dbias, n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, accumulate,
+                                               ws, ws_bytes, stream, nullptr);
+}
+
+// Stand-alone statistics pass in the partial-sum format of the fused epilogues, for producers that cannot emit them
+// (a thin-channel or generic kernel): one read of y.
+int movae_bn_stats(const float* y, int rows, int c, float* stats, size_t stats_cap, int* parts_out, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(y && stats && parts_out && rows > 0 && c > 0, "movae_bn_stats: bad argument");
+    g_fuse = FuseCtx();
+    g_fuse.stats = stats, g_fuse.stats_cap = stats_cap;
+    const bool ok = launch_reduce_stats(y, nullptr, rows, c, 1, nullptr, 0, 0, 0, nullptr, (hipStream_t)stream);
+    *parts_out = g_fuse.stats_parts;
+    g_fuse = FuseCtx();
+    if (!ok) {
+        movae_set_error("movae_bn_stats: unsupported shape rows=%d c=%d (needs c %% 4 == 0, 256 %% (c / 4) == 0, aligned operands, room for the partials)", rows, c);
+        return MOVAE_EUNSUPPORTED;
+    }
+    MOVAE_CHECK_LAUNCH("bn_stats");
+    return MOVAE_OK;
 }
 
 }  // extern "C"

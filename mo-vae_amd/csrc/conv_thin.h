@@ -18,7 +18,7 @@ namespace thin {
 template <int NN, bool BWD>
 __global__ __launch_bounds__(256) void thin_in_k(const float* __restrict__ X, const float* __restrict__ W,
                                                  const float* __restrict__ bias, float* __restrict__ Y, Geom g, int M, int act,
-                                                 float slope) {
+                                                 float slope, float* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) float Wl[];  // [K][NN]
     const int t = threadIdx.x;
     const int taps = g.KH * g.KW, K = taps * g.Cr, N = g.Nn;
@@ -83,6 +83,26 @@ __global__ __launch_bounds__(256) void thin_in_k(const float* __restrict__ X, co
         __syncthreads();
         float* yb = Y + (long)blockIdx.x * 256 * 32;
         const long rows_left = (long)M - (long)blockIdx.x * 256;
+        if (stats) {
+            // column statistics of the block's 256 x 32 tile for the BatchNorm that follows (the tile sits in LDS anyway):
+            // thread t sums channel t & 31 over rows 32 * (t >> 5) ..+31 (stride 33: conflict-free), the two row groups of a
+            // wave fold with one shuffle; one partial pair per wave: stats[((4 * block + wave) * 2 + {0,1}) * 32 + c]
+            const int c = t & 31, r0 = (t >> 5) * 32;
+            float sm = 0.f, sq = 0.f;
+            for (int r = 0; r < 32; ++r)
+                if (r0 + r < rows_left) {
+                    const float v = Wl[(r0 + r) * 33 + c];
+                    sm += v;
+                    sq = fmaf(v, v, sq);
+                }
+            sm += __shfl_xor(sm, 32, 64);
+            sq += __shfl_xor(sq, 32, 64);
+            if ((t & 63) < 32) {
+                const long pidx = (long)blockIdx.x * 4 + (t >> 6);
+                stats[(pidx * 2 + 0) * 32 + c] = sm;
+                stats[(pidx * 2 + 1) * 32 + c] = sq;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int idx = i * 256 + t, px = idx >> 3, q = idx & 7;
@@ -169,7 +189,8 @@ __global__ __launch_bounds__(256) void thin_out_fwd_k(const float* __restrict__ 
 template <bool BWD, int CC, int PPT>
 __global__ __launch_bounds__(256) void thin_out_tile_k(const float* __restrict__ X, const float* __restrict__ W,
                                                        const float* __restrict__ bias, float* __restrict__ Y, Geom g, int TH,
-                                                       int TW, int tiles_h, int tiles_w, int IH, int IW, int act, float slope) {
+                                                       int TW, int tiles_h, int tiles_w, int IH, int IW, int act, float slope,
+                                                       Norm nrm) {
     constexpr int XS = CC + 4;  // LDS pixel stride
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xT = lds;                    // [IH*IW][XS]
@@ -228,7 +249,7 @@ __global__ __launch_bounds__(256) void thin_out_tile_k(const float* __restrict__
         // load per trip pays the full memory latency every trip
         for (int base = t; base < IH * IW * QC; base += 4 * 256) {
             f32x4 v[4];
-            int dst[4];
+            int dst[4], nch[4];  // nch: first channel of the chunk when it holds real data under a fused input transform, else -1
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int idx = base + u * 256;
@@ -237,7 +258,15 @@ __global__ __launch_bounds__(256) void thin_out_tile_k(const float* __restrict__
                 const int h = iy0 + r, w = ix0 + c, ch = c0 + q * 4;
                 const bool ok = idx < IH * IW * QC && h >= 0 && h < g.Hi && w >= 0 && w < g.Wi && ch < g.Cr;
                 dst[u] = idx < IH * IW * QC ? pix * XS + q * 4 : -1;
+                nch[u] = (ok && nrm.scale) ? ch : -1;  // padding stays exactly zero under the transform
                 v[u] = ok ? *reinterpret_cast<const f32x4*>(Xb + ((long)h * g.Wi + w) * g.Cr + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (nrm.scale) {  // virtual input (fused BatchNorm + activation of the producer): transform between load and LDS store
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (nch[u] >= 0)
+                        v[u] = norm_apply(v[u], *reinterpret_cast<const f32x4*>(nrm.scale + nch[u]),
+                                          *reinterpret_cast<const f32x4*>(nrm.shift + nch[u]), nrm.slope);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -458,7 +487,7 @@ template <int TC, int KH, int KW, bool REV>
 __global__ __launch_bounds__(256) void thin_wgrad_sweep_k(const float* __restrict__ Wide, const float* __restrict__ Thin,
                                                           float* __restrict__ slab, int Hw, int Ww, int Cw, int Ht, int Wt,
                                                           int stride, int pad, int TH, int TW, int tiles_h, int tiles_w,
-                                                          int Cs, int Cb, long wide_gs, long thin_gs, long slab_gs) {
+                                                          int Cs, int Cb, long wide_gs, long thin_gs, long slab_gs, Norm nrm) {
     constexpr int TAPS = KH * KW, NA = TAPS * TC;
     Wide += blockIdx.z * wide_gs;  // cotangent group (batched pull-back): 0 for the operand the groups share
     Thin += blockIdx.z * thin_gs;
@@ -483,7 +512,12 @@ __global__ __launch_bounds__(256) void thin_wgrad_sweep_k(const float* __restric
             const int py = pix / TW, px = pix - py * TW;
             const int y = y0 + py, x = x0 + px;
             f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (y < Hw && x < Ww) v = *reinterpret_cast<const f32x4*>(Wb + ((long)y * Ww + x) * Cw + q * 4);
+            if (y < Hw && x < Ww) {
+                v = *reinterpret_cast<const f32x4*>(Wb + ((long)y * Ww + x) * Cw + q * 4);
+                if (nrm.scale)  // the wide operand is a virtual activation (fused BatchNorm + activation of its producer)
+                    v = norm_apply(v, *reinterpret_cast<const f32x4*>(nrm.scale + c0 + q * 4),
+                                   *reinterpret_cast<const f32x4*>(nrm.shift + c0 + q * 4), nrm.slope);
+            }
             *reinterpret_cast<f32x4*>(wideT + pix * 32 + q * 4) = v;
         }
         // thin tile with its halo, zero outside the image
@@ -555,13 +589,15 @@ int launch_thin_in(const float* X, const float* W, float* Y, const Geom& g, cons
     if (g.Nn > 32) {
         dim3 grid(ceil_div(M, 256), ceil_div(g.Nn, 64));
         hipLaunchKernelGGL((thin_in_k<64, BWD>), grid, dim3(256), (size_t)K * 64 * sizeof(float), st, X, W, ep.bias, Y, g, M,
-                           ep.act, ep.slope);
+                           ep.act, ep.slope, (float*)nullptr);
     } else {
         dim3 grid(ceil_div(M, 256), 1);
         size_t lds_floats = (size_t)K * 32;
         if (g.Nn == 32 && lds_floats < 256 * 33) lds_floats = 256 * 33;  // room for the coalescing transpose of the outputs
+        float* stats = nullptr;  // the 32-output kernel holds its tile in LDS: statistics for a following BatchNorm come for free
+        if (!BWD && g.Nn == 32 && ep.act == MOVAE_ACT_NONE) stats = fuse_stats_claim((long)grid.x * 4, 32);
         hipLaunchKernelGGL((thin_in_k<32, BWD>), grid, dim3(256), lds_floats * sizeof(float), st, X, W, ep.bias, Y, g, M,
-                           ep.act, ep.slope);
+                           ep.act, ep.slope, stats);
     }
     MOVAE_CHECK_LAUNCH("thin_in");
     return MOVAE_OK;
@@ -624,7 +660,7 @@ int launch_thin_out_tile(const float* X, const float* W, float* Y, const Geom& g
     const size_t shb = ((size_t)IH * IW * (CC + 4) + (size_t)g.KH * g.KW * 4 * CC) * sizeof(float);
 #define MOVAE_TO(CCV, PPTV)                                                                                                      \
     hipLaunchKernelGGL((thin_out_tile_k<BWD, CCV, PPTV>), dim3((unsigned)nblk), dim3(256), shb, st, X, W, ep.bias, Y, g, TH, TW, tiles_h, \
-                       tiles_w, IH, IW, ep.act, ep.slope)
+                       tiles_w, IH, IW, ep.act, ep.slope, g_fuse.nrm)
     if (CC == 32) {
         if (PPT == 2) MOVAE_TO(32, 2); else MOVAE_TO(32, 1);
     } else {
@@ -681,9 +717,18 @@ int launch_thin_wgrad_impl(const float* S, const float* Bg, float* const* dW, in
                 const size_t shb = (size_t)lds_bytes(TH, TW);
                 const float* Wd = thin_small ? Bg : S;
                 const float* Tn = thin_small ? S : Bg;
+                // fused input transform: only when the activation is the WIDE operand (the thin one would be the image side)
+                Norm wide_nrm{nullptr, nullptr, 1.f};
+                if (fuse_norm()) {
+                    if (g_fuse.nrm_side != (thin_small ? 2 : 1)) {
+                        movae_set_error("thin wgrad: the fused input transform applies to the wide operand only");
+                        return MOVAE_EUNSUPPORTED;
+                    }
+                    wide_nrm = g_fuse.nrm;
+                }
 #define MOVAE_SW(K, REVV)                                                                                                      \
     hipLaunchKernelGGL((thin_wgrad_sweep_k<3, K, K, REVV>), grid, dim3(256), shb, st, Wd, Tn, slab, Hw, Ww, wide, Ht, Wt, g.stride, \
-                       g.pad, TH, TW, tiles_h, tiles_w, g.Cs, g.Cb, wide_gs, thin_gs, slab_gs)
+                       g.pad, TH, TW, tiles_h, tiles_w, g.Cs, g.Cb, wide_gs, thin_gs, slab_gs, wide_nrm)
                 if (thin_small) {
                     if (k33) MOVAE_SW(3, true); else MOVAE_SW(4, true);
                 } else {
@@ -699,6 +744,7 @@ int launch_thin_wgrad_impl(const float* S, const float* Bg, float* const* dW, in
         }
     }
     *handled = false;
+    MOVAE_NO_NORM("thin wgrad (non-sweep kernels)");
     return MOVAE_OK;
 }
 

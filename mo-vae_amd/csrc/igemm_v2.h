@@ -108,6 +108,36 @@ __device__ __forceinline__ void mma_kk(const float* __restrict__ As, const float
 
 #define ZERO4 (f32x4{0.f, 0.f, 0.f, 0.f})
 
+// Per-column partial sums of a wave's TM x TN 32x32 accumulator tiles (+ bias), rows >= M excluded: part[(p * 2 + 0) * N + n]
+// = sum, [(p * 2 + 1) * N + n] = sum of squares, p = the wave's partial index.  Lane l holds column l & 31 of each tile in 16
+// registers (rows (r & 3) + 8 (r >> 2) + 4 (l >> 5)); the two lane halves are folded with one cross-half shuffle.
+template <int TM, int TN>
+__device__ __forceinline__ void col_stats_store(const f32x16 (&acc)[TM * TN], const float* __restrict__ bias, float* __restrict__ part,
+                                                long pidx, int m_base, int n_base, int M, int N) {
+    const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int n = n_base + tn * 32 + l31;
+        const float bv = (bias && n < N) ? bias[n] : 0.f;
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m_base + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float v = m < M ? acc[tm * TN + tn][r] + bv : 0.f;
+                s += v;
+                q = fmaf(v, v, q);
+            }
+        s += __shfl_xor(s, 32, 64);
+        q += __shfl_xor(q, 32, 64);
+        if (half == 0 && n < N) {
+            part[(pidx * 2 + 0) * N + n] = s;
+            part[(pidx * 2 + 1) * N + n] = q;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Kernel arguments as plain structs and kernel bodies as device functions of an explicit block index (bx, by, bz) and an
 // LDS base: the stand-alone kernels below pass blockIdx, the paired kernel (igemm2_pair) runs a dgrad body and a wgrad
@@ -120,6 +150,8 @@ struct FwdArgs {
     Epilogue ep;
     int M, K, ktiles_per_split;
     float* slab;
+    Norm nrm;      // virtual gathered operand (zero-initialised: plain)
+    float* stats;  // column partial sums of the stored result [gx * WM][2][N], or null (only without split-K)
 };
 
 template <int BM, int BN>
@@ -176,17 +208,30 @@ __device__ __forceinline__ void igemm2_fwd_body(const FwdArgs& a, float* __restr
     const int kt_end = min(nk_total, kt_begin + ktiles_per_split);
 
     f32x4 ra[AC], rb[BC];
+    // virtual operand (Norm): the transform is applied in store_tile, i.e. where the loaded values are first consumed -- applied
+    // at the load it would put the load's wait in front of the MFMAs that are meant to hide it
+    const float* __restrict__ nsc = a.nrm.scale;
+    const float* __restrict__ nsh = a.nrm.shift;
+    const float nslope = a.nrm.slope;
+    f32x4 nsa = ZERO4, nsb = ZERO4;
+    unsigned amask = 0;
     auto load_tile = [&](int kt) {
         const int k = kt * BK2 + kq * 4;
         const bool kv = k < K;
         const int kk = kv ? k : 0;
         const int tap = kk / g.Cr, c = kk - tap * g.Cr;
         const int kh = tap / g.KW, kw = tap - kh * g.KW;
+        amask = 0;
 #pragma unroll
         for (int i = 0; i < AC; ++i) {
             const int h = a_h0[i] + kh, w = a_w0[i] + kw;
             const bool v = kv && a_ok[i] && h >= 0 && h < g.Hi && w >= 0 && w < g.Wi;
             ra[i] = v ? *reinterpret_cast<const f32x4*>(a_base[i] + ((long)h * g.Wi + w) * g.Cr + c) : ZERO4;
+            amask |= (v ? 1u : 0u) << i;
+        }
+        if (nsc) {
+            nsa = *reinterpret_cast<const f32x4*>(nsc + c);
+            nsb = *reinterpret_cast<const f32x4*>(nsh + c);
         }
         const int kb = g.wlen ? (kk / g.wlen) * g.wstride + kk % g.wlen : kk;  // window row -> stored kernel row
 #pragma unroll
@@ -200,6 +245,11 @@ __device__ __forceinline__ void igemm2_fwd_body(const FwdArgs& a, float* __restr
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     const int wave = t >> 6, wm = wave / T::WN, wn = wave % T::WN;
     auto store_tile = [&](int buf) {
+        if (nsc) {
+#pragma unroll
+            for (int i = 0; i < AC; ++i)
+                if ((amask >> i) & 1u) ra[i] = norm_apply(ra[i], nsa, nsb, nslope);
+        }
 #pragma unroll
         for (int i = 0; i < AC; ++i) *reinterpret_cast<f32x4*>(As + buf * ASZ + (r8 + RPP * i) * LDR + kq * 4) = ra[i];
 #pragma unroll
@@ -241,6 +291,8 @@ __device__ __forceinline__ void igemm2_fwd_body(const FwdArgs& a, float* __restr
     const int lane = t & 63, half = lane >> 5, l31 = lane & 31;
     const bool to_slab = slab != nullptr;
     float* out = to_slab ? slab + (long)bz * M * N : Y;
+    if (a.stats && !to_slab)  // statistics of v + bias (the host asks for them only with act == none)
+        col_stats_store<T::TM, T::TN>(acc, ep.bias, a.stats, (long)bx * T::WM + wm, m0 + wm * T::TM * 32, n0 + wn * T::TN * 32, M, N);
 #pragma unroll
     for (int tn = 0; tn < T::TN; ++tn) {
         const int n = n0 + wn * T::TN * 32 + tn * 32 + l31;
@@ -273,6 +325,9 @@ struct BwdArgs {
     ClsSplit scls, kps;
     float* slab;
     long total;
+    Norm nrm;
+    float* stats;  // [classes * gx * WM][2][N] or null (only without split-K)
+    int stats_gx;  // row blocks per class (the launch's grid x) -- the partial index is (class * gx + bx) * WM + wave row
 };
 
 template <int BM, int BN>
@@ -308,8 +363,19 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
     const int Hoc = (g.Ho - ph + s - 1) / s, Woc = (g.Wo - pw + s - 1) / s;
     const int M = g.Nimg * Hoc * Woc;
     const int m0 = bx * BM, n0 = by * BN;
-    if (m0 >= M) return;
     const int N = g.Nn;
+    if (m0 >= M) {  // a class with fewer row blocks than the grid: nothing to compute, but its statistics slots must read zero
+        if (a.stats && a.slab == nullptr) {
+            const int wv = t >> 6, wm_ = wv / T2<BM, BN>::WN, wn_ = wv % T2<BM, BN>::WN, l = t & 63;
+            const long pidx = ((long)cls * a.stats_gx + bx) * T2<BM, BN>::WM + wm_;
+            if (l < 32)
+                for (int tn = 0; tn < T2<BM, BN>::TN; ++tn) {
+                    const int n = n0 + wn_ * T2<BM, BN>::TN * 32 + tn * 32 + l;
+                    if (n < N) a.stats[(pidx * 2 + 0) * N + n] = 0.f, a.stats[(pidx * 2 + 1) * N + n] = 0.f;
+                }
+        }
+        return;
+    }
     const int kh0 = (ph + g.pad) % s, kw0 = (pw + g.pad) % s;
     const int nA = kh0 < g.KH ? (g.KH - kh0 + s - 1) / s : 0;
     const int nB = kw0 < g.KW ? (g.KW - kw0 + s - 1) / s : 0;
@@ -343,6 +409,11 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
     const bool bn_ok = bn < N;              // N % 4 == 0 on this path
 
     f32x4 ra[AC], rb[BC];
+    const float* __restrict__ nsc = a.nrm.scale;  // virtual operand: see igemm2_fwd_body
+    const float* __restrict__ nsh = a.nrm.shift;
+    const float nslope = a.nrm.slope;
+    f32x4 nsa = ZERO4, nsb = ZERO4;
+    unsigned amask = 0;
     auto load_tile = [&](int kt) {
         {
             const int k = kt * BK2 + kq * 4;
@@ -350,11 +421,17 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
             const int kk = kv ? k : 0;
             const int tt = kk / g.Cr, c = kk - tt * g.Cr;
             const int a = tt / nBd, b = tt - a * nBd;
+            amask = 0;
 #pragma unroll
             for (int i = 0; i < AC; ++i) {
                 const int h = a_h0[i] - a, w = a_w0[i] - b;
                 const bool v = kv && a_ok[i] && h >= 0 && h < g.Hi && w >= 0 && w < g.Wi;
                 ra[i] = v ? *reinterpret_cast<const f32x4*>(a_base[i] + ((long)h * g.Wi + w) * g.Cr + c) : ZERO4;
+                amask |= (v ? 1u : 0u) << i;
+            }
+            if (nsc) {
+                nsa = *reinterpret_cast<const f32x4*>(nsc + c);
+                nsb = *reinterpret_cast<const f32x4*>(nsh + c);
             }
         }
 #pragma unroll
@@ -379,6 +456,11 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
     const int kt_begin = split * ktiles_per_split;
     const int kt_end = min(nk_total, kt_begin + ktiles_per_split);
     auto store_tile = [&](int buf) {
+        if (nsc) {
+#pragma unroll
+            for (int i = 0; i < AC; ++i)
+                if ((amask >> i) & 1u) ra[i] = norm_apply(ra[i], nsa, nsb, nslope);
+        }
 #pragma unroll
         for (int i = 0; i < AC; ++i) *reinterpret_cast<f32x4*>(As + buf * ASZ + (r8 + RPP * i) * LDR + kq * 4) = ra[i];
 #pragma unroll
@@ -417,6 +499,9 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
     const int lane = t & 63, half = lane >> 5, l31 = lane & 31;
     const bool to_slab = slab != nullptr;
     float* out = to_slab ? slab + (long)split * total : Y;
+    if (a.stats && !to_slab)
+        col_stats_store<T::TM, T::TN>(acc, ep.bias, a.stats, ((long)cls * a.stats_gx + bx) * T::WM + wm, m0 + wm * T::TM * 32,
+                                      n0 + wn * T::TN * 32, M, N);
 #pragma unroll
     for (int tm = 0; tm < T::TM; ++tm)
 #pragma unroll
@@ -459,6 +544,8 @@ struct WgArgs {
     int K, kchunk, to_slab, Sp;
     long s_gs, b_gs;
     WOut tab;
+    Norm nrm;      // virtual activation operand ...
+    int nrm_side;  // ... 1: the small-side operand Sm (transposed-conv x), 2: the gathered operand Bg (conv x); 0: none
 };
 
 template <int BM, int BN>
@@ -515,11 +602,27 @@ __device__ __forceinline__ void igemm2_wgrad_body(const WgArgs& a, float* __rest
     const int hw = g.Hs * g.Ws;
 
     f32x4 ra[ACH], rb[BCH];
+    // virtual activation operand (Norm): this thread's four channels are the same for every k, so scale / shift are loaded once;
+    // applied in store_tile (see igemm2_fwd_body)
+    const int nside = a.nrm.scale ? a.nrm_side : 0;
+    const float nslope = a.nrm.slope;
+    f32x4 nsa = ZERO4, nsb = ZERO4;
+    if (nside == 1 && am_ok) {
+        nsa = *reinterpret_cast<const f32x4*>(a.nrm.scale + am);
+        nsb = *reinterpret_cast<const f32x4*>(a.nrm.shift + am);
+    } else if (nside == 2 && bn_ok) {
+        nsa = *reinterpret_cast<const f32x4*>(a.nrm.scale + b_c);
+        nsb = *reinterpret_cast<const f32x4*>(a.nrm.shift + b_c);
+    }
+    unsigned vmask = 0;
     auto load_tile = [&](int k0) {
+        vmask = 0;
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
             const int k = k0 + ak + AKS * i;
-            ra[i] = (k < k_end && am_ok) ? *reinterpret_cast<const f32x4*>(Sm + (long)k * M + am) : ZERO4;
+            const bool v = k < k_end && am_ok;
+            ra[i] = v ? *reinterpret_cast<const f32x4*>(Sm + (long)k * M + am) : ZERO4;
+            if (nside == 1) vmask |= (v ? 1u : 0u) << i;
         }
 #pragma unroll
         for (int i = 0; i < BCH; ++i) {
@@ -531,6 +634,7 @@ __device__ __forceinline__ void igemm2_wgrad_body(const WgArgs& a, float* __rest
             const int h = hs * g.stride - g.pad + b_kh, w = ws * g.stride - g.pad + b_kw;
             const bool v = kv && h >= 0 && h < g.Hb && w >= 0 && w < g.Wb;
             rb[i] = v ? *reinterpret_cast<const f32x4*>(Bg + (((long)img * g.Hb + h) * g.Wb + w) * g.Cb + b_c) : ZERO4;
+            if (nside == 2) vmask |= (v ? 1u : 0u) << i;
         }
     };
 
@@ -541,6 +645,15 @@ __device__ __forceinline__ void igemm2_wgrad_body(const WgArgs& a, float* __rest
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     const int wave = t >> 6, wm = wave / T::WN, wn = wave % T::WN;
     auto store_tile = [&](int buf) {
+        if (nside == 1) {
+#pragma unroll
+            for (int i = 0; i < ACH; ++i)
+                if ((vmask >> i) & 1u) ra[i] = norm_apply(ra[i], nsa, nsb, nslope);
+        } else if (nside == 2) {
+#pragma unroll
+            for (int i = 0; i < BCH; ++i)
+                if ((vmask >> i) & 1u) rb[i] = norm_apply(rb[i], nsa, nsb, nslope);
+        }
 #pragma unroll
         for (int i = 0; i < ACH; ++i) *reinterpret_cast<f32x4*>(As + buf * ASZ + (ak + AKS * i) * T::LDKA + aq * 4) = ra[i];
 #pragma unroll
@@ -706,7 +819,11 @@ int launch_fwd2(const float* X, const float* W, float* Y, const Geom& g, const E
     const int per_split = ceil_div(nk, S);
     S = ceil_div(nk, per_split);
     float* slab = S > 1 ? static_cast<float*>(ws) : nullptr;
-    const FwdArgs a{X, W, Y, g, ep, M, K, per_split, slab};
+    FwdArgs a{X, W, Y, g, ep, M, K, per_split, slab};
+    a.nrm = g_fuse.nrm;
+    // statistics of the result for the BatchNorm that follows (never on a backward pass: those are the paired / collected ones)
+    const bool want_stats = g_fuse.stats && ep.act == MOVAE_ACT_NONE && !g_pair_collect;
+    if (want_stats && S == 1) a.stats = fuse_stats_claim((long)gx * T2<BM, BN>::WM, g.Nn);
     if (g_pair_collect && pair_dgrad_tile<BM, BN>()) {
         PendingDgrad& p = g_pending;
         p.active = true;
@@ -717,7 +834,13 @@ int launch_fwd2(const float* X, const float* W, float* Y, const Geom& g, const E
     }
     hipLaunchKernelGGL((igemm2_fwd<BM, BN>), dim3(gx, gy, S), dim3(256), 0, st, a);
     MOVAE_CHECK_LAUNCH("igemm2_fwd");
-    if (S > 1) return launch_reduce(slab, Y, (long)M * g.Nn, S, g.Nn, ep.bias, ep.act, ep.slope, 0, st);
+    if (S > 1) {
+        if (want_stats && launch_reduce_stats(slab, Y, M, g.Nn, S, nullptr, 0, 0, 0, ep.bias, st)) {
+            MOVAE_CHECK_LAUNCH("splitk_reduce_stats");
+            return MOVAE_OK;
+        }
+        return launch_reduce(slab, Y, (long)M * g.Nn, S, g.Nn, ep.bias, ep.act, ep.slope, 0, st);
+    }
     return MOVAE_OK;
 }
 
@@ -778,7 +901,11 @@ int launch_bwd2(const float* X, const float* W, float* Y, const Geom& g, const E
         movae_set_error("conv bwd-form: workspace too small for %d slabs", Sreal);
         return MOVAE_EINVAL;
     }
-    const BwdArgs a{X, W, Y, g, ep, scls, kps, slab, total};
+    BwdArgs a{X, W, Y, g, ep, scls, kps, slab, total};
+    a.nrm = g_fuse.nrm;
+    a.stats_gx = gx;
+    const bool want_stats = g_fuse.stats && ep.act == MOVAE_ACT_NONE && !g_pair_collect;
+    if (want_stats && Sreal == 1) a.stats = fuse_stats_claim((long)ncls * gx * T2<BM, BN>::WM, g.Nn);
     if (g_pair_collect && pair_dgrad_tile<BM, BN>()) {
         PendingDgrad& p = g_pending;
         p.active = true;
@@ -790,6 +917,10 @@ int launch_bwd2(const float* X, const float* W, float* Y, const Geom& g, const E
     hipLaunchKernelGGL((igemm2_bwd<BM, BN>), dim3(gx, gy, zsum), dim3(256), 0, st, a);
     MOVAE_CHECK_LAUNCH("igemm2_bwd");
     if (Sreal > 1 && !g_bench_main_only) {
+        if (want_stats && launch_reduce_stats(slab, Y, (long)g.Nimg * g.Ho * g.Wo, g.Nn, Sreal, &scls, g.Ho, g.Wo, s, ep.bias, st)) {
+            MOVAE_CHECK_LAUNCH("splitk_reduce_stats");
+            return MOVAE_OK;
+        }
         long gq = (total / 4 + 255) / 256;
         if (gq > 4096) gq = 4096;
         hipLaunchKernelGGL(splitk_reduce_cls, dim3((unsigned)gq), dim3(256), 0, st, slab, Y, total, g.Nn, g.Ho, g.Wo, s, scls, ep.bias,
@@ -825,7 +956,9 @@ int launch_wgrad2(const float* Sm, const float* Bg, float* const* dW, int G, lon
     WOut tab;
     for (int i = 0; i < 8; ++i) tab.p[i] = i < G ? dW[i] : nullptr;
     float* out = slab ? static_cast<float*>(ws) : nullptr;
-    const WgArgs a{Sm, Bg, out, g, K, kchunk, slab ? 1 : 0, Sp, s_gs, b_gs, tab};
+    WgArgs a{Sm, Bg, out, g, K, kchunk, slab ? 1 : 0, Sp, s_gs, b_gs, tab};
+    a.nrm = g_fuse.nrm;  // virtual activation operand: Sm (transposed-conv x) or Bg (conv x), as the entry point says
+    a.nrm_side = g_fuse.nrm_side;
     PendingDgrad& p = g_pending;
     if (p.active && pair_wgrad_tile<BM, BN>() && (long)p.gx * p.gy * p.gz + (long)gx * gy * Sp * G < 0x7fffffffL) {
         p.active = false;

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void vq_embed_part_k(const float* __restrict__
         if (d < D)
             for (int i = lo + slot; i < hi; i += slots) {
                 const long r = (long)(sorted[i] & 0xffffffffu);
-                acc += q[r * D + d] - x[r * D + d];
+                acc += x ? q[r * D + d] - x[r * D + d] : q[r * D + d];  // x == nullptr: a plain segmented sum of q's rows
             }
         sh[t] = acc;
         __syncthreads();
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void vq_embed_final_k(const float* __restrict_
                                                         const float* __restrict__ ge, float* __restrict__ de, int D, float inv_numel) {
     __shared__ float sh[256];
     const int k = blockIdx.x, t = threadIdx.x;
-    const float fe = ge[0] * 2.f * inv_numel;
+    const float fe = ge ? ge[0] * 2.f * inv_numel : 1.f;
     const int b0 = item_base[k], b1 = item_base[k + 1];
     int DL = 1;
     while (DL < D && DL < 256) DL <<= 1;
@@ -288,6 +288,38 @@ template <int D>
 void launch_mfma(const float* x, const float* e, float* q, int64_t* idx, double* part, int* used, int rows, int K, int nblk,
                  hipStream_t st) {
     hipLaunchKernelGGL(vq_nearest_mfma<D>, dim3(nblk), dim3(256), 0, st, x, e, q, idx, part, used, rows, K);
+}
+
+// de[k] = f * sum_{rows r with idx[r] == k} (q[r] - x[r])   (x may be null: plain sum of q's rows; ge null: f = 1)
+static int segmented_code_sum(const float* x, const float* q, const int64_t* idx, const float* ge, float* de, int rows, int k, int d,
+                              void* ws, hipStream_t st) {
+    const long total = (long)rows * d;
+    char* base = static_cast<char*>(ws);
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(base);
+    unsigned long long* sorted = keys + rows;
+    const int max_items = rows / VQ_CHUNK + k + 1;
+    float* part = reinterpret_cast<float*>(sorted + rows);
+    int* seg_lo = reinterpret_cast<int*>(part + (size_t)max_items * d);
+    int* item_base = seg_lo + k + 2;
+    void* temp = reinterpret_cast<void*>(item_base + k + 2);
+    temp = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(temp) + 255) & ~(uintptr_t)255);
+    size_t temp_bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, keys, sorted, rows, 0, 64);
+    hipLaunchKernelGGL(vq_keys_k, dim3(ceil_div(rows, 256)), dim3(256), 0, st, idx, keys, rows);
+    MOVAE_CHECK_LAUNCH("vq_keys");
+    int kbits = 1;
+    while ((1 << kbits) < k) ++kbits;
+    if (hipcub::DeviceRadixSort::SortKeys(temp, temp_bytes, keys, sorted, rows, 0, 32 + kbits, st) != hipSuccess) {
+        movae_set_error("segmented_code_sum: radix sort failed");
+        return MOVAE_ELAUNCH;
+    }
+    hipLaunchKernelGGL(vq_segments_k, dim3(1), dim3(1024), 0, st, sorted, rows, k, seg_lo, item_base);
+    MOVAE_CHECK_LAUNCH("vq_segments");
+    hipLaunchKernelGGL(vq_embed_part_k, dim3(max_items), dim3(256), 0, st, x, q, sorted, seg_lo, item_base, part, k, d);
+    MOVAE_CHECK_LAUNCH("vq_embed_part");
+    hipLaunchKernelGGL(vq_embed_final_k, dim3(k), dim3(256), 0, st, part, item_base, ge, de, d, 1.f / (float)total);
+    MOVAE_CHECK_LAUNCH("vq_embed_final");
+    return MOVAE_OK;
 }
 
 }  // namespace
@@ -349,31 +381,7 @@ int movae_vq_bwd(const float* x, const float* q, const int64_t* idx, const float
     }
     if (de && ge) {
         MOVAE_CHECK_ARG(ws && ws_bytes + MOVAE_WS_HEADER_BYTES >= movae_vq_bwd_ws_bytes(rows, k, d), "movae_vq_bwd: workspace too small");
-        char* base = static_cast<char*>(ws);
-        unsigned long long* keys = reinterpret_cast<unsigned long long*>(base);
-        unsigned long long* sorted = keys + rows;
-        const int max_items = rows / VQ_CHUNK + k + 1;
-        float* part = reinterpret_cast<float*>(sorted + rows);
-        int* seg_lo = reinterpret_cast<int*>(part + (size_t)max_items * d);
-        int* item_base = seg_lo + k + 2;
-        void* temp = reinterpret_cast<void*>(item_base + k + 2);
-        temp = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(temp) + 255) & ~(uintptr_t)255);
-        size_t temp_bytes = 0;
-        (void)hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, keys, sorted, rows, 0, 64);
-        hipLaunchKernelGGL(vq_keys_k, dim3(ceil_div(rows, 256)), dim3(256), 0, st, idx, keys, rows);
-        MOVAE_CHECK_LAUNCH("vq_keys");
-        int kbits = 1;
-        while ((1 << kbits) < k) ++kbits;
-        if (hipcub::DeviceRadixSort::SortKeys(temp, temp_bytes, keys, sorted, rows, 0, 32 + kbits, st) != hipSuccess) {
-            movae_set_error("movae_vq_bwd: radix sort failed");
-            return MOVAE_ELAUNCH;
-        }
-        hipLaunchKernelGGL(vq_segments_k, dim3(1), dim3(1024), 0, st, sorted, rows, k, seg_lo, item_base);
-        MOVAE_CHECK_LAUNCH("vq_segments");
-        hipLaunchKernelGGL(vq_embed_part_k, dim3(max_items), dim3(256), 0, st, x, q, sorted, seg_lo, item_base, part, k, d);
-        MOVAE_CHECK_LAUNCH("vq_embed_part");
-        hipLaunchKernelGGL(vq_embed_final_k, dim3(k), dim3(256), 0, st, part, item_base, ge, de, d, 1.f / (float)total);
-        MOVAE_CHECK_LAUNCH("vq_embed_final");
+        if (int rc = segmented_code_sum(x, q, idx, ge, de, rows, k, d, ws, st)) return rc;
     } else if (de) {
         if (hipMemsetAsync(de, 0, (size_t)k * d * sizeof(float), st) != hipSuccess) {
             movae_set_error("movae_vq_bwd: memset failed");
@@ -381,6 +389,14 @@ int movae_vq_bwd(const float* x, const float* q, const int64_t* idx, const float
         }
     }
     return MOVAE_OK;
+}
+
+int movae_embedding_bwd(const float* dy, const int64_t* idx, float* dweight, int rows, int k, int d, void* ws, size_t ws_bytes,
+                        movae_stream_t stream) {
+    MOVAE_WS_SCRATCH(ws, ws_bytes);
+    MOVAE_CHECK_ARG(dy && idx && dweight && rows > 0 && k > 0 && d > 0, "movae_embedding_bwd: bad argument");
+    MOVAE_CHECK_ARG(ws && ws_bytes + MOVAE_WS_HEADER_BYTES >= movae_vq_bwd_ws_bytes(rows, k, d), "movae_embedding_bwd: workspace too small");
+    return segmented_code_sum(nullptr, dy, idx, nullptr, dweight, rows, k, d, ws, (hipStream_t)stream);
 }
 
 }  // extern "C"

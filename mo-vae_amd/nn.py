@@ -6,10 +6,15 @@ Initialisation replays torch.nn's reset_parameters on a temporary contiguous ten
 the reference constructors create their layers, so a given seed yields bit-identical parameters
 (models/vae.py:117-173 etc.), then stores conv weights channels_last.
 """
+import os
+
 import torch
 import torch.nn as tnn
 
 from . import ops
+
+#: MOVAE_FUSE_BN=0: every training-mode BatchNorm runs as its own statistics + apply passes (the pre-fusion path)
+FUSE_BN = os.environ.get("MOVAE_FUSE_BN", "1") != "0"
 
 LRELU_SLOPE = 0.01  # nn.LeakyReLU() default used everywhere in the reference
 
@@ -27,8 +32,11 @@ class Conv2d(tnn.Module):
         self.stride, self.padding, self.kernel_size = stride, padding, k
         self.in_channels, self.out_channels = cin, cout
 
-    def forward(self, x, act=None, feeds_batchnorm=False):
-        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, act, LRELU_SLOPE, feeds_batchnorm)
+    def forward(self, x, act=None, feeds_batchnorm=False, fusion=None):
+        if isinstance(x, ops.LazyBN):  # the producer's BatchNorm + activation is applied while this conv loads its input
+            fusion = x.fusion(want_stats=fusion is not None and fusion.want_stats) if fusion is None or fusion.in_scale is None else fusion
+            x = x.y
+        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, act, LRELU_SLOPE, feeds_batchnorm, fusion)
 
     def extra_repr(self):
         return f"{self.in_channels}, {self.out_channels}, k={self.kernel_size}, s={self.stride}, p={self.padding}"
@@ -43,9 +51,12 @@ class ConvTranspose2d(tnn.Module):
         self.stride, self.padding, self.output_padding, self.kernel_size = stride, padding, output_padding, k
         self.in_channels, self.out_channels = cin, cout
 
-    def forward(self, x, act=None, feeds_batchnorm=False):
+    def forward(self, x, act=None, feeds_batchnorm=False, fusion=None):
+        if isinstance(x, ops.LazyBN):
+            fusion = x.fusion(want_stats=fusion is not None and fusion.want_stats) if fusion is None or fusion.in_scale is None else fusion
+            x = x.y
         return ops.conv_transpose2d(x, self.weight, self.bias, self.stride, self.padding, self.output_padding, act, LRELU_SLOPE,
-                                    feeds_batchnorm)
+                                    feeds_batchnorm, fusion)
 
     def extra_repr(self):
         return (f"{self.in_channels}, {self.out_channels}, k={self.kernel_size}, s={self.stride}, p={self.padding}, "
@@ -83,6 +94,11 @@ class BatchNorm2d(tnn.Module):
         # num_batches_tracked += 1 happens inside the statistics kernel (training mode only)
         return ops.batch_norm_act(y, self.weight, self.bias, self.running_mean, self.running_var, self.training, self.eps,
                                   self.momentum, act, LRELU_SLOPE, self.num_batches_tracked)
+
+    def forward_lazy(self, y, act, fusion):
+        """Training mode, fused: statistics from the producer conv's epilogue (fusion), output left unmaterialised (ops.LazyBN)."""
+        return ops.batch_norm_lazy(y, self.weight, self.bias, self.running_mean, self.running_var, self.num_batches_tracked, self.eps,
+                                   self.momentum, act, LRELU_SLOPE, fusion)
 
     def extra_repr(self):
         return f"{self.num_features}"
@@ -123,6 +139,9 @@ class Stack(tnn.Sequential):
     conv -> [batchnorm] -> activation runs into the conv / batch-norm kernels' epilogues."""
 
     def forward(self, x):
+        """x: an NHWC tensor or an ops.LazyBN (the unmaterialised output of a fused BatchNorm); may return either -- a LazyBN
+        leaves a Stack only when its last module is a fused BatchNorm (+ activation), and is handed on to Stacks and convs
+        as it is; every other module receives the materialised tensor."""
         mods = list(self)
         i, n = 0, len(mods)
         while i < n:
@@ -134,7 +153,15 @@ class Stack(tnn.Sequential):
                 nxt = mods[i + 1] if i + 1 < n else None
                 if isinstance(nxt, BatchNorm2d):
                     act = mods[i + 2] if i + 2 < n and isinstance(mods[i + 2], _Act) else None
-                    x = nxt(m(x, None, nxt.training), act.kind if act is not None else None)
+                    kind = act.kind if act is not None else None
+                    if FUSE_BN and nxt.training and kind in (None, "lrelu", "relu") and m.out_channels % 4 == 0:
+                        fusion = ops.ConvFusion(want_stats=True)
+                        if isinstance(x, ops.LazyBN):
+                            fusion.in_scale, fusion.in_shift, fusion.in_slope = x.scale, x.shift, x.slope
+                            x = x.y
+                        x = nxt.forward_lazy(m(x, None, True, fusion), kind, fusion)
+                    else:
+                        x = nxt(m(x, None, nxt.training), kind)
                     i += 3 if act is not None else 2
                 elif isinstance(nxt, _Act):
                     x = m(x, nxt.kind)
@@ -143,7 +170,7 @@ class Stack(tnn.Sequential):
                     x = m(x)
                     i += 1
             else:
-                x = m(x)
+                x = m(ops.materialize(x))
                 i += 1
         return x
 

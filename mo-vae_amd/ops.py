@@ -235,11 +235,47 @@ def join_wgrad():
         L.DEFER.join()
 
 
+class ConvFusion:
+    """What a conv call is asked to fuse of its neighbouring BatchNorms (include/movae.h: movae_fuse_t).
+    in_*: the input is the RAW output y of a producer conv whose BatchNorm + activation this conv applies while loading,
+    x = leaky_relu(in_scale[c] * y + in_shift[c], in_slope).  want_stats: the epilogue (or split-K reduce) also emits the
+    per-channel partial sums of this conv's own output for the BatchNorm that follows it: `stats` / `parts` on return."""
+    __slots__ = ("in_scale", "in_shift", "in_slope", "want_stats", "stats", "parts")
+
+    def __init__(self, in_scale=None, in_shift=None, in_slope=1.0, want_stats=False):
+        self.in_scale, self.in_shift, self.in_slope, self.want_stats = in_scale, in_shift, float(in_slope), want_stats
+        self.stats, self.parts = None, 0
+
+
+#: (entry point, geometry) for which the library answered "unsupported" to a fused input transform: not asked again
+_NO_FUSE = set()
+
+
+def _fuse_struct(in_norm, stats=None):
+    f = L.MovaeFuse()
+    if in_norm is not None:
+        f.in_scale, f.in_shift, f.in_slope = in_norm[0].data_ptr(), in_norm[1].data_ptr(), float(in_norm[2])
+    if stats is not None:
+        f.stats, f.stats_cap = stats.data_ptr(), stats.numel()
+    return f
+
+
+def scale_shift_act(y, scale, shift, slope):
+    """leaky_relu(scale[c] * y + shift[c], slope) as a real tensor (no tape: callers wrap it)."""
+    y = _c(y)
+    c = y.shape[-1]
+    out = torch.empty_like(y)
+    _call("movae_scale_shift_act", y.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.data_ptr(), y.numel() // c, c, float(slope), _st(y))
+    return out
+
+
 class Conv(Function):
-    """conv2d / conv_transpose2d / linear (+bias, + fused activation)."""
+    """conv2d / conv_transpose2d / linear (+bias, + fused activation).  `fusion` (ConvFusion or None): BatchNorm fused into the
+    conv -- the producer's normalisation + activation applied to the input while it is loaded, and / or the statistics of the
+    output emitted for the BatchNorm that follows."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, out_pad, transposed, act, slope, bias_grad_is_zero=False):
+    def forward(ctx, x, w, b, stride, pad, out_pad, transposed, act, slope, bias_grad_is_zero=False, fusion=None):
         L.require_gpu(x)
         x = _c(x)
         wm = weight_mem(w)
@@ -256,17 +292,74 @@ class Conv(Function):
             fn = "movae_conv2d_fwd"
         y = torch.empty((n, ho, wo, co), dtype=x.dtype, device=x.device)
         wsp, wsb = _ws(x)
-        _call(fn, x.data_ptr(), wm.data_ptr(), L.ptr(b), y.data_ptr(), n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad,
-              L.ACT[act], float(slope), wsp, wsb, _st(x))
-        ctx.geom = (n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad)
+        geom = (n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad)
+        in_norm = None
+        if fusion is not None and fusion.in_scale is not None:
+            in_norm = (fusion.in_scale, fusion.in_shift, fusion.in_slope)
+        stats = None
+        if fusion is not None and fusion.want_stats and not L.ACT[act]:
+            # room for the finest partial granularity of any producer (a pair per 32-row wave tile; per 8 rows in the reduce)
+            stats = torch.empty((n * ho * wo // 8 + 64) * 2 * co, dtype=torch.float32, device=x.device)
+        if in_norm is not None and (fn, geom) in _NO_FUSE:
+            x, in_norm = scale_shift_act(x, *in_norm), None
+        if in_norm is None and stats is None:
+            _call(fn, x.data_ptr(), wm.data_ptr(), L.ptr(b), y.data_ptr(), *geom, L.ACT[act], float(slope), wsp, wsb, _st(x))
+        else:
+            f = _fuse_struct(in_norm, stats)
+            try:
+                _call(fn + "_f", x.data_ptr(), wm.data_ptr(), L.ptr(b), y.data_ptr(), *geom, L.ACT[act], float(slope), wsp, wsb, _st(x),
+                      C.byref(f))
+            except L.Unsupported:  # nothing was launched: materialise the normalised input, then the same call without it
+                if in_norm is None:
+                    raise
+                _NO_FUSE.add((fn, geom))
+                x, in_norm = scale_shift_act(x, *in_norm), None
+                f = _fuse_struct(None, stats)
+                _call(fn + "_f", x.data_ptr(), wm.data_ptr(), L.ptr(b), y.data_ptr(), *geom, L.ACT[act], float(slope), wsp, wsb, _st(x),
+                      C.byref(f))
+            if fusion is not None:
+                fusion.stats, fusion.parts = stats, int(f.stats_parts)
+        ctx.geom = geom
         ctx.transposed, ctx.act, ctx.slope, ctx.has_bias = transposed, act, slope, b is not None
         ctx.bias_grad_is_zero = bias_grad_is_zero
-        ctx.save_for_backward(x, w, y if L.ACT[act] else None, b)
+        ctx.in_slope = in_norm[2] if in_norm is not None else None
+        ctx.save_for_backward(x, w, y if L.ACT[act] else None, b, *(in_norm[:2] if in_norm is not None else ()))
         return y
 
     @staticmethod
+    def _saved(ctx):
+        """(x, w, y, b, in_norm): in_norm = (scale, shift, slope) when x is the raw output of a BatchNorm-fused producer."""
+        sv = ctx.saved_tensors
+        in_norm = (sv[4], sv[5], ctx.in_slope) if ctx.in_slope is not None else None
+        return sv[0], sv[1], sv[2], sv[3], in_norm
+
+    @staticmethod
+    def _wgrad_call(name, in_norm, geom, args):
+        """One weight-gradient (or paired dgrad + wgrad) call; with a virtual activation operand the *_f form, falling back
+        to a materialised activation where the dispatched kernel cannot apply the transform.  args: (head, x_index, tail)."""
+        head, xi, tail = args
+        if in_norm is not None and (name, geom) in _NO_FUSE:
+            head = list(head)
+            head[xi] = scale_shift_act(head[xi], *in_norm)
+            in_norm = None
+        ptrs = lambda h: [t.data_ptr() if isinstance(t, torch.Tensor) else t for t in h]  # noqa: E731
+        if in_norm is None:
+            _call(name, *ptrs(head), *tail)
+            return head[xi]
+        f = _fuse_struct(in_norm)
+        try:
+            _call(name + "_f", *ptrs(head), *tail, C.byref(f))
+            return head[xi]
+        except L.Unsupported:
+            _NO_FUSE.add((name, geom))
+            head = list(head)
+            head[xi] = scale_shift_act(head[xi], *in_norm)
+            _call(name, *ptrs(head), *tail)
+            return head[xi]
+
+    @staticmethod
     def backward(ctx, dy):
-        x, w, y, b = ctx.saved_tensors
+        x, w, y, b, in_norm = Conv._saved(ctx)
         dy = _c(dy)
         n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad = ctx.geom
         st = _st(dy)
@@ -316,20 +409,20 @@ class Conv(Function):
                     db = _sink_zeros(b, (co,))
                 else:
                     db = db_k = _sink(b, (co,))
+            dbp = (C.c_void_p * 1)(db_k.data_ptr()) if db_k is not None else None
+            tail = (n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, 0, wsp, wsb, st)
             if pair:
-                _call(pre + "dgrad_wgrad_grouped", 1, dy.data_ptr(), wm.data_ptr(), x.data_ptr(), dx.data_ptr(),
-                      (C.c_void_p * 1)(dwm.data_ptr()), (C.c_void_p * 1)(db_k.data_ptr()) if db_k is not None else None, n, hi, wi, ci,
-                      ho, wo, co, kh, kw, stride, pad, 0, wsp, wsb, st)
+                x = Conv._wgrad_call(pre + "dgrad_wgrad_grouped", in_norm, ctx.geom,
+                                     ((1, dy, wm, x, dx, (C.c_void_p * 1)(dwm.data_ptr()), dbp), 3, tail))
             else:
-                _call(pre + "wgrad", dy.data_ptr(), x.data_ptr(), dwm.data_ptr(), L.ptr(db_k), n, hi, wi, ci, ho, wo, co, kh, kw,
-                      stride, pad, 0, wsp, wsb, st)
+                x = Conv._wgrad_call(pre + "wgrad_grouped", in_norm, ctx.geom, ((1, dy, x, (C.c_void_p * 1)(dwm.data_ptr()), dbp), 2, tail))
             dw = dwm.permute(0, 3, 1, 2)
         if fork and defer is not None:
             defer.keep.append((dy, x, dwm, db))  # joined once, by wgrad_side_stream
             defer.used = True
         elif fork:
             main.wait_stream(side)
-        return dx, dw, db, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None
 
     @staticmethod
     def backward_batched(ctx, G, dy):
@@ -337,7 +430,7 @@ class Conv(Function):
         G tensors).  dgrad runs as ONE launch over G*n images -- the pull-back is linear and per-sample, and the deep
         layers' grids are far too small to fill the chip one cotangent at a time; wgrad is one grouped launch (each
         group reduces over its own pixels, x is shared) writing straight into the groups' Jacobian rows."""
-        x, w, y, b = ctx.saved_tensors
+        x, w, y, b, in_norm = Conv._saved(ctx)
         dy = _stacked(dy, G)
         n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad = ctx.geom
         st = _st(dy)
@@ -383,17 +476,17 @@ class Conv(Function):
                 dbp = arr(*[t.data_ptr() for t in db]) if (need_b and not ctx.bias_grad_is_zero) else None
             # one grouped launch: blockIdx.z = group * splits + split, x is read by every group, dy by its own; with the
             # input gradient wanted too, dgrad and wgrad share the launch (igemm2_pair)
+            tail = (n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, 0, wsp, wsb, st)
             if pair:
-                _call(pre + "dgrad_wgrad_grouped", G, dy.data_ptr(), wm.data_ptr(), x.data_ptr(), dx.data_ptr(),
-                      arr(*[t.data_ptr() for t in dwm]), dbp, n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, 0, wsp, wsb, st)
+                x = Conv._wgrad_call(pre + "dgrad_wgrad_grouped", in_norm, ctx.geom,
+                                     ((G, dy, wm, x, dx, arr(*[t.data_ptr() for t in dwm]), dbp), 3, tail))
             else:
-                _call(pre + "wgrad_grouped", G, dy.data_ptr(), x.data_ptr(), arr(*[t.data_ptr() for t in dwm]), dbp, n, hi, wi, ci,
-                      ho, wo, co, kh, kw, stride, pad, 0, wsp, wsb, st)
+                x = Conv._wgrad_call(pre + "wgrad_grouped", in_norm, ctx.geom, ((G, dy, x, arr(*[t.data_ptr() for t in dwm]), dbp), 2, tail))
             dw = [t.permute(0, 3, 1, 2) for t in dwm]
             if defer is not None:
                 defer.keep.append((dy, x, dwm, db))
                 defer.used = True
-        return dx, dw, db, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None
 
 
 def _fuse_bias_grad(ctx, dy, y, co):
@@ -402,12 +495,12 @@ def _fuse_bias_grad(ctx, dy, y, co):
             dy.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0)
 
 
-def conv2d(x, w, b=None, stride=1, pad=0, act=None, slope=0.01, bias_grad_is_zero=False):
-    return Conv.apply(x, w, b, stride, pad, 0, False, act, slope, bias_grad_is_zero)
+def conv2d(x, w, b=None, stride=1, pad=0, act=None, slope=0.01, bias_grad_is_zero=False, fusion=None):
+    return Conv.apply(x, w, b, stride, pad, 0, False, act, slope, bias_grad_is_zero, fusion)
 
 
-def conv_transpose2d(x, w, b=None, stride=1, pad=0, out_pad=0, act=None, slope=0.01, bias_grad_is_zero=False):
-    return Conv.apply(x, w, b, stride, pad, out_pad, True, act, slope, bias_grad_is_zero)
+def conv_transpose2d(x, w, b=None, stride=1, pad=0, out_pad=0, act=None, slope=0.01, bias_grad_is_zero=False, fusion=None):
+    return Conv.apply(x, w, b, stride, pad, out_pad, True, act, slope, bias_grad_is_zero, fusion)
 
 
 def linear(x, w, b=None, act=None, slope=0.01):
@@ -472,6 +565,118 @@ class BatchNormAct(Function):
               rstd.data_ptr(), dy.data_ptr(), arr(*[t.data_ptr() for t in dgs]), arr(*[t.data_ptr() for t in dbs]), rows, c,
               L.ACT[ctx.act], float(ctx.slope), 0, wsp, wsb, _st(y))
         return dy, dgs, dbs, None, None, None, None, None, None, None, None
+
+
+# ---- BatchNorm fused into its neighbours ---------------------------------------------------------------
+class LazyBN:
+    """The output of a training-mode BatchNorm (+ LeakyReLU / ReLU) that has NOT been written to memory: `y` is the producer
+    conv's raw output (as a node of the tape whose gradient is the gradient w.r.t. the normalised activation), scale / shift the
+    folded per-channel map.  Convolutions consume it directly (ops.conv2d(..., fusion=...) applies the map while loading);
+    anything else calls materialize().  Deliberately NOT a tensor: a consumer that does not know about it fails loudly."""
+    __slots__ = ("y", "scale", "shift", "slope")
+
+    def __init__(self, y, scale, shift, slope):
+        self.y, self.scale, self.shift, self.slope = y, scale, shift, float(slope)
+
+    def fusion(self, want_stats=False):
+        return ConvFusion(self.scale, self.shift, self.slope, want_stats)
+
+    def materialize(self):
+        return ScaleShiftAct.apply(self.y, self.scale, self.shift, self.slope)
+
+
+def materialize(x):
+    return x.materialize() if isinstance(x, LazyBN) else x
+
+
+class ScaleShiftAct(Function):
+    """LazyBN -> real tensor.  `y` stands for the normalised activation on the tape, so the backward is the identity."""
+
+    @staticmethod
+    def forward(ctx, y, scale, shift, slope):
+        return scale_shift_act(y, scale, shift, slope)
+
+    @staticmethod
+    def backward(ctx, dout):
+        return dout, None, None, None
+
+    @staticmethod
+    def backward_batched(ctx, G, dout):
+        return dout, None, None, None
+
+
+_ACT_OF_SLOPE = {1.0: None, 0.0: "relu"}
+
+
+class BatchNormLazy(Function):
+    """Training-mode BatchNorm2d (+ LeakyReLU / ReLU) whose statistics come from the producer conv's partial sums
+    (ConvFusion.stats) -- or from one stand-alone pass over y when that kernel could not emit them -- and whose output is
+    not materialised: returns (y as a new tape node, scale, shift).  Backward: the ordinary BatchNorm backward kernels
+    (movae_bn_act_bwd) on the saved raw y."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum, slope, stats, parts):
+        L.require_gpu(y)
+        c = y.shape[-1]
+        rows = y.numel() // c
+        st = _st(y)
+        if not parts:
+            stats = torch.empty(1025 * 2 * c, dtype=torch.float32, device=y.device)  # movae_bn_stats: at most 1024 partials
+            pout = C.c_int(0)
+            _call("movae_bn_stats", y.data_ptr(), rows, c, stats.data_ptr(), stats.numel(), C.byref(pout), st)
+            parts = pout.value
+        mean = torch.empty(c, dtype=y.dtype, device=y.device)
+        rstd, scale, shift = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
+        _call("movae_bn_finalize", stats.data_ptr(), int(parts), rows, c, gamma.data_ptr(), beta.data_ptr(), float(eps), float(momentum),
+              mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), L.ptr(running_mean), L.ptr(running_var),
+              L.ptr(num_batches_tracked), st)
+        ctx.act, ctx.slope = ("lrelu" if slope not in _ACT_OF_SLOPE else _ACT_OF_SLOPE[slope]), slope
+        ctx.save_for_backward(y, gamma, beta, mean, rstd)
+        ctx.mark_non_differentiable(scale, shift)
+        return y.view_as(y), scale, shift
+
+    @staticmethod
+    def backward(ctx, dout, _ds, _dh):
+        y, gamma, beta, mean, rstd = ctx.saved_tensors
+        dout = _c(dout)
+        c = y.shape[-1]
+        rows = y.numel() // c
+        dy = torch.empty_like(y)
+        dg = _sink(gamma, gamma.shape)
+        db = _sink(beta, beta.shape)
+        wsp, wsb = _ws(y)
+        _call("movae_bn_act_bwd", dout.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
+              rstd.data_ptr(), dy.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, c, L.ACT[ctx.act], float(ctx.slope), 0,
+              wsp, wsb, _st(y))
+        return dy, dg, db, None, None, None, None, None, None, None, None
+
+    @staticmethod
+    def backward_batched(ctx, G, dout, _ds=None, _dh=None):
+        y, gamma, beta, mean, rstd = ctx.saved_tensors
+        dout = _stacked(dout, G)
+        c = y.shape[-1]
+        rows = y.numel() // c
+        dy = torch.empty_like(dout)
+        wsp, wsb = _ws(y)
+        dgs = [_sink_row(g, gamma, gamma.shape) for g in range(G)]
+        dbs = [_sink_row(g, beta, beta.shape) for g in range(G)]
+        arr = C.c_void_p * G
+        _call("movae_bn_act_bwd_grouped", G, dout.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
+              rstd.data_ptr(), dy.data_ptr(), arr(*[t.data_ptr() for t in dgs]), arr(*[t.data_ptr() for t in dbs]), rows, c,
+              L.ACT[ctx.act], float(ctx.slope), 0, wsp, wsb, _st(y))
+        return dy, dgs, dbs, None, None, None, None, None, None, None, None
+
+
+def batch_norm_lazy(y, gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum, act, slope, fusion):
+    """-> LazyBN.  act in (None, 'lrelu', 'relu'); fusion: the ConvFusion the producer conv was called with (its statistics)."""
+    sl = 1.0 if act is None else (0.0 if act == "relu" else float(slope))
+    stats, parts = (fusion.stats, fusion.parts) if fusion is not None else (None, 0)
+    try:
+        yv, scale, shift = BatchNormLazy.apply(y, gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum, sl, stats,
+                                               parts)
+    except L.Unsupported:  # no partial sums from the producer and a shape the stand-alone statistics pass does not take
+        return batch_norm_act(y, gamma, beta, running_mean, running_var, True, eps, momentum, act, slope, num_batches_tracked)
+    return LazyBN(yv, scale, shift, sl)
 
 
 def batch_norm_act(y, gamma, beta, running_mean, running_var, training, eps=1e-5, momentum=0.1, act=None, slope=0.01,
@@ -806,3 +1011,105 @@ class VectorQuantize(Function):
 
 def vector_quantize(x, codebook):
     return VectorQuantize.apply(x, codebook)
+
+
+# ---------------------------------------------------------------------------------------------
+# PixelCNN prior (models/pixelcnn_prior.py)
+class EmbeddingLookup(Function):
+    """nn.Embedding forward over a [B, H, W] int64 code grid -> NHWC activations [B, H, W, D] (pixelcnn_prior.py:306,371); the
+    weight gradient is a fixed-order segmented sum over the sorted codes (no float atomics)."""
+
+    @staticmethod
+    def forward(ctx, idx, weight):
+        L.require_gpu(weight)
+        idx = idx.contiguous()
+        w = _c(weight)
+        k, d = w.shape
+        y = torch.empty(tuple(idx.shape) + (d,), dtype=w.dtype, device=w.device)
+        _call("movae_embedding_fwd", w.data_ptr(), idx.data_ptr(), y.data_ptr(), idx.numel(), k, d, _st(w))
+        ctx.save_for_backward(idx)
+        ctx.kd = (k, d)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        k, d = ctx.kd
+        dy = _c(dy)
+        dw = torch.empty((k, d), dtype=dy.dtype, device=dy.device)
+        wsp, wsb = _ws(dy)
+        _call("movae_embedding_bwd", dy.data_ptr(), idx.data_ptr(), dw.data_ptr(), idx.numel(), k, d, wsp, wsb, _st(dy))
+        return None, dw
+
+
+def embedding(idx, weight):
+    return EmbeddingLookup.apply(idx, weight)
+
+
+class GatedResidual(Function):
+    """out = res + gate * feat (gate / feat already activated by the conv epilogues; pixelcnn_prior.py:85-90)."""
+
+    @staticmethod
+    def forward(ctx, res, gate, feat):
+        L.require_gpu(res)
+        res, gate, feat = _c(res), _c(gate), _c(feat)
+        out = torch.empty_like(res)
+        _call("movae_gated_residual_fwd", res.data_ptr(), gate.data_ptr(), feat.data_ptr(), out.data_ptr(), res.numel(), _st(res))
+        ctx.save_for_backward(gate, feat)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        gate, feat = ctx.saved_tensors
+        dout = _c(dout)
+        dg, df = torch.empty_like(dout), torch.empty_like(dout)
+        _call("movae_gated_residual_bwd", dout.data_ptr(), gate.data_ptr(), feat.data_ptr(), dg.data_ptr(), df.data_ptr(), dout.numel(),
+              _st(dout))
+        return dout, dg, df
+
+
+def gated_residual(res, gate, feat):
+    assert res.shape == gate.shape == feat.shape and res.numel() % 4 == 0
+    return GatedResidual.apply(res, gate, feat)
+
+
+@torch.no_grad()
+def mask_weight_(weight, mask):
+    """MaskedConv2d's `self.weight.data *= self.mask` (pixelcnn_prior.py:52): in place, outside the tape.  Both tensors share one
+    dense memory layout (channels_last), so the flat product is the element-wise one."""
+    L.require_gpu(weight)
+    assert weight.shape == mask.shape and weight.stride() == mask.stride(), "mask must share the weight's memory layout"
+    _call("movae_mul", weight.data_ptr(), mask.data_ptr(), weight.data_ptr(), weight.numel(), _st(weight))
+    return weight
+
+
+class CrossEntropy(Function):
+    """F.cross_entropy(logits[rows, K], target[rows]) with mean reduction (main.py:1003-1006; pixelcnn_prior.py:392-395)."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        L.require_gpu(logits)
+        logits, target = _c(logits), target.contiguous()
+        rows, k = logits.shape
+        assert target.numel() == rows and target.dtype == torch.int64
+        loss = torch.empty((), dtype=logits.dtype, device=logits.device)
+        lse = torch.empty(rows, dtype=logits.dtype, device=logits.device)
+        wsp, wsb = _ws(logits)
+        _call("movae_cross_entropy_fwd", logits.data_ptr(), target.data_ptr(), loss.data_ptr(), lse.data_ptr(), rows, k, wsp, wsb,
+              _st(logits))
+        ctx.save_for_backward(logits, target, lse)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, lse = ctx.saved_tensors
+        g = _c(g)
+        rows, k = logits.shape
+        dl = torch.empty_like(logits)
+        _call("movae_cross_entropy_bwd", logits.data_ptr(), target.data_ptr(), lse.data_ptr(), g.data_ptr(), dl.data_ptr(), rows, k,
+              _st(logits))
+        return dl, None
+
+
+def cross_entropy(logits, target):
+    return CrossEntropy.apply(logits, target)

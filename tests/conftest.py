@@ -11,6 +11,10 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# the CPU oracle runs small convolutions: PyTorch's default of one thread per visible core (128 on a GPU box, whose CPU
+# share is 16) oversubscribes them and is ~10x slower than 16 threads
+torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -377,6 +377,57 @@ def edge_variants_fixture():
 
 
 # --------------------------------------------------------------------------------------
+def pixelcnn_fixture():
+    """models/pixelcnn_prior.py (imports torch only): PixelCNN and HierarchicalPixelCNN at tiny sizes -- init state_dict (incl. the
+    mask buffers), logits, cross-entropy (main.py:1003-1006 / loss_function), every parameter's gradient, and the parameters
+    after one step of the prior loop main.py:995-1011 (clip_grad_norm_ 1.0, Adam lr 3e-4) followed by a second forward (which
+    re-applies the in-place weight mask)."""
+    import torch.nn.functional as F
+    from models.pixelcnn_prior import HierarchicalPixelCNN, PixelCNN
+
+    out = {}
+    K, D, hid, L, seed = 16, 8, 16, 2, 7
+    g = torch.Generator().manual_seed(70)
+    z = torch.randint(0, K, (3, 8, 8), generator=g)
+    z_top = torch.randint(0, K, (2, 4, 4), generator=g)
+    z_bot = torch.randint(0, K, (2, 8, 8), generator=g)
+    out["meta"] = np.array([f"num_embeddings={K}", f"embedding_dim={D}", f"hidden_channels={hid}", f"num_layers={L}", f"seed={seed}",
+                            "lr=0.0003"])
+    out["z"], out["z_top"], out["z_bottom"] = _np(z), _np(z_top), _np(z_bot)
+    for tag, hier in (("flat", False), ("hier", True)):
+        torch.manual_seed(seed)
+        net = (HierarchicalPixelCNN(K, D, hid, L) if hier else PixelCNN(K, D, hid, L)).train()
+        for k, v in net.state_dict().items():
+            out[f"{tag}.sd0.{k}"] = _np(v)
+        opt = torch.optim.Adam(net.parameters(), lr=3e-4, weight_decay=0.0)
+        opt.zero_grad()
+        if hier:
+            o = net(z_top, z_bot)
+            ld = net.loss_function(z_top, z_bot)
+            out[f"{tag}.logits_top"], out[f"{tag}.logits_bottom"] = _np(o["logits_top"]), _np(o["logits_bottom"])
+        else:
+            logits = net(z)
+            ld = {"total_loss": F.cross_entropy(logits.permute(0, 2, 3, 1).reshape(-1, K), z.reshape(-1))}
+            out[f"{tag}.logits"] = _np(logits)
+        for k, v in ld.items():
+            out[f"{tag}.loss.{k}"] = _np(v)
+        ld["total_loss"].backward()
+        for n, p in net.named_parameters():
+            out[f"{tag}.g.{n}"] = _np(p.grad if p.grad is not None else torch.zeros_like(p))
+        out[f"{tag}.gnorm"] = _np(torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0))
+        opt.step()
+        if hier:
+            ld2 = net.loss_function(z_top, z_bot)
+        else:
+            ld2 = {"total_loss": F.cross_entropy(net(z).permute(0, 2, 3, 1).reshape(-1, K), z.reshape(-1))}
+        for k, v in ld2.items():
+            out[f"{tag}.loss2.{k}"] = _np(v)
+        for k, v in net.state_dict().items():
+            out[f"{tag}.sd1.{k}"] = _np(v)
+        print("pixelcnn", tag, {k: float(v) for k, v in ld.items()}, {k: float(v) for k, v in ld2.items()})
+    np.savez_compressed(os.path.join(HERE, "pixelcnn_tiny.npz"), **out)
+
+
 def _checksum(t):
     t = t.detach().double()
     return np.array([t.sum().item(), t.norm().item()])
@@ -437,6 +488,7 @@ if __name__ == "__main__":
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--only-agg-variants", action="store_true", help="regenerate agg_variants.npz only")
     ap.add_argument("--only-gg-vae", action="store_true", help="regenerate gg_vae_tiny.npz only")
+    ap.add_argument("--only-pixelcnn", action="store_true", help="regenerate pixelcnn_tiny.npz only")
     a = ap.parse_args()
     _install_placeholders()
     sys.path.insert(0, REF)
@@ -447,9 +499,13 @@ if __name__ == "__main__":
     if a.only_gg_vae:
         gg_vae_fixture()
         sys.exit(0)
+    if a.only_pixelcnn:
+        pixelcnn_fixture()
+        sys.exit(0)
     objectives_fixture()
     weightings_fixture()
     agg_variants_fixture()
     model_fixtures()
+    pixelcnn_fixture()
     if a.full:
         full_fixture()
