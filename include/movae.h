@@ -303,6 +303,18 @@ typedef struct movae_fuse {
     float* stats;          /* device buffer for the partial sums (fwd entry points, act == none, no fused activation) */
     size_t stats_cap;      /* floats available at stats */
     int stats_parts;       /* OUT */
+    /* input-gradient passes (dgrad / dgrad_wgrad entry points): dx is the gradient `dout` w.r.t. the never-materialised output
+     * act(bn_scale[c] * bn_y + bn_shift[c]) of a fused BatchNorm over the raw conv output bn_y [n][hi][wi][ci] (shared by the
+     * `groups` cotangents).  The epilogue / split-K reduce then also emits that BatchNorm's backward sums per cotangent group,
+     * bn_part[((g * bn_ppg + p) * 2 + {0,1}) * ci + c] = partial (sum d, sum d * bn_y), d = dout * act'(...), for
+     * movae_bn_bwd_finalize.  bn_ppg == 0 on return: not produced (shape / kernel without the epilogue). */
+    const float* bn_y;
+    const float* bn_scale;
+    const float* bn_shift;
+    float bn_slope;
+    float* bn_part;
+    size_t bn_cap;         /* floats available at bn_part */
+    int bn_ppg;            /* OUT: partial pairs per group and channel */
 } movae_fuse_t;
 int movae_conv2d_fwd_f(const float* x, const float* w, const float* bias, float* y,
                        int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad,
@@ -325,6 +337,22 @@ int movae_convT2d_dgrad_wgrad_grouped_f(int groups, const float* dy, const float
                                         float* const* dw, float* const* dbias,
                                         int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad,
                                         int accumulate, void* ws, size_t ws_bytes, movae_stream_t stream, const movae_fuse_t* fuse);
+int movae_conv2d_dgrad_f(const float* dy, const float* w, float* dx,
+                         int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad,
+                         void* ws, size_t ws_bytes, movae_stream_t stream, movae_fuse_t* fuse, int groups);
+int movae_convT2d_dgrad_f(const float* dy, const float* w, float* dx,
+                          int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad,
+                          void* ws, size_t ws_bytes, movae_stream_t stream, movae_fuse_t* fuse, int groups);
+/* BatchNorm backward from the sums above (models/vae.py:119-126 through autograd): per cotangent group g
+ *   dbeta[g] = S1, dgamma[g] = rstd * (S2 - mean * S1)            (dgamma / dbeta: HOST arrays of device pointers, NULLs allowed)
+ *   coef[g][0..2][c] such that dy = coef0 * d + coef1 * y + coef2, d = dout * act'(scale * y + shift)
+ * and the one pass that forms dy [groups][rows][c] from dout [groups][rows][c] and y [rows][c].  accumulate != 0 adds to
+ * dgamma / dbeta. */
+int movae_bn_bwd_finalize(const float* bn_part, int ppg, int groups, int rows, int c, const float* gamma, const float* save_mean,
+                          const float* save_rstd, float* const* dgamma, float* const* dbeta, float* coef, int accumulate,
+                          movae_stream_t stream);
+int movae_bn_bwd_apply(const float* dout, const float* y, const float* scale, const float* shift, float slope, const float* coef,
+                       float* dy, int groups, size_t rows, int c, movae_stream_t stream);
 /* partial sums -> mean / rstd (saved for movae_bn_act_bwd), scale / shift (for the consumers), running statistics with
  * nn.BatchNorm2d's momentum rule and unbiased variance, num_batches_tracked += 1 (each may be NULL).  rows = n * h * w. */
 int movae_bn_finalize(const float* stats, int parts, int rows, int c, const float* gamma, const float* beta, float eps, float momentum,

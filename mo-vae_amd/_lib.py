@@ -24,7 +24,9 @@ _p, _i, _f, _z, _l = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_long
 class MovaeFuse(C.Structure):
     """movae_fuse_t (include/movae.h): BatchNorm fused into the neighbouring convolutions."""
     _fields_ = [("in_scale", C.c_void_p), ("in_shift", C.c_void_p), ("in_slope", C.c_float), ("stats", C.c_void_p),
-                ("stats_cap", C.c_size_t), ("stats_parts", C.c_int)]
+                ("stats_cap", C.c_size_t), ("stats_parts", C.c_int),
+                ("bn_y", C.c_void_p), ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p), ("bn_slope", C.c_float), ("bn_part", C.c_void_p),
+                ("bn_cap", C.c_size_t), ("bn_ppg", C.c_int)]
 
 
 _conv_fwd = [_p, _p, _p, _p] + [_i] * 11 + [_i, _f, _p, _z, _p]
@@ -99,6 +101,10 @@ SIGNATURES = {
     "movae_convT2d_wgrad_grouped_f": ([_i] + _conv_wgrad + [_p], _i),
     "movae_conv2d_dgrad_wgrad_grouped_f": ([_i, _p, _p, _p, _p, _p, _p] + [_i] * 11 + [_i, _p, _z, _p, _p], _i),
     "movae_convT2d_dgrad_wgrad_grouped_f": ([_i, _p, _p, _p, _p, _p, _p] + [_i] * 11 + [_i, _p, _z, _p, _p], _i),
+    "movae_conv2d_dgrad_f": (_conv_dgrad + [_p, _i], _i),
+    "movae_convT2d_dgrad_f": (_conv_dgrad + [_p, _i], _i),
+    "movae_bn_bwd_finalize": ([_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p], _i),
+    "movae_bn_bwd_apply": ([_p, _p, _p, _p, _f, _p, _p, _i, _z, _i, _p], _i),
     "movae_bn_finalize": ([_p, _i, _i, _i, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p], _i),
     "movae_bn_stats": ([_p, _i, _i, _p, _z, _p, _p], _i),
     "movae_scale_shift_act": ([_p, _p, _p, _p, _z, _i, _f, _p], _i),

@@ -600,6 +600,61 @@ __global__ __launch_bounds__(256) void scale_shift_act_k(const float* __restrict
     }
 }
 
+// ---- fused BatchNorm backward: the input-gradient pass that produced dout already emitted, per cotangent
+// group, the partial sums S1 = sum d, S2 = sum d * y with d = dout * act'(scale * y + shift).  One wave per (channel, group):
+//   dbeta = S1,  dgamma = sum d * x_hat = rstd * (S2 - mean * S1)
+//   dy = gamma * rstd * (d - S1/M - x_hat * dgamma/M) = k1 * d + c2 * y + c3,
+//   k1 = gamma * rstd,  c2 = -k1 * rstd * dgamma / M,  c3 = -k1 * S1 / M - c2 * mean          coef[g][0..2][C]
+__global__ __launch_bounds__(64) void bn_bwd_finalize_k(const float* __restrict__ part, int ppg, int rows, int C,
+                                                        const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, BnOut out, float* __restrict__ coef,
+                                                        int accumulate) {
+    const int c = blockIdx.x, g = blockIdx.y;
+    double s1 = 0.0, s2 = 0.0;
+    for (int p = threadIdx.x; p < ppg; p += 64) {
+        const long q = (long)g * ppg + p;
+        s1 += (double)part[(q * 2 + 0) * C + c];
+        s2 += (double)part[(q * 2 + 1) * C + c];
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (threadIdx.x != 0) return;
+    const double m = mean[c], r = rstd[c], ga = gamma[c];
+    const double dgam = r * (s2 - m * s1);
+    if (out.dbeta[g]) out.dbeta[g][c] = (float)(accumulate ? out.dbeta[g][c] + s1 : s1);
+    if (out.dgamma[g]) out.dgamma[g][c] = (float)(accumulate ? out.dgamma[g][c] + dgam : dgam);
+    const double k1 = ga * r, c2 = -k1 * r * dgam / rows, c3 = -k1 * s1 / rows - c2 * m;
+    float* cf = coef + (long)g * 3 * C;
+    cf[c] = (float)k1;
+    cf[C + c] = (float)c2;
+    cf[2 * C + c] = (float)c3;
+}
+
+// dy[g][i] = k1[c] * dout[g][i] * act'(scale[c] * y[i] + shift[c]) + c2[c] * y[i] + c3[c]
+__global__ __launch_bounds__(256) void bn_bwd_apply_coef_k(const float* __restrict__ dout, const float* __restrict__ y,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift, float slope,
+                                                           const float* __restrict__ coef, float* __restrict__ dy, long nv, int C) {
+    const int g = blockIdx.y;
+    const float* cf = coef + (long)g * 3 * C;
+    const long off = (long)g * nv;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+        const int c = (int)((i * 4) % C);
+        const f32x4 d4 = reinterpret_cast<const f32x4*>(dout)[off + i], y4 = reinterpret_cast<const f32x4*>(y)[i];
+        const f32x4 a = *reinterpret_cast<const f32x4*>(scale + c), b = *reinterpret_cast<const f32x4*>(shift + c);
+        const f32x4 k1 = *reinterpret_cast<const f32x4*>(cf + c), c2 = *reinterpret_cast<const f32x4*>(cf + C + c),
+                    c3 = *reinterpret_cast<const f32x4*>(cf + 2 * C + c);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float z = fmaf(y4[j], a[j], b[j]);
+            const float d = d4[j] * (z > 0.f ? 1.f : slope);
+            o[j] = fmaf(k1[j], d, fmaf(c2[j], y4[j], c3[j]));
+        }
+        reinterpret_cast<f32x4*>(dy)[off + i] = o;
+    }
+}
+
 inline int small_rows() {  // MOVAE_BN_SMALL_ROWS: largest row count served by the one-launch kernels (0 disables them)
     static const int v = getenv("MOVAE_BN_SMALL_ROWS") ? atoi(getenv("MOVAE_BN_SMALL_ROWS")) : 1024;
     return v < 1024 ? v : 1024;  // the kernels hold the whole column in registers: 4 rows per thread
@@ -773,6 +828,33 @@ int movae_scale_shift_act(const float* y, const float* scale, const float* shift
     const long nv = (long)rows * c / 4;
     hipLaunchKernelGGL(scale_shift_act_k, dim3(grid_for(nv / 4 + 1)), dim3(256), 0, (hipStream_t)stream, y, scale, shift, out, nv, c, slope);
     MOVAE_CHECK_LAUNCH("scale_shift_act");
+    return MOVAE_OK;
+}
+
+int movae_bn_bwd_finalize(const float* bn_part, int ppg, int groups, int rows, int c, const float* gamma, const float* save_mean,
+                          const float* save_rstd, float* const* dgamma, float* const* dbeta, float* coef, int accumulate,
+                          movae_stream_t stream) {
+    MOVAE_CHECK_ARG(bn_part && gamma && save_mean && save_rstd && coef, "movae_bn_bwd_finalize: null pointer");
+    MOVAE_CHECK_ARG(ppg > 0 && rows > 0 && c > 0 && groups >= 1 && groups <= MAX_GROUPS, "movae_bn_bwd_finalize: bad shape");
+    BnOut tab;
+    for (int g = 0; g < MAX_GROUPS; ++g) {
+        tab.dgamma[g] = (g < groups && dgamma) ? dgamma[g] : nullptr;
+        tab.dbeta[g] = (g < groups && dbeta) ? dbeta[g] : nullptr;
+    }
+    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(c, groups), dim3(64), 0, (hipStream_t)stream, bn_part, ppg, rows, c, gamma, save_mean,
+                       save_rstd, tab, coef, accumulate);
+    MOVAE_CHECK_LAUNCH("bn_bwd_finalize");
+    return MOVAE_OK;
+}
+
+int movae_bn_bwd_apply(const float* dout, const float* y, const float* scale, const float* shift, float slope, const float* coef,
+                       float* dy, int groups, size_t rows, int c, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(dout && y && scale && shift && coef && dy && rows > 0 && c > 0 && groups >= 1, "movae_bn_bwd_apply: bad argument");
+    MOVAE_CHECK_ARG(c % 4 == 0 && al16(dout, y, dy) && al16(scale, shift, coef), "movae_bn_bwd_apply: needs c %% 4 == 0 and aligned operands");
+    const long nv = (long)rows * c / 4;
+    hipLaunchKernelGGL(bn_bwd_apply_coef_k, dim3(grid_for(nv / 4 + 1), groups), dim3(256), 0, (hipStream_t)stream, dout, y, scale, shift, slope,
+                       coef, dy, nv, c);
+    MOVAE_CHECK_LAUNCH("bn_bwd_apply");
     return MOVAE_OK;
 }
 

@@ -58,6 +58,20 @@ __device__ __forceinline__ f32x4 norm_apply(f32x4 v, const f32x4 sc, const f32x4
 }
 
 
+// The result of an input-gradient pass is `dout`, the gradient w.r.t. the (never materialised) output of a fused BatchNorm +
+// activation over the raw conv output y: the epilogue also emits that BatchNorm's backward sums, per column and cotangent
+// group, d = dout * act'(scale * y + shift):   (sum d, sum d * y)   -- the BatchNorm backward then needs no reduction pass.
+// y is shared by the cotangent groups (rows_per_group rows each); the partials of group g are rows [g * ppg, (g + 1) * ppg).
+struct BnBwd {
+    const float* y;      // null: none
+    const float* scale;
+    const float* shift;
+    float slope;
+    float* part;         // [groups * ppg][2][N]
+    int rows_per_group;
+    int ppg;             // partials per group
+};
+
 // What the *_f entry points ask of the next conv-family dispatch of the calling thread (cleared by the entry point on return).
 // The launchers that can honour a request mark it: an operand transform that the dispatched kernel cannot apply is an
 // error raised BEFORE anything is launched (MOVAE_EUNSUPPORTED: the caller materialises the activation and calls the plain
@@ -69,6 +83,15 @@ struct FuseCtx {
     float* stats = nullptr;           // column partial sums of the forward result
     size_t stats_cap = 0;             // floats available at `stats`
     int stats_parts = 0;              // out: partial pairs written per column (0 = none)
+    // backward sums of the fused BatchNorm whose output gradient the dispatched input-gradient pass produces (BnBwd)
+    const float* bn_y = nullptr;
+    const float* bn_scale = nullptr;
+    const float* bn_shift = nullptr;
+    float bn_slope = 1.f;
+    float* bn_part = nullptr;
+    size_t bn_cap = 0;
+    int bn_groups = 1;
+    int bn_ppg = 0;                   // out: partial pairs per group and column (0 = none)
 };
 static thread_local FuseCtx g_fuse;
 
@@ -78,6 +101,12 @@ inline float* fuse_stats_claim(long parts, int n) {
     if (!g_fuse.stats || parts <= 0 || (size_t)parts * 2 * (size_t)n > g_fuse.stats_cap) return nullptr;
     g_fuse.stats_parts = (int)parts;
     return g_fuse.stats;
+}
+// claims room for `groups * ppg` backward-sum partials of `n` columns; null when absent / no room
+inline float* fuse_bn_claim(long ppg, int n) {
+    if (!g_fuse.bn_part || !g_fuse.bn_y || ppg <= 0 || (size_t)ppg * g_fuse.bn_groups * 2 * (size_t)n > g_fuse.bn_cap) return nullptr;
+    g_fuse.bn_ppg = (int)ppg;
+    return g_fuse.bn_part;
 }
 #define MOVAE_NO_NORM(what)                                                                                 \
     do {                                                                                                    \
@@ -630,13 +659,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_cls(const float* __restrict
 // rows_per_block rows.  stride > 0: BWD-form slabs with per-class split counts (splitk_reduce_cls); else S slabs everywhere.
 __global__ __launch_bounds__(256) void splitk_reduce_stats(const float* __restrict__ slab, float* __restrict__ out, int M, int N, int S,
                                                            ClsSplit scls, int Ho, int Wo, int stride, const float* __restrict__ bias,
-                                                           float* __restrict__ part, int rows_per_block) {
+                                                           float* __restrict__ part, int rows_per_block, BnBwd bb) {
     __shared__ float sh[2][4][256];
     const int t = threadIdx.x, NQ = N >> 2, RG = 256 / NQ;
     const int cq = t % NQ, rg = t / NQ;
     const long total = (long)M * N;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
     const f32x4 b4 = bias ? *reinterpret_cast<const f32x4*>(bias + cq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    // BnBwd mode (bb.y): the reduced value is dout; the sums are (d, d * y) with d = dout * act'(scale * y + shift)
+    f32x4 sc4 = f32x4{0.f, 0.f, 0.f, 0.f}, sh4 = sc4;
+    if (bb.y) {
+        sc4 = *reinterpret_cast<const f32x4*>(bb.scale + cq * 4);
+        sh4 = *reinterpret_cast<const f32x4*>(bb.shift + cq * 4);
+        part = bb.part;
+    }
     f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f}, q4 = s4;
     for (int r = r0 + rg; r < r1; r += RG) {
         int Sr = S;
@@ -649,9 +685,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats(const float* __restri
         for (int z = 1; z < Sr; ++z) v += *reinterpret_cast<const f32x4*>(slab + (long)z * total + i);
         v += b4;
         if (out) *reinterpret_cast<f32x4*>(out + i) = v;
-        s4 += v;
+        if (bb.y) {
+            const f32x4 y4 = *reinterpret_cast<const f32x4*>(bb.y + (long)(r % bb.rows_per_group) * N + cq * 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) q4[j] = fmaf(v[j], v[j], q4[j]);
+            for (int j = 0; j < 4; ++j) {
+                const float z = fmaf(y4[j], sc4[j], sh4[j]);
+                const float d = v[j] * (z > 0.f ? 1.f : bb.slope);
+                s4[j] += d;
+                q4[j] = fmaf(d, y4[j], q4[j]);
+            }
+        } else {
+            s4 += v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q4[j] = fmaf(v[j], v[j], q4[j]);
+        }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) sh[0][j][t] = s4[j], sh[1][j][t] = q4[j];
@@ -694,12 +741,15 @@ inline int launch_reduce(const float* slab, float* out, long total, int S, int N
 
 // The reduce of a split-K forward whose result feeds a BatchNorm: sums, adds the bias and emits the column statistics.
 // Returns false when the shape does not fit the kernel (the caller then reduces plainly and no statistics are produced).
+inline bool reduce_stats_shape_ok(const void* slab, const void* out, const void* part, const void* bias, long M, int N) {
+    return N % 4 == 0 && N <= 1024 && 256 % (N / 4) == 0 && M <= 0x7fffffffL &&
+           ((reinterpret_cast<uintptr_t>(slab) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(part)) & 15) == 0 &&
+           (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0);
+}
+
 inline bool launch_reduce_stats(const float* slab, float* out, long M, int N, int S, const ClsSplit* scls, int Ho, int Wo, int stride,
                                 const float* bias, hipStream_t st) {
-    if (!g_fuse.stats || N % 4 != 0 || N > 1024 || 256 % (N / 4) != 0 || M > 0x7fffffffL ||
-        ((reinterpret_cast<uintptr_t>(slab) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(g_fuse.stats)) & 15) != 0 ||
-        (bias && (reinterpret_cast<uintptr_t>(bias) & 15) != 0))
-        return false;
+    if (!g_fuse.stats || !reduce_stats_shape_ok(slab, out, g_fuse.stats, bias, M, N)) return false;
     const int RG = 256 / (N / 4);
     long rpb = 4L * RG;                                  // four rows per thread ...
     if ((M + rpb - 1) / rpb > 1024) rpb = ((M + 1023) / 1024 + RG - 1) / RG * RG;  // ... at most 1024 partials
@@ -708,8 +758,37 @@ inline bool launch_reduce_stats(const float* slab, float* out, long M, int N, in
     if (!part) return false;
     ClsSplit one{{S, S, S, S}};
     hipLaunchKernelGGL(splitk_reduce_stats, dim3((unsigned)nblk), dim3(256), 0, st, slab, out, (int)M, N, S, scls ? *scls : one, Ho, Wo,
-                       scls ? stride : 0, bias, part, (int)rpb);
+                       scls ? stride : 0, bias, part, (int)rpb, BnBwd{});
     return true;
+}
+
+// Plan of the same reduce in BnBwd mode (the reduced tensor is a fused BatchNorm's output gradient): rows per block such that
+// no block straddles two cotangent groups.  Fills `bb` (part / rows_per_group / ppg) and claims the partials; false = not possible.
+inline bool plan_reduce_bnbwd(long M, int N, BnBwd* bb, int* rows_per_block) {
+    if (!g_fuse.bn_y || !g_fuse.bn_part || N % 4 != 0 || N > 1024 || 256 % (N / 4) != 0 || M > 0x7fffffffL || M % g_fuse.bn_groups != 0)
+        return false;
+    const long rpg = M / g_fuse.bn_groups;
+    const int RG = 256 / (N / 4);
+    long rpb = 4L * RG;
+    while (rpb > RG && rpg % rpb != 0) rpb -= RG;
+    if (rpg % rpb != 0) return false;
+    while (rpg / rpb * g_fuse.bn_groups > 2048 && rpg % (rpb * 2) == 0) rpb *= 2;
+    float* part = fuse_bn_claim(rpg / rpb, N);
+    if (!part || ((reinterpret_cast<uintptr_t>(part) | reinterpret_cast<uintptr_t>(g_fuse.bn_y) | reinterpret_cast<uintptr_t>(g_fuse.bn_scale) |
+                   reinterpret_cast<uintptr_t>(g_fuse.bn_shift)) & 15) != 0) {
+        g_fuse.bn_ppg = 0;
+        return false;
+    }
+    *bb = BnBwd{g_fuse.bn_y, g_fuse.bn_scale, g_fuse.bn_shift, g_fuse.bn_slope, part, (int)rpg, (int)(rpg / rpb)};
+    *rows_per_block = (int)rpb;
+    return true;
+}
+
+inline void launch_reduce_bnbwd(const float* slab, float* out, long M, int N, int S, const ClsSplit* scls, int Ho, int Wo, int stride,
+                                const BnBwd& bb, int rows_per_block, hipStream_t st) {
+    ClsSplit one{{S, S, S, S}};
+    hipLaunchKernelGGL(splitk_reduce_stats, dim3((unsigned)((M + rows_per_block - 1) / rows_per_block)), dim3(256), 0, st, slab, out, (int)M,
+                       N, S, scls ? *scls : one, Ho, Wo, scls ? stride : 0, (const float*)nullptr, (float*)nullptr, rows_per_block, bb);
 }
 
 // split-K factor from a small cost model fitted to tools/conv_microbench.py --sweep-split on MI355X (tools/split_model.py
@@ -1037,6 +1116,20 @@ struct FuseScope {
         g_fuse = FuseCtx();
     }
 };
+
+// the BatchNorm-backward request of an input-gradient pass (movae_fuse_t::bn_*): installed for the dgrad dispatch only
+inline void fuse_bn_install(movae_fuse_t* f, int groups) {
+    if (!f) return;
+    f->bn_ppg = 0;
+    if (f->bn_y && f->bn_scale && f->bn_shift && f->bn_part && f->bn_cap > 0 && groups >= 1) {
+        g_fuse.bn_y = f->bn_y, g_fuse.bn_scale = f->bn_scale, g_fuse.bn_shift = f->bn_shift, g_fuse.bn_slope = f->bn_slope;
+        g_fuse.bn_part = f->bn_part, g_fuse.bn_cap = f->bn_cap, g_fuse.bn_groups = groups;
+    }
+}
+inline void fuse_bn_collect(movae_fuse_t* f) {
+    if (f) f->bn_ppg = g_fuse.bn_ppg;
+    g_fuse.bn_y = nullptr, g_fuse.bn_part = nullptr, g_fuse.bn_ppg = 0, g_fuse.bn_groups = 1;
+}
 #define MOVAE_CHECK_FUSE(f, c)                                                                                                   \
     MOVAE_CHECK_ARG(!(f) || !(f)->in_scale ||                                                                                    \
                         ((f)->in_shift && (c) % 4 == 0 && ((reinterpret_cast<uintptr_t>((f)->in_scale) | reinterpret_cast<uintptr_t>((f)->in_shift)) & 15) == 0), \
@@ -1084,6 +1177,17 @@ int movae_conv2d_dgrad(const float* dy, const float* w, float* dx, int n, int hi
     // gathered tensor = dy (ho x wo x co), output grid = dx (hi x wi x ci); W[co][tap][ci] is the [Cr][tap][Nn] image
     Geom g{n, ho, wo, co, hi, wi, ci, kh, kw, stride, pad};
     return launch_bwd(dy, w, dx, g, Epilogue{nullptr, MOVAE_ACT_NONE, 0.f}, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// n counts the images of ALL `groups` cotangents (dy / dx stacked); fuse->bn_* as in include/movae.h
+int movae_conv2d_dgrad_f(const float* dy, const float* w, float* dx, int n, int hi, int wi, int ci, int ho, int wo, int co,
+                         int kh, int kw, int stride, int pad, void* ws, size_t ws_bytes, movae_stream_t stream, movae_fuse_t* fuse,
+                         int groups) {
+    g_fuse = FuseCtx();
+    fuse_bn_install(fuse, groups);
+    const int rc = movae_conv2d_dgrad(dy, w, dx, n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, ws, ws_bytes, stream);
+    fuse_bn_collect(fuse);
+    return rc;
 }
 
 int movae_conv2d_wgrad_grouped_f(int groups, const float* dy, const float* x, float* const* dw, float* const* dbias, int n, int hi,
@@ -1151,6 +1255,16 @@ int movae_convT2d_dgrad(const float* dy, const float* w, float* dx, int n, int h
     return launch_fwd(dy, w, dx, g, Epilogue{nullptr, MOVAE_ACT_NONE, 0.f}, ws, ws_bytes, (hipStream_t)stream);
 }
 
+int movae_convT2d_dgrad_f(const float* dy, const float* w, float* dx, int n, int hi, int wi, int ci, int ho, int wo, int co,
+                          int kh, int kw, int stride, int pad, void* ws, size_t ws_bytes, movae_stream_t stream, movae_fuse_t* fuse,
+                          int groups) {
+    g_fuse = FuseCtx();
+    fuse_bn_install(fuse, groups);
+    const int rc = movae_convT2d_dgrad(dy, w, dx, n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, ws, ws_bytes, stream);
+    fuse_bn_collect(fuse);
+    return rc;
+}
+
 int movae_convT2d_wgrad_grouped_f(int groups, const float* dy, const float* x, float* const* dw, float* const* dbias, int n, int hi,
                                 int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad, int accumulate,
                                 void* ws, size_t ws_bytes, movae_stream_t stream, const movae_fuse_t* fuse) {
@@ -1195,8 +1309,11 @@ static int pair_calls(bool transposed, int groups, const float* dy, const float*
     static const bool enabled = !getenv("MOVAE_NO_PAIR");
     v2::g_pending.active = false;
     v2::g_pair_collect = enabled;
+    g_fuse = FuseCtx();
+    fuse_bn_install(const_cast<movae_fuse_t*>(fuse), groups);  // (the dgrad's plan -- also a stashed one -- keeps what it claimed)
     int rc = transposed ? movae_convT2d_dgrad(dy, w, dx, groups * n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, ws, ws_bytes, stream)
                         : movae_conv2d_dgrad(dy, w, dx, groups * n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, ws, ws_bytes, stream);
+    fuse_bn_collect(const_cast<movae_fuse_t*>(fuse));
     v2::g_pair_collect = false;
     if (rc) {
         v2::g_pending.active = false;

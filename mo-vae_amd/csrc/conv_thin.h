@@ -18,7 +18,7 @@ namespace thin {
 template <int NN, bool BWD>
 __global__ __launch_bounds__(256) void thin_in_k(const float* __restrict__ X, const float* __restrict__ W,
                                                  const float* __restrict__ bias, float* __restrict__ Y, Geom g, int M, int act,
-                                                 float slope, float* __restrict__ stats) {
+                                                 float slope, float* __restrict__ stats, BnBwd bb) {
     extern __shared__ __attribute__((aligned(16))) float Wl[];  // [K][NN]
     const int t = threadIdx.x;
     const int taps = g.KH * g.KW, K = taps * g.Cr, N = g.Nn;
@@ -101,6 +101,29 @@ __global__ __launch_bounds__(256) void thin_in_k(const float* __restrict__ X, co
                 const long pidx = (long)blockIdx.x * 4 + (t >> 6);
                 stats[(pidx * 2 + 0) * 32 + c] = sm;
                 stats[(pidx * 2 + 1) * 32 + c] = sq;
+            }
+        }
+        if (bb.y) {
+            // the tile is `dout` of a fused BatchNorm over y (same shape as Y): its backward sums, same thread mapping; a
+            // block's 256 rows never straddle two cotangent groups (host).  Each load instruction covers two whole 128-byte rows.
+            const int c = t & 31, r0 = (t >> 5) * 32;
+            const float sc = bb.scale[c], sh_ = bb.shift[c];
+            const float* yb_ = bb.y + ((long)blockIdx.x * 256 % bb.rows_per_group) * 32;
+            float s1 = 0.f, s2 = 0.f;
+            for (int r = 0; r < 32; ++r)
+                if (r0 + r < rows_left) {
+                    const float yv = yb_[(r0 + r) * 32 + c];
+                    const float z = fmaf(yv, sc, sh_);
+                    const float d = Wl[(r0 + r) * 33 + c] * (z > 0.f ? 1.f : bb.slope);
+                    s1 += d;
+                    s2 = fmaf(d, yv, s2);
+                }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if ((t & 63) < 32) {
+                const long pidx = (long)blockIdx.x * 4 + (t >> 6);
+                bb.part[(pidx * 2 + 0) * 32 + c] = s1;
+                bb.part[(pidx * 2 + 1) * 32 + c] = s2;
             }
         }
 #pragma unroll
@@ -589,15 +612,22 @@ int launch_thin_in(const float* X, const float* W, float* Y, const Geom& g, cons
     if (g.Nn > 32) {
         dim3 grid(ceil_div(M, 256), ceil_div(g.Nn, 64));
         hipLaunchKernelGGL((thin_in_k<64, BWD>), grid, dim3(256), (size_t)K * 64 * sizeof(float), st, X, W, ep.bias, Y, g, M,
-                           ep.act, ep.slope, (float*)nullptr);
+                           ep.act, ep.slope, (float*)nullptr, BnBwd{});
     } else {
         dim3 grid(ceil_div(M, 256), 1);
         size_t lds_floats = (size_t)K * 32;
         if (g.Nn == 32 && lds_floats < 256 * 33) lds_floats = 256 * 33;  // room for the coalescing transpose of the outputs
         float* stats = nullptr;  // the 32-output kernel holds its tile in LDS: statistics for a following BatchNorm come for free
         if (!BWD && g.Nn == 32 && ep.act == MOVAE_ACT_NONE) stats = fuse_stats_claim((long)grid.x * 4, 32);
+        BnBwd bb{};  // input gradient of the last conv = output gradient of the fused BatchNorm in front of it
+        if (BWD && g.Nn == 32 && g_fuse.bn_y && ep.act == MOVAE_ACT_NONE && !ep.bias && M % g_fuse.bn_groups == 0 &&
+            (M / g_fuse.bn_groups) % 256 == 0) {
+            const long rpg = M / g_fuse.bn_groups;
+            if (float* part = fuse_bn_claim(rpg / 256 * 4, 32))
+                bb = BnBwd{g_fuse.bn_y, g_fuse.bn_scale, g_fuse.bn_shift, g_fuse.bn_slope, part, (int)rpg, (int)(rpg / 256 * 4)};
+        }
         hipLaunchKernelGGL((thin_in_k<32, BWD>), grid, dim3(256), lds_floats * sizeof(float), st, X, W, ep.bias, Y, g, M,
-                           ep.act, ep.slope, stats);
+                           ep.act, ep.slope, stats, bb);
     }
     MOVAE_CHECK_LAUNCH("thin_in");
     return MOVAE_OK;

@@ -138,6 +138,39 @@ __device__ __forceinline__ void col_stats_store(const f32x16 (&acc)[TM * TN], co
     }
 }
 
+// BnBwd sums of a wave's accumulator tiles: the stored value IS dout; yrow(tm, r) gives the row of y (and validity, < 0 = none)
+// that output row (tm, r) of this lane half corresponds to.  part[(p * 2 + 0) * N + n] = sum d, [(p * 2 + 1) * N + n] = sum d * y.
+template <int TM, int TN, class RowFn>
+__device__ __forceinline__ void col_bnbwd_store(const f32x16 (&acc)[TM * TN], const BnBwd& bb, long pidx, int n_base, int N, RowFn yrow) {
+    const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int n = n_base + tn * 32 + l31;
+        const bool nv = n < N;
+        const float sc = nv ? bb.scale[n] : 0.f, sh = nv ? bb.shift[n] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long yr = yrow(tm, r, half);
+                if (yr >= 0 && nv) {
+                    const float yv = bb.y[yr * N + n];
+                    const float z = fmaf(yv, sc, sh);
+                    const float d = acc[tm * TN + tn][r] * (z > 0.f ? 1.f : bb.slope);
+                    s1 += d;
+                    s2 = fmaf(d, yv, s2);
+                }
+            }
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (half == 0 && nv) {
+            bb.part[(pidx * 2 + 0) * N + n] = s1;
+            bb.part[(pidx * 2 + 1) * N + n] = s2;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Kernel arguments as plain structs and kernel bodies as device functions of an explicit block index (bx, by, bz) and an
 // LDS base: the stand-alone kernels below pass blockIdx, the paired kernel (igemm2_pair) runs a dgrad body and a wgrad
@@ -152,6 +185,7 @@ struct FwdArgs {
     float* slab;
     Norm nrm;      // virtual gathered operand (zero-initialised: plain)
     float* stats;  // column partial sums of the stored result [gx * WM][2][N], or null (only without split-K)
+    BnBwd bb;      // the result is a fused BatchNorm's output gradient: its backward sums (only without split-K)
 };
 
 template <int BM, int BN>
@@ -293,6 +327,14 @@ __device__ __forceinline__ void igemm2_fwd_body(const FwdArgs& a, float* __restr
     float* out = to_slab ? slab + (long)bz * M * N : Y;
     if (a.stats && !to_slab)  // statistics of v + bias (the host asks for them only with act == none)
         col_stats_store<T::TM, T::TN>(acc, ep.bias, a.stats, (long)bx * T::WM + wm, m0 + wm * T::TM * 32, n0 + wn * T::TN * 32, M, N);
+    if (a.bb.y && !to_slab) {  // (the host guarantees that no row block straddles two cotangent groups)
+        const int mw = m0 + wm * T::TM * 32, rpg = a.bb.rows_per_group;
+        const int g0 = m0 / rpg;
+        col_bnbwd_store<T::TM, T::TN>(acc, a.bb, (long)bx * T::WM + wm, n0 + wn * T::TN * 32, N, [&](int tm, int r, int hf) -> long {
+            const int m = mw + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+            return m < M ? (long)(m - g0 * rpg) : -1L;
+        });
+    }
 #pragma unroll
     for (int tn = 0; tn < T::TN; ++tn) {
         const int n = n0 + wn * T::TN * 32 + tn * 32 + l31;
@@ -328,6 +370,7 @@ struct BwdArgs {
     Norm nrm;
     float* stats;  // [classes * gx * WM][2][N] or null (only without split-K)
     int stats_gx;  // row blocks per class (the launch's grid x) -- the partial index is (class * gx + bx) * WM + wave row
+    BnBwd bb;      // backward sums of a fused BatchNorm (only without split-K; ppg = classes * (gx / groups) * WM)
 };
 
 template <int BM, int BN>
@@ -502,6 +545,22 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
     if (a.stats && !to_slab)
         col_stats_store<T::TM, T::TN>(acc, ep.bias, a.stats, ((long)cls * a.stats_gx + bx) * T::WM + wm, m0 + wm * T::TM * 32,
                                       n0 + wn * T::TN * 32, M, N);
+    if (a.bb.y && !to_slab) {
+        // classes are equally large and no row block straddles two cotangent groups (host): group gi owns bpg row blocks of
+        // every class; its partials are [gi * ppg, (gi + 1) * ppg), ordered (class, block in group, wave row)
+        const int ncls_ = s * s, bpg = a.bb.ppg / (ncls_ * T::WM), gi = bx / bpg;
+        const long pidx = (long)gi * a.bb.ppg + ((long)cls * bpg + (bx - gi * bpg)) * T::WM + wm;
+        const int mw = m0 + wm * T::TM * 32, hwc = Hoc * Woc;
+        const long ppg_pix = (long)a.bb.rows_per_group;  // pixels of one group in the full output grid
+        col_bnbwd_store<T::TM, T::TN>(acc, a.bb, pidx, n0 + wn * T::TN * 32, N, [&](int tm, int r, int hf) -> long {
+            const int m = mw + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+            if (m >= M) return -1L;
+            const int img = m / hwc, rem = m - img * hwc;
+            const int hc = rem / Woc, wc = rem - hc * Woc;
+            const long p = ((long)img * g.Ho + (hc * s + ph)) * g.Wo + (wc * s + pw);
+            return p % ppg_pix;
+        });
+    }
 #pragma unroll
     for (int tm = 0; tm < T::TM; ++tm)
 #pragma unroll
@@ -760,6 +819,8 @@ struct PendingDgrad {
     bool reduce = false;
     int S = 1;
     long total = 0;
+    BnBwd rbb{};          // rbb.y != null: the reduce also emits the fused BatchNorm's backward sums (rows per block: rbb_rpb)
+    int rbb_rpb = 0;
 };
 static thread_local PendingDgrad g_pending;
 static thread_local bool g_pair_collect = false;
@@ -781,9 +842,19 @@ inline int finish_pending(hipStream_t st) {  // the stashed dgrad's reduce
     if (!p.reduce || g_bench_main_only) return MOVAE_OK;
     if (p.form == 0) {
         const FwdArgs& a = p.fa;
+        if (p.rbb.y) {
+            launch_reduce_bnbwd(a.slab, a.Y, a.M, a.g.Nn, p.S, nullptr, 0, 0, 0, p.rbb, p.rbb_rpb, st);
+            MOVAE_CHECK_LAUNCH("splitk_reduce_stats (bn bwd)");
+            return MOVAE_OK;
+        }
         return launch_reduce(a.slab, a.Y, (long)a.M * a.g.Nn, p.S, a.g.Nn, a.ep.bias, a.ep.act, a.ep.slope, 0, st);
     }
     const BwdArgs& a = p.ba;
+    if (p.rbb.y) {
+        launch_reduce_bnbwd(a.slab, a.Y, (long)a.g.Nimg * a.g.Ho * a.g.Wo, a.g.Nn, p.S, &a.scls, a.g.Ho, a.g.Wo, a.g.stride, p.rbb, p.rbb_rpb, st);
+        MOVAE_CHECK_LAUNCH("splitk_reduce_stats (bn bwd)");
+        return MOVAE_OK;
+    }
     long gq = (a.total / 4 + 255) / 256;
     if (gq > 4096) gq = 4096;
     hipLaunchKernelGGL(splitk_reduce_cls, dim3((unsigned)gq), dim3(256), 0, st, a.slab, a.Y, a.total, a.g.Nn, a.g.Ho, a.g.Wo, a.g.stride,
@@ -824,10 +895,26 @@ int launch_fwd2(const float* X, const float* W, float* Y, const Geom& g, const E
     // statistics of the result for the BatchNorm that follows (never on a backward pass: those are the paired / collected ones)
     const bool want_stats = g_fuse.stats && ep.act == MOVAE_ACT_NONE && !g_pair_collect;
     if (want_stats && S == 1) a.stats = fuse_stats_claim((long)gx * T2<BM, BN>::WM, g.Nn);
+    // the result is a fused BatchNorm's output gradient: its backward sums from the epilogue (unsplit) or from the reduce
+    BnBwd rbb{};
+    int rbb_rpb = 0;
+    if (g_fuse.bn_y && ep.act == MOVAE_ACT_NONE && !ep.bias) {
+        const long rpg = M / g_fuse.bn_groups;
+        if (S == 1) {
+            if (M % g_fuse.bn_groups == 0 && rpg % BM == 0) {
+                const long ppg = rpg / BM * T2<BM, BN>::WM;
+                if (float* part = fuse_bn_claim(ppg, g.Nn))
+                    a.bb = BnBwd{g_fuse.bn_y, g_fuse.bn_scale, g_fuse.bn_shift, g_fuse.bn_slope, part, (int)rpg, (int)ppg};
+            }
+        } else {
+            plan_reduce_bnbwd(M, g.Nn, &rbb, &rbb_rpb);
+        }
+    }
     if (g_pair_collect && pair_dgrad_tile<BM, BN>()) {
         PendingDgrad& p = g_pending;
         p.active = true;
         p.form = 0, p.bm = BM, p.bn = BN, p.fa = a, p.gx = gx, p.gy = gy, p.gz = S;
+        p.rbb = rbb, p.rbb_rpb = rbb_rpb;
         p.reduce = S > 1, p.S = S, p.total = (long)M * g.Nn;
         p.ws_used = S > 1 ? (size_t)M * g.Nn * sizeof(float) * S : 0;
         return MOVAE_OK;
@@ -835,7 +922,12 @@ int launch_fwd2(const float* X, const float* W, float* Y, const Geom& g, const E
     hipLaunchKernelGGL((igemm2_fwd<BM, BN>), dim3(gx, gy, S), dim3(256), 0, st, a);
     MOVAE_CHECK_LAUNCH("igemm2_fwd");
     if (S > 1) {
-        if (want_stats && launch_reduce_stats(slab, Y, M, g.Nn, S, nullptr, 0, 0, 0, ep.bias, st)) {
+        if (rbb.y && !g_bench_main_only) {
+            launch_reduce_bnbwd(slab, Y, M, g.Nn, S, nullptr, 0, 0, 0, rbb, rbb_rpb, st);
+            MOVAE_CHECK_LAUNCH("splitk_reduce_stats (bn bwd)");
+            return MOVAE_OK;
+        }
+        if (want_stats && !g_bench_main_only && launch_reduce_stats(slab, Y, M, g.Nn, S, nullptr, 0, 0, 0, ep.bias, st)) {
             MOVAE_CHECK_LAUNCH("splitk_reduce_stats");
             return MOVAE_OK;
         }
@@ -906,10 +998,27 @@ int launch_bwd2(const float* X, const float* W, float* Y, const Geom& g, const E
     a.stats_gx = gx;
     const bool want_stats = g_fuse.stats && ep.act == MOVAE_ACT_NONE && !g_pair_collect;
     if (want_stats && Sreal == 1) a.stats = fuse_stats_claim((long)ncls * gx * T2<BM, BN>::WM, g.Nn);
+    BnBwd rbb{};
+    int rbb_rpb = 0;
+    if (g_fuse.bn_y && ep.act == MOVAE_ACT_NONE && !ep.bias) {
+        const long pix = (long)g.Nimg * g.Ho * g.Wo;  // output pixels over all cotangent groups
+        if (Sreal == 1) {
+            // equally large classes (even output grid) and whole row blocks per group and class
+            const long rows_c = pix / ncls / g_fuse.bn_groups;
+            if (g.Ho % s == 0 && g.Wo % s == 0 && pix % ((long)ncls * g_fuse.bn_groups) == 0 && rows_c % BM == 0) {
+                const long ppg = (long)ncls * (rows_c / BM) * T2<BM, BN>::WM;
+                if (float* part = fuse_bn_claim(ppg, g.Nn))
+                    a.bb = BnBwd{g_fuse.bn_y, g_fuse.bn_scale, g_fuse.bn_shift, g_fuse.bn_slope, part, (int)(pix / g_fuse.bn_groups), (int)ppg};
+            }
+        } else {
+            plan_reduce_bnbwd(pix, g.Nn, &rbb, &rbb_rpb);
+        }
+    }
     if (g_pair_collect && pair_dgrad_tile<BM, BN>()) {
         PendingDgrad& p = g_pending;
         p.active = true;
         p.form = 1, p.bm = BM, p.bn = BN, p.ba = a, p.gx = gx, p.gy = gy, p.gz = zsum;
+        p.rbb = rbb, p.rbb_rpb = rbb_rpb;
         p.reduce = Sreal > 1, p.S = Sreal, p.total = total;
         p.ws_used = Sreal > 1 ? (size_t)total * sizeof(float) * Sreal : 0;
         return MOVAE_OK;
@@ -917,6 +1026,11 @@ int launch_bwd2(const float* X, const float* W, float* Y, const Geom& g, const E
     hipLaunchKernelGGL((igemm2_bwd<BM, BN>), dim3(gx, gy, zsum), dim3(256), 0, st, a);
     MOVAE_CHECK_LAUNCH("igemm2_bwd");
     if (Sreal > 1 && !g_bench_main_only) {
+        if (rbb.y) {
+            launch_reduce_bnbwd(slab, Y, (long)g.Nimg * g.Ho * g.Wo, g.Nn, Sreal, &scls, g.Ho, g.Wo, s, rbb, rbb_rpb, st);
+            MOVAE_CHECK_LAUNCH("splitk_reduce_stats (bn bwd)");
+            return MOVAE_OK;
+        }
         if (want_stats && launch_reduce_stats(slab, Y, (long)g.Nimg * g.Ho * g.Wo, g.Nn, Sreal, &scls, g.Ho, g.Wo, s, ep.bias, st)) {
             MOVAE_CHECK_LAUNCH("splitk_reduce_stats");
             return MOVAE_OK;

@@ -157,7 +157,7 @@ class Stack(tnn.Sequential):
                     if FUSE_BN and nxt.training and kind in (None, "lrelu", "relu") and m.out_channels % 4 == 0:
                         fusion = ops.ConvFusion(want_stats=True)
                         if isinstance(x, ops.LazyBN):
-                            fusion.in_scale, fusion.in_shift, fusion.in_slope = x.scale, x.shift, x.slope
+                            fusion.in_scale, fusion.in_shift, fusion.in_slope, fusion.link = x.scale, x.shift, x.slope, x.link
                             x = x.y
                         x = nxt.forward_lazy(m(x, None, True, fusion), kind, fusion)
                     else:

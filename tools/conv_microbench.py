@@ -35,6 +35,11 @@ C3 = [
 ]
 
 
+# full C3 batch: the layers whose 128x128 tiles dominate C3-C5 (tools/gpu_pmc_igemm128.sh)
+C3BIG = [("conv", 128, 16, 16, 256, 16, 16, 256, 3, 1, 1), ("conv", 128, 32, 32, 128, 16, 16, 256, 4, 2, 1),
+         ("convT", 128, 16, 16, 256, 32, 32, 128, 4, 2, 1)]
+
+
 def time_call(fn, args, reps):
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -69,7 +74,7 @@ def main():
     lib = L.load()
     dev = torch.device("cuda:0")
     ws = L.workspace(dev)
-    shapes = C2 if a.shapes == "c2" else C3
+    shapes = {"c2": C2, "c3": C3, "c3big": C3BIG}[a.shapes]
     tot = 0.0
     for i, (kind, n, hi, wi, ci, ho, wo, co, k, s, p) in enumerate(shapes):
         if a.index is not None and i not in a.index:
