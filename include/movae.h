@@ -348,16 +348,18 @@ int movae_convT2d_dgrad_f(const float* dy, const float* w, float* dx,
  *   coef[g][0..2][c] such that dy = coef0 * d + coef1 * y + coef2, d = dout * act'(scale * y + shift)
  * and the one pass that forms dy [groups][rows][c] from dout [groups][rows][c] and y [rows][c].  accumulate != 0 adds to
  * dgamma / dbeta. */
-int movae_bn_bwd_finalize(const float* bn_part, int ppg, int groups, int rows, int c, const float* gamma, const float* save_mean,
-                          const float* save_rstd, float* const* dgamma, float* const* dbeta, float* coef, int accumulate,
-                          movae_stream_t stream);
+int movae_bn_bwd_finalize(const float* bn_part, size_t bn_cap, int ppg, int groups, int rows, int c, const float* gamma,
+                          const float* save_mean, const float* save_rstd, float* const* dgamma, float* const* dbeta, float* coef,
+                          int accumulate, movae_stream_t stream);
 int movae_bn_bwd_apply(const float* dout, const float* y, const float* scale, const float* shift, float slope, const float* coef,
                        float* dy, int groups, size_t rows, int c, movae_stream_t stream);
 /* partial sums -> mean / rstd (saved for movae_bn_act_bwd), scale / shift (for the consumers), running statistics with
- * nn.BatchNorm2d's momentum rule and unbiased variance, num_batches_tracked += 1 (each may be NULL).  rows = n * h * w. */
-int movae_bn_finalize(const float* stats, int parts, int rows, int c, const float* gamma, const float* beta, float eps, float momentum,
-                      float* save_mean, float* save_rstd, float* scale, float* shift, float* running_mean, float* running_var,
-                      long long* num_batches_tracked, movae_stream_t stream);
+ * nn.BatchNorm2d's momentum rule and unbiased variance, num_batches_tracked += 1 (each may be NULL).  rows = n * h * w.
+ * stats_cap / bn_cap: floats available at the partials buffer -- with more than 256 partials and room behind them, a first
+ * stage folds them to 64 rows there (the buffer is scratch: its contents are not preserved). */
+int movae_bn_finalize(const float* stats, size_t stats_cap, int parts, int rows, int c, const float* gamma, const float* beta, float eps,
+                      float momentum, float* save_mean, float* save_rstd, float* scale, float* shift, float* running_mean,
+                      float* running_var, long long* num_batches_tracked, movae_stream_t stream);
 /* the same partial sums from one read of y, for producers whose kernel cannot emit them; *parts_out is a HOST int */
 int movae_bn_stats(const float* y, int rows, int c, float* stats, size_t stats_cap, int* parts_out, movae_stream_t stream);
 /* out = leaky_relu(scale[c] * y + shift[c], slope): materialises a fused BatchNorm output */

@@ -600,6 +600,44 @@ __global__ __launch_bounds__(256) void scale_shift_act_k(const float* __restrict
     }
 }
 
+// Many partials (a 262144-row layer leaves 8192 per channel): folding them one wave per channel is a long strided read.  This
+// first stage cuts the partial rows into gridDim.x slices; block b sums its slice for every column (reads coalesced across the
+// 2C columns, fixed order) into row b of `dst` -- the finalize kernels then fold gridDim.x rows.  blockIdx.y = cotangent group.
+__global__ __launch_bounds__(256) void bn_partials_fold_k(const float* __restrict__ part, int P, int E, float* __restrict__ dst) {
+    __shared__ float sh[256];
+    const int t = threadIdx.x, nb = gridDim.x, b = blockIdx.x;
+    part += (long)blockIdx.y * P * E;
+    dst += (long)blockIdx.y * nb * E;
+    const int chunk = (P + nb - 1) / nb, p0 = b * chunk, p1 = min(P, p0 + chunk);
+    const int EL = E < 256 ? E : 256, PL = 256 / EL;  // column lanes x partial-row lanes
+    const int el = t % EL, pl = t / EL;
+    for (int e0 = 0; e0 < E; e0 += EL) {
+        const int e = e0 + el;
+        float acc = 0.f;
+        if (e < E && pl < PL)
+            for (int p = p0 + pl; p < p1; p += PL) acc += part[(long)p * E + e];
+        sh[t] = acc;
+        __syncthreads();
+        if (pl == 0 && e < E) {
+            float s = acc;
+            for (int i = 1; i < PL; ++i) s += sh[i * EL + el];
+            dst[(long)b * E + e] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// -> (partials to finalise, their count): folds in the free tail of the caller's buffer when there are many
+inline const float* fold_partials(const float* part, size_t cap_floats, int* parts, int groups, int c, hipStream_t st) {
+    const int P = *parts, E = 2 * c;
+    const int nb = 64;
+    if (P <= 256 || (size_t)groups * P * E + (size_t)groups * nb * E > cap_floats) return part;
+    float* dst = const_cast<float*>(part) + (size_t)groups * P * E;
+    hipLaunchKernelGGL(bn_partials_fold_k, dim3(nb, groups), dim3(256), 0, st, part, P, E, dst);
+    *parts = nb;
+    return dst;
+}
+
 // ---- fused BatchNorm backward: the input-gradient pass that produced dout already emitted, per cotangent
 // group, the partial sums S1 = sum d, S2 = sum d * y with d = dout * act'(scale * y + shift).  One wave per (channel, group):
 //   dbeta = S1,  dgamma = sum d * x_hat = rstd * (S2 - mean * S1)
@@ -810,11 +848,12 @@ int movae_bn_act_bwd(const float* dout, const float* y, const float* gamma, cons
                                     ws_bytes, stream);
 }
 
-int movae_bn_finalize(const float* stats, int parts, int rows, int c, const float* gamma, const float* beta, float eps, float momentum,
-                      float* save_mean, float* save_rstd, float* scale, float* shift, float* running_mean, float* running_var,
-                      long long* num_batches_tracked, movae_stream_t stream) {
+int movae_bn_finalize(const float* stats, size_t stats_cap, int parts, int rows, int c, const float* gamma, const float* beta, float eps,
+                      float momentum, float* save_mean, float* save_rstd, float* scale, float* shift, float* running_mean,
+                      float* running_var, long long* num_batches_tracked, movae_stream_t stream) {
     MOVAE_CHECK_ARG(stats && gamma && beta && save_mean && save_rstd && scale && shift, "movae_bn_finalize: null pointer");
     MOVAE_CHECK_ARG(parts > 0 && rows > 0 && c > 0, "movae_bn_finalize: bad shape parts=%d rows=%d c=%d", parts, rows, c);
+    stats = fold_partials(stats, stats_cap, &parts, 1, c, (hipStream_t)stream);
     hipLaunchKernelGGL(bn_finalize_k, dim3(c), dim3(64), 0, (hipStream_t)stream, stats, parts, rows, c, gamma, beta, eps, momentum,
                        save_mean, save_rstd, scale, shift, running_mean, running_var, num_batches_tracked);
     MOVAE_CHECK_LAUNCH("bn_finalize");
@@ -831,11 +870,12 @@ int movae_scale_shift_act(const float* y, const float* scale, const float* shift
     return MOVAE_OK;
 }
 
-int movae_bn_bwd_finalize(const float* bn_part, int ppg, int groups, int rows, int c, const float* gamma, const float* save_mean,
-                          const float* save_rstd, float* const* dgamma, float* const* dbeta, float* coef, int accumulate,
-                          movae_stream_t stream) {
+int movae_bn_bwd_finalize(const float* bn_part, size_t bn_cap, int ppg, int groups, int rows, int c, const float* gamma,
+                          const float* save_mean, const float* save_rstd, float* const* dgamma, float* const* dbeta, float* coef,
+                          int accumulate, movae_stream_t stream) {
     MOVAE_CHECK_ARG(bn_part && gamma && save_mean && save_rstd && coef, "movae_bn_bwd_finalize: null pointer");
     MOVAE_CHECK_ARG(ppg > 0 && rows > 0 && c > 0 && groups >= 1 && groups <= MAX_GROUPS, "movae_bn_bwd_finalize: bad shape");
+    bn_part = fold_partials(bn_part, bn_cap, &ppg, groups, c, (hipStream_t)stream);
     BnOut tab;
     for (int g = 0; g < MAX_GROUPS; ++g) {
         tab.dgamma[g] = (g < groups && dgamma) ? dgamma[g] : nullptr;

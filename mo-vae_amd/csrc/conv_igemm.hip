@@ -682,7 +682,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats(const float* __restri
         }
         const long i = (long)r * N + cq * 4;
         f32x4 v = *reinterpret_cast<const f32x4*>(slab + i);
-        for (int z = 1; z < Sr; ++z) v += *reinterpret_cast<const f32x4*>(slab + (long)z * total + i);
+        int z = 1;
+        for (; z + 3 < Sr; z += 4) {  // four slabs in flight per trip (a dependent chain of S loads is what made this kernel slow)
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(slab + (long)z * total + i),
+                        a1 = *reinterpret_cast<const f32x4*>(slab + (long)(z + 1) * total + i),
+                        a2 = *reinterpret_cast<const f32x4*>(slab + (long)(z + 2) * total + i),
+                        a3 = *reinterpret_cast<const f32x4*>(slab + (long)(z + 3) * total + i);
+            v += (a0 + a1) + (a2 + a3);
+        }
+        for (; z < Sr; ++z) v += *reinterpret_cast<const f32x4*>(slab + (long)z * total + i);
         v += b4;
         if (out) *reinterpret_cast<f32x4*>(out + i) = v;
         if (bb.y) {
@@ -751,7 +759,7 @@ inline bool launch_reduce_stats(const float* slab, float* out, long M, int N, in
                                 const float* bias, hipStream_t st) {
     if (!g_fuse.stats || !reduce_stats_shape_ok(slab, out, g_fuse.stats, bias, M, N)) return false;
     const int RG = 256 / (N / 4);
-    long rpb = 4L * RG;                                  // four rows per thread ...
+    long rpb = 2L * RG;                                  // two rows per thread ...
     if ((M + rpb - 1) / rpb > 1024) rpb = ((M + 1023) / 1024 + RG - 1) / RG * RG;  // ... at most 1024 partials
     const long nblk = (M + rpb - 1) / rpb;
     float* part = fuse_stats_claim(nblk, N);
@@ -769,7 +777,7 @@ inline bool plan_reduce_bnbwd(long M, int N, BnBwd* bb, int* rows_per_block) {
         return false;
     const long rpg = M / g_fuse.bn_groups;
     const int RG = 256 / (N / 4);
-    long rpb = 4L * RG;
+    long rpb = 2L * RG;
     while (rpb > RG && rpg % rpb != 0) rpb -= RG;
     if (rpg % rpb != 0) return false;
     while (rpg / rpb * g_fuse.bn_groups > 2048 && rpg % (rpb * 2) == 0) rpb *= 2;

@@ -108,69 +108,6 @@ __device__ __forceinline__ void mma_kk(const float* __restrict__ As, const float
 
 #define ZERO4 (f32x4{0.f, 0.f, 0.f, 0.f})
 
-// Per-column partial sums of a wave's TM x TN 32x32 accumulator tiles (+ bias), rows >= M excluded: part[(p * 2 + 0) * N + n]
-// = sum, [(p * 2 + 1) * N + n] = sum of squares, p = the wave's partial index.  Lane l holds column l & 31 of each tile in 16
-// registers (rows (r & 3) + 8 (r >> 2) + 4 (l >> 5)); the two lane halves are folded with one cross-half shuffle.
-template <int TM, int TN>
-__device__ __forceinline__ void col_stats_store(const f32x16 (&acc)[TM * TN], const float* __restrict__ bias, float* __restrict__ part,
-                                                long pidx, int m_base, int n_base, int M, int N) {
-    const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const int n = n_base + tn * 32 + l31;
-        const float bv = (bias && n < N) ? bias[n] : 0.f;
-        float s = 0.f, q = 0.f;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m_base + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const float v = m < M ? acc[tm * TN + tn][r] + bv : 0.f;
-                s += v;
-                q = fmaf(v, v, q);
-            }
-        s += __shfl_xor(s, 32, 64);
-        q += __shfl_xor(q, 32, 64);
-        if (half == 0 && n < N) {
-            part[(pidx * 2 + 0) * N + n] = s;
-            part[(pidx * 2 + 1) * N + n] = q;
-        }
-    }
-}
-
-// BnBwd sums of a wave's accumulator tiles: the stored value IS dout; yrow(tm, r) gives the row of y (and validity, < 0 = none)
-// that output row (tm, r) of this lane half corresponds to.  part[(p * 2 + 0) * N + n] = sum d, [(p * 2 + 1) * N + n] = sum d * y.
-template <int TM, int TN, class RowFn>
-__device__ __forceinline__ void col_bnbwd_store(const f32x16 (&acc)[TM * TN], const BnBwd& bb, long pidx, int n_base, int N, RowFn yrow) {
-    const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const int n = n_base + tn * 32 + l31;
-        const bool nv = n < N;
-        const float sc = nv ? bb.scale[n] : 0.f, sh = nv ? bb.shift[n] : 0.f;
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long yr = yrow(tm, r, half);
-                if (yr >= 0 && nv) {
-                    const float yv = bb.y[yr * N + n];
-                    const float z = fmaf(yv, sc, sh);
-                    const float d = acc[tm * TN + tn][r] * (z > 0.f ? 1.f : bb.slope);
-                    s1 += d;
-                    s2 = fmaf(d, yv, s2);
-                }
-            }
-        s1 += __shfl_xor(s1, 32, 64);
-        s2 += __shfl_xor(s2, 32, 64);
-        if (half == 0 && nv) {
-            bb.part[(pidx * 2 + 0) * N + n] = s1;
-            bb.part[(pidx * 2 + 1) * N + n] = s2;
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Kernel arguments as plain structs and kernel bodies as device functions of an explicit block index (bx, by, bz) and an
 // LDS base: the stand-alone kernels below pass blockIdx, the paired kernel (igemm2_pair) runs a dgrad body and a wgrad
@@ -325,29 +262,49 @@ __device__ __forceinline__ void igemm2_fwd_body(const FwdArgs& a, float* __restr
     const int lane = t & 63, half = lane >> 5, l31 = lane & 31;
     const bool to_slab = slab != nullptr;
     float* out = to_slab ? slab + (long)bz * M * N : Y;
-    if (a.stats && !to_slab)  // statistics of v + bias (the host asks for them only with act == none)
-        col_stats_store<T::TM, T::TN>(acc, ep.bias, a.stats, (long)bx * T::WM + wm, m0 + wm * T::TM * 32, n0 + wn * T::TN * 32, M, N);
-    if (a.bb.y && !to_slab) {  // (the host guarantees that no row block straddles two cotangent groups)
-        const int mw = m0 + wm * T::TM * 32, rpg = a.bb.rows_per_group;
-        const int g0 = m0 / rpg;
-        col_bnbwd_store<T::TM, T::TN>(acc, a.bb, (long)bx * T::WM + wm, n0 + wn * T::TN * 32, N, [&](int tm, int r, int hf) -> long {
-            const int m = mw + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
-            return m < M ? (long)(m - g0 * rpg) : -1L;
-        });
-    }
+    // Fused BatchNorm side products of the stores (never both): `stats` = column sums (v, v^2) of what is stored (the host asks
+    // only with act == none); `bb` = the stored value is dout of a fused BatchNorm over bb.y: sums (d, d * y).  One partial pair
+    // per wave and column; the two lane halves fold with one shuffle.  (No row block straddles two cotangent groups: host.)
+    const bool st_on = a.stats && !to_slab, bb_on = a.bb.y && !to_slab;
+    const long pidx = (long)bx * T::WM + wm;
+    const int yrow0 = bb_on ? m0 % a.bb.rows_per_group : 0;  // the block's first row inside its group
 #pragma unroll
     for (int tn = 0; tn < T::TN; ++tn) {
         const int n = n0 + wn * T::TN * 32 + tn * 32 + l31;
         if (n >= N) continue;
         const float bv = (!to_slab && ep.bias) ? ep.bias[n] : 0.f;
+        const float sc = bb_on ? a.bb.scale[n] : 0.f, sh = bb_on ? a.bb.shift[n] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int tm = 0; tm < T::TM; ++tm)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * T::TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int ml = wm * T::TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;  // row inside the block
+                const int m = m0 + ml;
                 const float v = acc[tm * T::TN + tn][r];
-                if (m < M) out[(long)m * N + n] = to_slab ? v : apply_act(v + bv, ep.act, ep.slope);
+                if (m < M) {
+                    const float o = to_slab ? v : apply_act(v + bv, ep.act, ep.slope);
+                    out[(long)m * N + n] = o;
+                    if (st_on) {
+                        s1 += o;
+                        s2 = fmaf(o, o, s2);
+                    } else if (bb_on) {
+                        const float yv = a.bb.y[(long)(yrow0 + ml) * N + n];
+                        const float d = v * (fmaf(yv, sc, sh) > 0.f ? 1.f : a.bb.slope);
+                        s1 += d;
+                        s2 = fmaf(d, yv, s2);
+                    }
+                }
             }
+        if (st_on || bb_on) {
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (half == 0) {
+                float* P = st_on ? a.stats : a.bb.part;
+                P[(pidx * 2 + 0) * N + n] = s1;
+                P[(pidx * 2 + 1) * N + n] = s2;
+            }
+        }
     }
 }
 
@@ -542,24 +499,24 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
     const int lane = t & 63, half = lane >> 5, l31 = lane & 31;
     const bool to_slab = slab != nullptr;
     float* out = to_slab ? slab + (long)split * total : Y;
-    if (a.stats && !to_slab)
-        col_stats_store<T::TM, T::TN>(acc, ep.bias, a.stats, ((long)cls * a.stats_gx + bx) * T::WM + wm, m0 + wm * T::TM * 32,
-                                      n0 + wn * T::TN * 32, M, N);
-    if (a.bb.y && !to_slab) {
+    // fused BatchNorm side products of the stores (see igemm2_fwd_body); the output pixel p is computed once for both
+    const bool st_on = a.stats && !to_slab, bb_on = a.bb.y && !to_slab;
+    long pidx = ((long)cls * a.stats_gx + bx) * T::WM + wm;
+    long ybase = 0;  // first pixel of the block's cotangent group
+    if (bb_on) {
         // classes are equally large and no row block straddles two cotangent groups (host): group gi owns bpg row blocks of
         // every class; its partials are [gi * ppg, (gi + 1) * ppg), ordered (class, block in group, wave row)
-        const int ncls_ = s * s, bpg = a.bb.ppg / (ncls_ * T::WM), gi = bx / bpg;
-        const long pidx = (long)gi * a.bb.ppg + ((long)cls * bpg + (bx - gi * bpg)) * T::WM + wm;
-        const int mw = m0 + wm * T::TM * 32, hwc = Hoc * Woc;
-        const long ppg_pix = (long)a.bb.rows_per_group;  // pixels of one group in the full output grid
-        col_bnbwd_store<T::TM, T::TN>(acc, a.bb, pidx, n0 + wn * T::TN * 32, N, [&](int tm, int r, int hf) -> long {
-            const int m = mw + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
-            if (m >= M) return -1L;
-            const int img = m / hwc, rem = m - img * hwc;
-            const int hc = rem / Woc, wc = rem - hc * Woc;
-            const long p = ((long)img * g.Ho + (hc * s + ph)) * g.Wo + (wc * s + pw);
-            return p % ppg_pix;
-        });
+        const int bpg = a.bb.ppg / (s * s * T::WM), gi = bx / bpg;
+        pidx = (long)gi * a.bb.ppg + ((long)cls * bpg + (bx - gi * bpg)) * T::WM + wm;
+        ybase = (long)gi * a.bb.rows_per_group;
+    }
+    float sc[T::TN], sh[T::TN], s1[T::TN], s2[T::TN];
+#pragma unroll
+    for (int tn = 0; tn < T::TN; ++tn) {
+        const int n = n0 + wn * T::TN * 32 + tn * 32 + l31;
+        sc[tn] = (bb_on && n < N) ? a.bb.scale[n] : 0.f;
+        sh[tn] = (bb_on && n < N) ? a.bb.shift[n] : 0.f;
+        s1[tn] = s2[tn] = 0.f;
     }
 #pragma unroll
     for (int tm = 0; tm < T::TM; ++tm)
@@ -577,9 +534,31 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
                 if (n >= N) continue;
                 const float bv = (!to_slab && ep.bias) ? ep.bias[n] : 0.f;
                 const float v = acc[tm * T::TN + tn][r];
-                out[p * N + n] = to_slab ? v : apply_act(v + bv, ep.act, ep.slope);
+                const float o = to_slab ? v : apply_act(v + bv, ep.act, ep.slope);
+                out[p * N + n] = o;
+                if (st_on) {
+                    s1[tn] += o;
+                    s2[tn] = fmaf(o, o, s2[tn]);
+                } else if (bb_on) {
+                    const float yv = a.bb.y[(p - ybase) * N + n];
+                    const float d = v * (fmaf(yv, sc[tn], sh[tn]) > 0.f ? 1.f : a.bb.slope);
+                    s1[tn] += d;
+                    s2[tn] = fmaf(d, yv, s2[tn]);
+                }
             }
         }
+    if (st_on || bb_on) {
+        float* P = st_on ? a.stats : a.bb.part;
+#pragma unroll
+        for (int tn = 0; tn < T::TN; ++tn) {
+            const int n = n0 + wn * T::TN * 32 + tn * 32 + l31;
+            const float t1 = s1[tn] + __shfl_xor(s1[tn], 32, 64), t2 = s2[tn] + __shfl_xor(s2[tn], 32, 64);
+            if (half == 0 && n < N) {
+                P[(pidx * 2 + 0) * N + n] = t1;
+                P[(pidx * 2 + 1) * N + n] = t2;
+            }
+        }
+    }
 }
 
 template <int BM, int BN>

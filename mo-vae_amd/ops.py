@@ -252,6 +252,9 @@ class ConvFusion:
 
 #: (entry point, geometry) for which the library answered "unsupported" to a fused input transform: not asked again
 _NO_FUSE = set()
+#: A/B knobs of the fusion's three parts (development): the normalise-on-load of consumers, the statistics from producer epilogues
+FUSE_NORM = __import__("os").environ.get("MOVAE_FUSE_NORM", "1") != "0"
+FUSE_STATS = __import__("os").environ.get("MOVAE_FUSE_STATS", "1") != "0"
 
 
 def _fuse_struct(in_norm, stats=None, bn=None):
@@ -325,10 +328,10 @@ class Conv(Function):
         if fusion is not None and fusion.in_scale is not None:
             in_norm = (fusion.in_scale, fusion.in_shift, fusion.in_slope)
         stats = None
-        if fusion is not None and fusion.want_stats and not L.ACT[act]:
+        if fusion is not None and fusion.want_stats and not L.ACT[act] and FUSE_STATS:
             # room for the finest partial granularity of any producer (a pair per 32-row wave tile; per 8 rows in the reduce)
             stats = torch.empty((n * ho * wo // 8 + 64) * 2 * co, dtype=torch.float32, device=x.device)
-        if in_norm is not None and (fn, geom) in _NO_FUSE:
+        if in_norm is not None and ((fn, geom) in _NO_FUSE or not FUSE_NORM):
             x, in_norm = scale_shift_act(x, *in_norm), None
         if in_norm is None and stats is None:
             _call(fn, x.data_ptr(), wm.data_ptr(), L.ptr(b), y.data_ptr(), *geom, L.ACT[act], float(slope), wsp, wsb, _st(x))
@@ -670,13 +673,13 @@ class BatchNormLazy(Function):
         rows = y.numel() // c
         st = _st(y)
         if not parts:
-            stats = torch.empty(1025 * 2 * c, dtype=torch.float32, device=y.device)  # movae_bn_stats: at most 1024 partials
+            stats = torch.empty(1100 * 2 * c, dtype=torch.float32, device=y.device)  # movae_bn_stats: at most 1024 partials (+ room to fold them)
             pout = C.c_int(0)
             _call("movae_bn_stats", y.data_ptr(), rows, c, stats.data_ptr(), stats.numel(), C.byref(pout), st)
             parts = pout.value
         mean = torch.empty(c, dtype=y.dtype, device=y.device)
         rstd, scale, shift = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
-        _call("movae_bn_finalize", stats.data_ptr(), int(parts), rows, c, gamma.data_ptr(), beta.data_ptr(), float(eps), float(momentum),
+        _call("movae_bn_finalize", stats.data_ptr(), stats.numel(), int(parts), rows, c, gamma.data_ptr(), beta.data_ptr(), float(eps), float(momentum),
               mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), L.ptr(running_mean), L.ptr(running_var),
               L.ptr(num_batches_tracked), st)
         ctx.act, ctx.slope = ("lrelu" if slope not in _ACT_OF_SLOPE else _ACT_OF_SLOPE[slope]), slope
@@ -701,7 +704,7 @@ class BatchNormLazy(Function):
         coef = torch.empty((G, 3, c), dtype=y.dtype, device=y.device)
         arr = C.c_void_p * G
         st = _st(y)
-        _call("movae_bn_bwd_finalize", part.data_ptr(), ppg, G, rows, c, gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+        _call("movae_bn_bwd_finalize", part.data_ptr(), part.numel(), ppg, G, rows, c, gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
               arr(*[t.data_ptr() for t in dgs]), arr(*[t.data_ptr() for t in dbs]), coef.data_ptr(), 0, st)
         dy = torch.empty_like(dout)
         _call("movae_bn_bwd_apply", dout.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr(), float(ctx.slope), coef.data_ptr(),
