@@ -56,7 +56,16 @@ __device__ __forceinline__ f32x4 norm_apply(f32x4 v, const f32x4 sc, const f32x4
     }
     return v;
 }
-
+// branch-free form for the staging loops: padding / out-of-range chunks (valid == false) stay exactly zero
+__device__ __forceinline__ float norm1(float v, float sc, float sh, float slope, float keep) {
+    const float z = fmaf(v, sc, sh);
+    return keep * (fmaxf(z, 0.f) + slope * fminf(z, 0.f));
+}
+__device__ __forceinline__ f32x4 norm_apply_if(bool valid, const f32x4 v, const f32x4 sc, const f32x4 sh, float slope) {
+    const float keep = valid ? 1.f : 0.f;
+    return f32x4{norm1(v[0], sc[0], sh[0], slope, keep), norm1(v[1], sc[1], sh[1], slope, keep), norm1(v[2], sc[2], sh[2], slope, keep),
+                 norm1(v[3], sc[3], sh[3], slope, keep)};
+}
 
 // The result of an input-gradient pass is `dout`, the gradient w.r.t. the (never materialised) output of a fused BatchNorm +
 // activation over the raw conv output y: the epilogue also emits that BatchNorm's backward sums, per column and cotangent

@@ -219,7 +219,7 @@ __device__ __forceinline__ void igemm2_fwd_body(const FwdArgs& a, float* __restr
         if (nsc) {
 #pragma unroll
             for (int i = 0; i < AC; ++i)
-                if ((amask >> i) & 1u) ra[i] = norm_apply(ra[i], nsa, nsb, nslope);
+                ra[i] = norm_apply_if((amask >> i) & 1u, ra[i], nsa, nsb, nslope);
         }
 #pragma unroll
         for (int i = 0; i < AC; ++i) *reinterpret_cast<f32x4*>(As + buf * ASZ + (r8 + RPP * i) * LDR + kq * 4) = ra[i];
@@ -275,6 +275,19 @@ __device__ __forceinline__ void igemm2_fwd_body(const FwdArgs& a, float* __restr
         const float bv = (!to_slab && ep.bias) ? ep.bias[n] : 0.f;
         const float sc = bb_on ? a.bb.scale[n] : 0.f, sh = bb_on ? a.bb.shift[n] : 0.f;
         float s1 = 0.f, s2 = 0.f;
+        // all of the column's y values are requested BEFORE the first store: `out` and `y` may alias as far as the compiler
+        // knows, so a load placed after a store waits for it -- sixteen serial round trips per tile otherwise
+        float yv[T::TM * 16];
+        if (bb_on) {
+            const float* __restrict__ yp = a.bb.y;
+#pragma unroll
+            for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = wm * T::TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    yv[tm * 16 + r] = (m0 + ml < M) ? yp[(long)(yrow0 + ml) * N + n] : 0.f;
+                }
+        }
 #pragma unroll
         for (int tm = 0; tm < T::TM; ++tm)
 #pragma unroll
@@ -289,10 +302,10 @@ __device__ __forceinline__ void igemm2_fwd_body(const FwdArgs& a, float* __restr
                         s1 += o;
                         s2 = fmaf(o, o, s2);
                     } else if (bb_on) {
-                        const float yv = a.bb.y[(long)(yrow0 + ml) * N + n];
-                        const float d = v * (fmaf(yv, sc, sh) > 0.f ? 1.f : a.bb.slope);
+                        const float y1 = yv[tm * 16 + r];
+                        const float d = v * (fmaf(y1, sc, sh) > 0.f ? 1.f : a.bb.slope);
                         s1 += d;
-                        s2 = fmaf(d, yv, s2);
+                        s2 = fmaf(d, y1, s2);
                     }
                 }
             }
@@ -459,7 +472,7 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
         if (nsc) {
 #pragma unroll
             for (int i = 0; i < AC; ++i)
-                if ((amask >> i) & 1u) ra[i] = norm_apply(ra[i], nsa, nsb, nslope);
+                ra[i] = norm_apply_if((amask >> i) & 1u, ra[i], nsa, nsb, nslope);
         }
 #pragma unroll
         for (int i = 0; i < AC; ++i) *reinterpret_cast<f32x4*>(As + buf * ASZ + (r8 + RPP * i) * LDR + kq * 4) = ra[i];
@@ -518,16 +531,37 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
         sh[tn] = (bb_on && n < N) ? a.bb.shift[n] : 0.f;
         s1[tn] = s2[tn] = 0.f;
     }
+    // output pixel of every accumulator row, computed once (three integer divisions each); -1 = past the class's rows
+    int pix[T::TM * 16];
 #pragma unroll
     for (int tm = 0; tm < T::TM; ++tm)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm * T::TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (m >= M) continue;
             const int hw = Hoc * Woc;
             const int img = m / hw, rem = m - img * hw;
             const int hc = rem / Woc, wc = rem - hc * Woc;
-            const long p = ((long)img * g.Ho + (hc * s + ph)) * g.Wo + (wc * s + pw);
+            pix[tm * 16 + r] = m < M ? (img * g.Ho + (hc * s + ph)) * g.Wo + (wc * s + pw) : -1;
+        }
+    // BnBwd: every y value is requested before the first store (see igemm2_fwd_body)
+    float yv[T::TM * 16 * T::TN];
+    if (bb_on) {
+        const float* __restrict__ yp = a.bb.y;
+#pragma unroll
+        for (int i = 0; i < T::TM * 16; ++i)
+#pragma unroll
+            for (int tn = 0; tn < T::TN; ++tn) {
+                const int n = n0 + wn * T::TN * 32 + tn * 32 + l31;
+                yv[i * T::TN + tn] = (pix[i] >= 0 && n < N) ? yp[((long)pix[i] - ybase) * N + n] : 0.f;
+            }
+    }
+#pragma unroll
+    for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int pi = pix[tm * 16 + r];
+            if (pi < 0) continue;
+            const long p = pi;
 #pragma unroll
             for (int tn = 0; tn < T::TN; ++tn) {
                 const int n = n0 + wn * T::TN * 32 + tn * 32 + l31;
@@ -540,10 +574,10 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
                     s1[tn] += o;
                     s2[tn] = fmaf(o, o, s2[tn]);
                 } else if (bb_on) {
-                    const float yv = a.bb.y[(p - ybase) * N + n];
-                    const float d = v * (fmaf(yv, sc[tn], sh[tn]) > 0.f ? 1.f : a.bb.slope);
+                    const float y1 = yv[(tm * 16 + r) * T::TN + tn];
+                    const float d = v * (fmaf(y1, sc[tn], sh[tn]) > 0.f ? 1.f : a.bb.slope);
                     s1[tn] += d;
-                    s2[tn] = fmaf(d, yv, s2[tn]);
+                    s2[tn] = fmaf(d, y1, s2[tn]);
                 }
             }
         }
@@ -683,14 +717,16 @@ __device__ __forceinline__ void igemm2_wgrad_body(const WgArgs& a, float* __rest
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     const int wave = t >> 6, wm = wave / T::WN, wn = wave % T::WN;
     auto store_tile = [&](int buf) {
+        // (two separate ifs with a compiler barrier between them: as an if / else over equally long arrays the two arms are merged
+        // into one loop over a run-time selected array, which moves ra / rb to scratch memory)
         if (nside == 1) {
 #pragma unroll
-            for (int i = 0; i < ACH; ++i)
-                if ((vmask >> i) & 1u) ra[i] = norm_apply(ra[i], nsa, nsb, nslope);
-        } else if (nside == 2) {
+            for (int i = 0; i < ACH; ++i) ra[i] = norm_apply_if((vmask >> i) & 1u, ra[i], nsa, nsb, nslope);
+        }
+        asm volatile("");
+        if (nside == 2) {
 #pragma unroll
-            for (int i = 0; i < BCH; ++i)
-                if ((vmask >> i) & 1u) rb[i] = norm_apply(rb[i], nsa, nsb, nslope);
+            for (int i = 0; i < BCH; ++i) rb[i] = norm_apply_if((vmask >> i) & 1u, rb[i], nsa, nsb, nslope);
         }
 #pragma unroll
         for (int i = 0; i < ACH; ++i) *reinterpret_cast<f32x4*>(As + buf * ASZ + (ak + AKS * i) * T::LDKA + aq * 4) = ra[i];

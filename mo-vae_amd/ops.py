@@ -1082,13 +1082,16 @@ class VectorQuantize(Function):
         rows = x.numel() // d
         dq = _c(dq) if dq is not None else None
         need_x, need_e = ctx.needs_input_grad
-        dx = torch.empty_like(x) if need_x else None
+        # a cotangent that reaches neither the straight-through output nor the commitment term (the embedding loss alone) has NO
+        # gradient w.r.t. x: None, not a tensor of zeros -- mtl_backward then skips that loss's pull-back through the encoder
+        # (a zero Jacobian row costs nothing); likewise no codebook gradient without an embedding-loss cotangent
+        dx = torch.empty_like(x) if (need_x and (dq is not None or gc is not None)) else None
         de = torch.empty((k, d), dtype=x.dtype, device=x.device) if (need_e and ge is not None) else None
+        if dx is None and de is None:
+            return None, None
         wsp, wsb = _ws(x)
         _call("movae_vq_bwd", x.data_ptr(), q.data_ptr(), idx.data_ptr(), L.ptr(dq), L.ptr(_c(gc) if gc is not None else None),
               L.ptr(_c(ge) if ge is not None else None), L.ptr(dx), L.ptr(de), rows, k, d, wsp, wsb, _st(x))
-        if need_e and de is None:
-            de = torch.zeros((k, d), dtype=x.dtype, device=x.device)
         return dx, de
 
 
