@@ -73,6 +73,8 @@ def _ones_like(t):
 def _accumulate(p, g):
     if p.grad is None:
         p.grad = g
+    elif g.data_ptr() == p.grad.data_ptr() and g.shape == p.grad.shape:
+        pass  # the kernels already added this loss's gradient into p.grad (ops.GRAD_ACCUM)
     else:
         ops.join_wgrad()  # both operands may still be in flight on the weight-gradient side stream
         p.grad = p.grad + g
@@ -304,7 +306,14 @@ def mtl_backward_begin(losses, features, aggregator, tasks_params=None, shared_p
         tp = list(tp)
         # the seed cotangent is a persistent ones tensor: autograd would launch a fill per loss for its implicit ones_like
         seed = _ones_like(loss) if loss.dim() == 0 and loss.dtype == torch.float32 else None
-        got = torch.autograd.grad(loss, tp + st.feat_diff, grad_outputs=seed, retain_graph=True, allow_unused=True)
+        # task-side parameters an earlier loss already reached get this loss's gradient added inside the weight-gradient kernels
+        ops.GRAD_ACCUM.clear()
+        if i > 0 and ops.L.DEFER is None:
+            ops.GRAD_ACCUM.update({p.data_ptr(): p.grad for p in tp if p.grad is not None})
+        try:
+            got = torch.autograd.grad(loss, tp + st.feat_diff, grad_outputs=seed, retain_graph=True, allow_unused=True)
+        finally:
+            ops.GRAD_ACCUM.clear()
         for p, g in zip(tp, got[: len(tp)]):
             if g is not None:
                 _accumulate(p, g)

@@ -29,6 +29,29 @@ def _sink(param, shape):
     return torch.empty(shape, dtype=param.dtype, device=param.device)
 
 
+#: data_ptr of a parameter -> its EXISTING gradient tensor: the weight-gradient kernels add into it (split-K reduce with
+#: accumulate) instead of writing a fresh tensor that a torch add then folds in.  autojac.mtl_backward_begin sets this for the
+#: task-side parameters that an earlier loss already reached (torchjd sums the per-loss gradients of those).
+GRAD_ACCUM = {}
+
+
+def _accum_targets(w, b, need_b):
+    """(dW destination in memory order, dbias destination) when BOTH of a layer's gradients can be accumulated in place."""
+    if not GRAD_ACCUM:
+        return None, None
+    gw = GRAD_ACCUM.get(w.data_ptr())
+    gb = GRAD_ACCUM.get(b.data_ptr()) if (b is not None and need_b) else None
+    if gw is None or (b is not None and need_b and gb is None):
+        return None, None
+    v = gw.permute(0, 2, 3, 1) if gw.dim() == 4 else gw
+    if not v.is_contiguous() or gw.shape != w.shape:
+        return None, None
+    GRAD_ACCUM.pop(w.data_ptr(), None)
+    if gb is not None:
+        GRAD_ACCUM.pop(b.data_ptr(), None)
+    return v, gb
+
+
 #: batched pull-back (autojac._batched_pullback): one sink dict per cotangent group, same keys as GRAD_SINK
 GRAD_SINK_ROWS = None
 
@@ -441,7 +464,11 @@ class Conv(Function):
             wsp, wsb, st = ws2.data_ptr(), ws2.numel(), side.cuda_stream
         if need_w:
             wm_shape = (ci, kh, kw, co) if ctx.transposed else (co, kh, kw, ci)
-            dwm = _sink(w, wm_shape)
+            # a task-side parameter that an earlier loss already reached: add into its gradient inside the kernels' reduce
+            plain_bias = ctx.has_bias and ctx.needs_input_grad[2] and db_done is None and not ctx.bias_grad_is_zero
+            acc_w, acc_b = _accum_targets(w, b, plain_bias) if (db_done is None and not (ctx.has_bias and ctx.bias_grad_is_zero)) else (None, None)
+            acc = 1 if acc_w is not None else 0
+            dwm = acc_w.view(wm_shape) if acc else _sink(w, wm_shape)
             db_k = None
             if db_done is not None:
                 db = db_done
@@ -451,9 +478,9 @@ class Conv(Function):
                     # identically (the reference's value is rounding noise of order 1e-9); no column-sum pass
                     db = _sink_zeros(b, (co,))
                 else:
-                    db = db_k = _sink(b, (co,))
+                    db = db_k = (acc_b if acc else _sink(b, (co,)))
             dbp = (C.c_void_p * 1)(db_k.data_ptr()) if db_k is not None else None
-            tail = (n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, 0, wsp, wsb, st)
+            tail = (n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, acc, wsp, wsb, st)
             if pair:
                 x, f = Conv._wgrad_call(pre + "dgrad_wgrad_grouped", in_norm, ctx.geom,
                                         ((1, dy, wm, x, dx, (C.c_void_p * 1)(dwm.data_ptr()), dbp), 3, tail), bn)
@@ -686,6 +713,7 @@ class BatchNormLazy(Function):
         ctx.link = link
         ctx.save_for_backward(y, gamma, beta, mean, rstd, scale, shift)
         ctx.mark_non_differentiable(scale, shift)
+        ctx.set_materialize_grads(False)  # no zero-fill launches for the two auxiliary outputs' (never used) gradients
         return y.view_as(y), scale, shift
 
     @staticmethod
@@ -713,6 +741,8 @@ class BatchNormLazy(Function):
 
     @staticmethod
     def backward(ctx, dout, _ds, _dh):
+        if dout is None:
+            return (None,) * 12
         y, gamma, beta, mean, rstd = ctx.saved_tensors[:5]
         dout = _c(dout)
         c = y.shape[-1]
