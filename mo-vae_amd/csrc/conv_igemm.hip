@@ -35,6 +35,27 @@ struct Epilogue {
     float slope;
 };
 
+// Division by a launch-invariant divisor inside the k loops (tap / pixel decoding of the gathers): n / d for 0 <= n < 2^31 as
+// one v_mul_hi + one shift instead of the ~35-instruction software division (the 128x128 kernels issued 4-8 VALU instructions
+// per MFMA, most of them these divisions; PMC: profiles/r02_pmc_igemm128.json).  m = ceil(2^(31+s) / d), s = ceil(log2 d):
+// exact because the rounding error of m, < d <= 2^s, times n < 2^31 stays below 2^(31+s).
+struct FastDiv {
+    unsigned mul, shift, d;
+};
+inline FastDiv fastdiv_make(int d) {
+    FastDiv f{0u, 0u, d > 0 ? (unsigned)d : 1u};
+    if (d <= 1) return f;
+    unsigned s = 0;
+    while ((1u << s) < (unsigned)d) ++s;
+    const unsigned long long p = 31ull + s;
+    f.mul = (unsigned)(((1ull << p) + (unsigned long long)d - 1ull) / (unsigned long long)d);
+    f.shift = s - 1u;
+    return f;
+}
+__device__ __forceinline__ int fdiv(int n, const FastDiv& f) {
+    return f.d == 1u ? n : (int)(__umulhi((unsigned)n, f.mul) >> f.shift);
+}
+
 // Fusion of a training-mode BatchNorm (+ LeakyReLU / ReLU) into its neighbours:
 //  * Norm -- the gathered activation operand is VIRTUAL: the kernel reads the producer's raw conv output y and applies
 //    x = act(scale[c] * y + shift[c]) (scale = gamma * rstd, shift = beta - mean * scale, act = leaky-ReLU with `slope`;

@@ -123,6 +123,7 @@ struct FwdArgs {
     Norm nrm;      // virtual gathered operand (zero-initialised: plain)
     float* stats;  // column partial sums of the stored result [gx * WM][2][N], or null (only without split-K)
     BnBwd bb;      // the result is a fused BatchNorm's output gradient: its backward sums (only without split-K)
+    FastDiv fd_cr, fd_kw, fd_wlen;  // divisions of the k loop: by g.Cr, g.KW, g.wlen
 };
 
 template <int BM, int BN>
@@ -190,8 +191,8 @@ __device__ __forceinline__ void igemm2_fwd_body(const FwdArgs& a, float* __restr
         const int k = kt * BK2 + kq * 4;
         const bool kv = k < K;
         const int kk = kv ? k : 0;
-        const int tap = kk / g.Cr, c = kk - tap * g.Cr;
-        const int kh = tap / g.KW, kw = tap - kh * g.KW;
+        const int tap = fdiv(kk, a.fd_cr), c = kk - tap * g.Cr;
+        const int kh = fdiv(tap, a.fd_kw), kw = tap - kh * g.KW;
         amask = 0;
 #pragma unroll
         for (int i = 0; i < AC; ++i) {
@@ -204,7 +205,11 @@ __device__ __forceinline__ void igemm2_fwd_body(const FwdArgs& a, float* __restr
             nsa = *reinterpret_cast<const f32x4*>(nsc + c);
             nsb = *reinterpret_cast<const f32x4*>(nsh + c);
         }
-        const int kb = g.wlen ? (kk / g.wlen) * g.wstride + kk % g.wlen : kk;  // window row -> stored kernel row
+        int kb = kk;  // window row -> stored kernel row
+        if (g.wlen) {
+            const int wr = fdiv(kk, a.fd_wlen);
+            kb = wr * g.wstride + (kk - wr * g.wlen);
+        }
 #pragma unroll
         for (int i = 0; i < BC; ++i) rb[i] = (kv && b_ok[i]) ? *reinterpret_cast<const f32x4*>(b_base[i] + kb) : ZERO4;
     };
@@ -341,6 +346,8 @@ struct BwdArgs {
     float* stats;  // [classes * gx * WM][2][N] or null (only without split-K)
     int stats_gx;  // row blocks per class (the launch's grid x) -- the partial index is (class * gx + bx) * WM + wave row
     BnBwd bb;      // backward sums of a fused BatchNorm (only without split-K; ppg = classes * (gx / groups) * WM)
+    FastDiv fd_cr;         // k loop: by g.Cr
+    FastDiv fd_hw[4], fd_w[4];  // epilogue, per output-parity class: by Hoc * Woc and by Woc
 };
 
 template <int BM, int BN>
@@ -352,6 +359,7 @@ struct BwdSmem {
 template <int BM, int BN>
 __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restrict__ smem, int bx, int by, int bz) {
     using T = T2<BM, BN>;
+    const BwdArgs& a_ = a;  // (the tap loops below name a local `a`)
     constexpr int ASZ = BM * LDR, BSZ = BK2 * T::LDKB;
     float* As = smem;
     float* Bs = smem + (T::DB ? 2 : 1) * ASZ;
@@ -432,8 +440,8 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
             const int k = kt * BK2 + kq * 4;
             const bool kv = k < K;
             const int kk = kv ? k : 0;
-            const int tt = kk / g.Cr, c = kk - tt * g.Cr;
-            const int a = tt / nBd, b = tt - a * nBd;
+            const int tt = fdiv(kk, a_.fd_cr), c = kk - tt * g.Cr;
+            const int a = nBd == 1 ? tt : (nBd == 2 ? tt >> 1 : tt / nBd), b = tt - a * nBd;
             amask = 0;
 #pragma unroll
             for (int i = 0; i < AC; ++i) {
@@ -452,8 +460,8 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
             const int k = kt * BK2 + bk + KSTEP * i;
             const bool kv = k < K && bn_ok;
             const int kk = k < K ? k : 0;
-            const int tt = kk / g.Cr, c = kk - tt * g.Cr;
-            const int a = tt / nBd, b = tt - a * nBd;
+            const int tt = fdiv(kk, a_.fd_cr), c = kk - tt * g.Cr;
+            const int a = nBd == 1 ? tt : (nBd == 2 ? tt >> 1 : tt / nBd), b = tt - a * nBd;
             const int kh = kh0 + s * a, kw = kw0 + s * b;
             rb[i] = kv ? *reinterpret_cast<const f32x4*>(W + ((long)c * taps + kh * g.KW + kw) * N + bn) : ZERO4;
         }
@@ -539,8 +547,8 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm * T::TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             const int hw = Hoc * Woc;
-            const int img = m / hw, rem = m - img * hw;
-            const int hc = rem / Woc, wc = rem - hc * Woc;
+            const int img = fdiv(m, a.fd_hw[cls]), rem = m - img * hw;
+            const int hc = fdiv(rem, a.fd_w[cls]), wc = rem - hc * Woc;
             pix[tm * 16 + r] = m < M ? (img * g.Ho + (hc * s + ph)) * g.Wo + (wc * s + pw) : -1;
         }
     // BnBwd: every y value is requested before the first store (see igemm2_fwd_body)
@@ -618,6 +626,7 @@ struct WgArgs {
     WOut tab;
     Norm nrm;      // virtual activation operand ...
     int nrm_side;  // ... 1: the small-side operand Sm (transposed-conv x), 2: the gathered operand Bg (conv x); 0: none
+    FastDiv fd_hw, fd_ws;  // k loop (pixel -> image, row, column): by g.Hs * g.Ws and by g.Ws
 };
 
 template <int BM, int BN>
@@ -701,8 +710,8 @@ __device__ __forceinline__ void igemm2_wgrad_body(const WgArgs& a, float* __rest
             const int k = k0 + bk + BKS * i;
             const bool kv = k < k_end && bn_ok;
             const int kk = k < k_end ? k : k_begin;
-            const int img = kk / hw, rem = kk - img * hw;
-            const int hs = rem / g.Ws, ws = rem - hs * g.Ws;
+            const int img = fdiv(kk, a.fd_hw), rem = kk - img * hw;
+            const int hs = fdiv(rem, a.fd_ws), ws = rem - hs * g.Ws;
             const int h = hs * g.stride - g.pad + b_kh, w = ws * g.stride - g.pad + b_kw;
             const bool v = kv && h >= 0 && h < g.Hb && w >= 0 && w < g.Wb;
             rb[i] = v ? *reinterpret_cast<const f32x4*>(Bg + (((long)img * g.Hb + h) * g.Wb + w) * g.Cb + b_c) : ZERO4;
@@ -906,6 +915,7 @@ int launch_fwd2(const float* X, const float* W, float* Y, const Geom& g, const E
     S = ceil_div(nk, per_split);
     float* slab = S > 1 ? static_cast<float*>(ws) : nullptr;
     FwdArgs a{X, W, Y, g, ep, M, K, per_split, slab};
+    a.fd_cr = fastdiv_make(g.Cr), a.fd_kw = fastdiv_make(g.KW), a.fd_wlen = fastdiv_make(g.wlen > 0 ? g.wlen : 1);
     a.nrm = g_fuse.nrm;
     // statistics of the result for the BatchNorm that follows (never on a backward pass: those are the paired / collected ones)
     const bool want_stats = g_fuse.stats && ep.act == MOVAE_ACT_NONE && !g_pair_collect;
@@ -1009,6 +1019,12 @@ int launch_bwd2(const float* X, const float* W, float* Y, const Geom& g, const E
         return MOVAE_EINVAL;
     }
     BwdArgs a{X, W, Y, g, ep, scls, kps, slab, total};
+    a.fd_cr = fastdiv_make(g.Cr);
+    for (int c = 0; c < 4; ++c) {
+        const int ph = c / s, pw = c % s;
+        const int Hoc = c < ncls ? (g.Ho - ph + s - 1) / s : 1, Woc = c < ncls ? (g.Wo - pw + s - 1) / s : 1;
+        a.fd_hw[c] = fastdiv_make(Hoc * Woc > 0 ? Hoc * Woc : 1), a.fd_w[c] = fastdiv_make(Woc > 0 ? Woc : 1);
+    }
     a.nrm = g_fuse.nrm;
     a.stats_gx = gx;
     const bool want_stats = g_fuse.stats && ep.act == MOVAE_ACT_NONE && !g_pair_collect;
@@ -1086,6 +1102,7 @@ int launch_wgrad2(const float* Sm, const float* Bg, float* const* dW, int G, lon
     for (int i = 0; i < 8; ++i) tab.p[i] = i < G ? dW[i] : nullptr;
     float* out = slab ? static_cast<float*>(ws) : nullptr;
     WgArgs a{Sm, Bg, out, g, K, kchunk, slab ? 1 : 0, Sp, s_gs, b_gs, tab};
+    a.fd_hw = fastdiv_make(g.Hs * g.Ws), a.fd_ws = fastdiv_make(g.Ws);
     a.nrm = g_fuse.nrm;  // virtual activation operand: Sm (transposed-conv x) or Bg (conv x), as the entry point says
     a.nrm_side = g_fuse.nrm_side;
     PendingDgrad& p = g_pending;

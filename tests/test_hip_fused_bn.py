@@ -13,7 +13,13 @@ pytestmark = pytest.mark.gpu
 def _close(got, want, what, rtol=2e-4, atol=2e-5):
     got = got.detach().cpu().float().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
     want = want.detach().cpu().float().numpy() if isinstance(want, torch.Tensor) else np.asarray(want)
-    np.testing.assert_allclose(got, want, rtol=rtol, atol=atol * max(1.0, float(np.abs(want).max())), err_msg=what)
+    tol = atol * max(1.0, float(np.abs(want).max())) + rtol * np.abs(want)
+    bad = np.argwhere(np.abs(got - want) > tol)
+    where = ""
+    if len(bad):  # which slices of each axis hold the mismatches: a tile-shaped pattern names the kernel and the block
+        where = f" | {len(bad)} mismatches; per axis: " + "; ".join(
+            f"ax{a}: {np.unique(bad[:, a])[:12].tolist()}{'...' if len(np.unique(bad[:, a])) > 12 else ''}" for a in range(bad.shape[1]))
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=atol * max(1.0, float(np.abs(want).max())), err_msg=what + where)
 
 
 # (name, producer, consumer, batch, size, cin, cmid, cout): producer / consumer are ("conv" | "convT", k, stride, pad, out_pad)
@@ -52,17 +58,28 @@ def test_conv_bn_act_conv_chain(case, fused, gpu_device, monkeypatch):
 
     name, (k1, ks1, s1, p1, op1), (k2, ks2, s2, p2, op2), B, size, cin, cmid, cout = case
     monkeypatch.setattr(mnn, "FUSE_BN", fused)
-    g = torch.Generator().manual_seed(hash(name) % 1000)
-    x = torch.randn(B, cin, size, size, generator=g)
-    w1, b1 = _mk(k1, cin, cmid, ks1, g)
-    w2, b2 = _mk(k2, cmid, cout, ks2, g)
-    gamma, beta = torch.rand(cmid, generator=g) + 0.5, torch.randn(cmid, generator=g) * 0.2
-    # ---- fp32 reference on the CPU ----
-    xr = x.clone().requires_grad_(True)
-    pr = [t.clone().requires_grad_(True) for t in (w1, b1, gamma, beta, w2, b2)]
-    rm, rv = torch.zeros(cmid), torch.ones(cmid)
-    y1 = _ref_conv(k1, xr, pr[0], pr[1], ks1, s1, p1, op1)
-    h = F.leaky_relu(F.batch_norm(y1, rm, rv, pr[2], pr[3], training=True, momentum=0.1, eps=1e-5), 0.01)
+    import zlib
+
+    seed = zlib.crc32(name.encode()) % 1000  # (not hash(): that is salted per process)
+    for attempt in range(50):
+        g = torch.Generator().manual_seed(seed + attempt)
+        x = torch.randn(B, cin, size, size, generator=g)
+        w1, b1 = _mk(k1, cin, cmid, ks1, g)
+        w2, b2 = _mk(k2, cmid, cout, ks2, g)
+        gamma, beta = torch.rand(cmid, generator=g) + 0.5, torch.randn(cmid, generator=g) * 0.2
+        # ---- fp32 reference on the CPU ----
+        xr = x.clone().requires_grad_(True)
+        pr = [t.clone().requires_grad_(True) for t in (w1, b1, gamma, beta, w2, b2)]
+        rm, rv = torch.zeros(cmid), torch.ones(cmid)
+        y1 = _ref_conv(k1, xr, pr[0], pr[1], ks1, s1, p1, op1)
+        z = F.batch_norm(y1, rm, rv, pr[2], pr[3], training=True, momentum=0.1, eps=1e-5)
+        # LeakyReLU' is discontinuous at 0: a pre-activation within rounding distance of zero may legitimately land on either
+        # side in two fp32 implementations, and ONE flipped sign moves that element's gradient by 99 % and, through the batch
+        # means of the BatchNorm backward, its whole channel a little.  Such draws (about one in forty) are not a parity
+        # question: draw again.
+        if float(z.detach().abs().min()) > 1e-6:
+            break
+    h = F.leaky_relu(z, 0.01)
     y2 = _ref_conv(k2, h, pr[4], pr[5], ks2, s2, p2, op2)
     cot = torch.randn(y2.shape, generator=g)
     (y2 * cot).sum().backward()
