@@ -125,6 +125,7 @@ def convT_out_size(h, k, s, p, op):
 class NchwToNhwc(Function):
     @staticmethod
     def forward(ctx, x):
+        ctx.set_materialize_grads(False)  # an absent cotangent arrives as None: no zero-fill, no kernels on zeros
         L.require_gpu(x)
         x = _c(x)
         n, c, h, w = x.shape
@@ -134,6 +135,8 @@ class NchwToNhwc(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if dy is None:
+            return (None,) * 1
         dy = _c(dy)
         n, h, w, c = dy.shape
         dx = torch.empty((n, c, h, w), dtype=dy.dtype, device=dy.device)
@@ -152,6 +155,7 @@ class NchwToNhwc(Function):
 class NhwcToNchw(Function):
     @staticmethod
     def forward(ctx, x):
+        ctx.set_materialize_grads(False)  # an absent cotangent arrives as None: no zero-fill, no kernels on zeros
         L.require_gpu(x)
         x = _c(x)
         n, h, w, c = x.shape
@@ -161,6 +165,8 @@ class NhwcToNchw(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if dy is None:
+            return (None,) * 1
         dy = _c(dy)
         n, c, h, w = dy.shape
         dx = torch.empty((n, h, w, c), dtype=dy.dtype, device=dy.device)
@@ -330,6 +336,7 @@ class Conv(Function):
 
     @staticmethod
     def forward(ctx, x, w, b, stride, pad, out_pad, transposed, act, slope, bias_grad_is_zero=False, fusion=None):
+        ctx.set_materialize_grads(False)  # an absent cotangent arrives as None: no zero-fill, no kernels on zeros
         L.require_gpu(x)
         x = _c(x)
         wm = weight_mem(w)
@@ -418,6 +425,8 @@ class Conv(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if dy is None:
+            return (None,) * 11
         x, w, y, b, in_norm = Conv._saved(ctx)
         dy = _c(dy)
         n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad = ctx.geom
@@ -593,6 +602,7 @@ def linear(x, w, b=None, act=None, slope=0.01):
 class BatchNormAct(Function):
     @staticmethod
     def forward(ctx, y, gamma, beta, running_mean, running_var, training, eps, momentum, act, slope, num_batches_tracked=None):
+        ctx.set_materialize_grads(False)  # an absent cotangent arrives as None: no zero-fill, no kernels on zeros
         L.require_gpu(y)
         y = _c(y)
         c = y.shape[-1]
@@ -611,6 +621,8 @@ class BatchNormAct(Function):
 
     @staticmethod
     def backward(ctx, dout):
+        if dout is None:
+            return (None,) * 11
         y, gamma, beta, mean, rstd = ctx.saved_tensors
         if not ctx.training:
             raise RuntimeError("BatchNormAct backward is implemented for training-mode statistics only")
@@ -673,10 +685,13 @@ class ScaleShiftAct(Function):
 
     @staticmethod
     def forward(ctx, y, scale, shift, slope):
+        ctx.set_materialize_grads(False)  # an absent cotangent arrives as None: no zero-fill, no kernels on zeros
         return scale_shift_act(y, scale, shift, slope)
 
     @staticmethod
     def backward(ctx, dout):
+        if dout is None:
+            return (None,) * 4
         return dout, None, None, None
 
     @staticmethod
@@ -802,6 +817,7 @@ def batch_norm_act(y, gamma, beta, running_mean, running_var, training, eps=1e-5
 class Activation(Function):
     @staticmethod
     def forward(ctx, x, act, slope):
+        ctx.set_materialize_grads(False)  # an absent cotangent arrives as None: no zero-fill, no kernels on zeros
         L.require_gpu(x)
         x = _c(x)
         y = torch.empty_like(x)
@@ -812,6 +828,8 @@ class Activation(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if dy is None:
+            return (None,) * 3
         (y,) = ctx.saved_tensors
         dy = _c(dy)
         dx = torch.empty_like(dy)
@@ -838,6 +856,7 @@ def activation(x, act, slope=0.01):
 class Add(Function):
     @staticmethod
     def forward(ctx, a, b):
+        ctx.set_materialize_grads(False)  # an absent cotangent arrives as None: no zero-fill, no kernels on zeros
         L.require_gpu(a)
         a, b = _c(a), _c(b)
         y = torch.empty_like(a)
@@ -846,6 +865,8 @@ class Add(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if dy is None:
+            return (None,) * 2
         return dy, dy
 
     @staticmethod
@@ -863,6 +884,7 @@ class ConcatChannels(Function):
 
     @staticmethod
     def forward(ctx, a, b):
+        ctx.set_materialize_grads(False)  # an absent cotangent arrives as None: no zero-fill, no kernels on zeros
         L.require_gpu(a)
         a, b = _c(a), _c(b)
         ca, cb = a.shape[-1], b.shape[-1]
@@ -876,6 +898,8 @@ class ConcatChannels(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if dy is None:
+            return (None,) * 2
         dy = _c(dy)
         ca, cb = ctx.ca, ctx.cb
         rows = dy.numel() // (ca + cb)
@@ -895,6 +919,7 @@ def concat_channels(a, b):
 class Reparameterize(Function):
     @staticmethod
     def forward(ctx, mu, log_var, eps):
+        ctx.set_materialize_grads(False)  # an absent cotangent arrives as None: no zero-fill, no kernels on zeros
         L.require_gpu(mu)
         mu, log_var, eps = _c(mu), _c(log_var), _c(eps)
         z = torch.empty_like(mu)
@@ -904,6 +929,8 @@ class Reparameterize(Function):
 
     @staticmethod
     def backward(ctx, dz):
+        if dz is None:
+            return (None,) * 3
         log_var, eps = ctx.saved_tensors
         dz = _c(dz)
         dmu, dlv = torch.empty_like(dz), torch.empty_like(dz)
@@ -921,6 +948,7 @@ class ReconLoss(Function):
 
     @staticmethod
     def forward(ctx, recons, inputs, kind, scale):
+        ctx.set_materialize_grads(False)  # an absent cotangent arrives as None: no zero-fill, no kernels on zeros
         L.require_gpu(recons)
         recons, inputs = _c(recons), _c(inputs)
         assert recons.shape == inputs.shape, (recons.shape, inputs.shape)
@@ -934,6 +962,8 @@ class ReconLoss(Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return (None,) * 4
         recons, inputs = ctx.saved_tensors
         g = _c(g)
         dr = torch.empty_like(recons)
@@ -948,6 +978,7 @@ class EdgeWeightedPixelLoss(Function):
 
     @staticmethod
     def forward(ctx, recons, inputs, scale):
+        ctx.set_materialize_grads(False)  # an absent cotangent arrives as None: no zero-fill, no kernels on zeros
         L.require_gpu(recons)
         recons, inputs = _c(recons), _c(inputs)
         assert recons.shape == inputs.shape and recons.dim() == 4, (recons.shape, inputs.shape)
@@ -966,6 +997,8 @@ class EdgeWeightedPixelLoss(Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return (None,) * 3
         recons, inputs, w_raw, wmax = ctx.saved_tensors
         g = _c(g)
         n, h, w, c = recons.shape
@@ -981,6 +1014,7 @@ class EdgeMatchingLoss(Function):
 
     @staticmethod
     def forward(ctx, recons, inputs, scale, mode):
+        ctx.set_materialize_grads(False)  # an absent cotangent arrives as None: no zero-fill, no kernels on zeros
         L.require_gpu(recons)
         recons, inputs = _c(recons), _c(inputs)
         assert recons.shape == inputs.shape and recons.dim() == 4, (recons.shape, inputs.shape)
@@ -996,6 +1030,8 @@ class EdgeMatchingLoss(Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return (None,) * 4
         recons, inputs, stats = ctx.saved_tensors
         g = _c(g)
         n, h, w, c = recons.shape
@@ -1020,6 +1056,7 @@ def recon_loss(recons, inputs, kind, scale=1.0):
 class KLDivergence(Function):
     @staticmethod
     def forward(ctx, mu, log_var, scale):
+        ctx.set_materialize_grads(False)  # an absent cotangent arrives as None: no zero-fill, no kernels on zeros
         L.require_gpu(mu)
         mu, log_var = _c(mu), _c(log_var)
         b, d = mu.shape
@@ -1032,6 +1069,8 @@ class KLDivergence(Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return (None,) * 3
         mu, log_var = ctx.saved_tensors
         g = _c(g)
         b, d = mu.shape
@@ -1050,6 +1089,7 @@ class TCDecomposition(Function):
 
     @staticmethod
     def forward(ctx, z, mu, log_var, log_iw):
+        ctx.set_materialize_grads(False)  # an absent cotangent arrives as None: no zero-fill, no kernels on zeros
         L.require_gpu(z)
         z, mu, log_var, log_iw = _c(z), _c(mu), _c(log_var), _c(log_iw)
         b, d = z.shape
@@ -1064,6 +1104,8 @@ class TCDecomposition(Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return (None,) * 4
         z, mu, log_var, log_iw, lj, lm = ctx.saved_tensors
         g = _c(g)
         b, d = z.shape
@@ -1137,6 +1179,7 @@ class EmbeddingLookup(Function):
 
     @staticmethod
     def forward(ctx, idx, weight):
+        ctx.set_materialize_grads(False)  # an absent cotangent arrives as None: no zero-fill, no kernels on zeros
         L.require_gpu(weight)
         idx = idx.contiguous()
         w = _c(weight)
@@ -1149,6 +1192,8 @@ class EmbeddingLookup(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if dy is None:
+            return (None,) * 2
         (idx,) = ctx.saved_tensors
         k, d = ctx.kd
         dy = _c(dy)
@@ -1167,6 +1212,7 @@ class GatedResidual(Function):
 
     @staticmethod
     def forward(ctx, res, gate, feat):
+        ctx.set_materialize_grads(False)  # an absent cotangent arrives as None: no zero-fill, no kernels on zeros
         L.require_gpu(res)
         res, gate, feat = _c(res), _c(gate), _c(feat)
         out = torch.empty_like(res)
@@ -1176,6 +1222,8 @@ class GatedResidual(Function):
 
     @staticmethod
     def backward(ctx, dout):
+        if dout is None:
+            return (None,) * 3
         gate, feat = ctx.saved_tensors
         dout = _c(dout)
         dg, df = torch.empty_like(dout), torch.empty_like(dout)
@@ -1204,6 +1252,7 @@ class CrossEntropy(Function):
 
     @staticmethod
     def forward(ctx, logits, target):
+        ctx.set_materialize_grads(False)  # an absent cotangent arrives as None: no zero-fill, no kernels on zeros
         L.require_gpu(logits)
         logits, target = _c(logits), target.contiguous()
         rows, k = logits.shape
@@ -1218,6 +1267,8 @@ class CrossEntropy(Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return (None,) * 2
         logits, target, lse = ctx.saved_tensors
         g = _c(g)
         rows, k = logits.shape
