@@ -70,7 +70,11 @@ def main():
     ap.add_argument("--index", type=int, nargs="*", default=None)
     ap.add_argument("--sweep-split", type=int, nargs="*", default=None,
                     help="time every call with the split-K factor pinned to each value (0 = the library's heuristic)")
+    ap.add_argument("--lib", type=str, default="", help="A/B: load this prebuilt libmovae_hip.so instead of the in-tree one")
     a = ap.parse_args()
+    if a.lib:
+        L.LIB_PATH = os.path.abspath(a.lib)
+        os.environ["MOVAE_NO_REBUILD"] = "1"
     lib = L.load()
     dev = torch.device("cuda:0")
     ws = L.workspace(dev)
