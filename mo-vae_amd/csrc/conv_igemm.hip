@@ -39,11 +39,12 @@ struct Epilogue {
 // one v_mul_hi + one shift instead of the ~35-instruction software division (the 128x128 kernels issued 4-8 VALU instructions
 // per MFMA, most of them these divisions; PMC: profiles/r02_pmc_igemm128.json).  m = ceil(2^(31+s) / d), s = ceil(log2 d):
 // exact because the rounding error of m, < d <= 2^s, times n < 2^31 stays below 2^(31+s).
+// (d = 1 has no such m: mul = 0 and the all-ones `one` mask passes n through -- branch-free in the kernel.)
 struct FastDiv {
-    unsigned mul, shift, d;
+    unsigned mul, shift, one;
 };
 inline FastDiv fastdiv_make(int d) {
-    FastDiv f{0u, 0u, d > 0 ? (unsigned)d : 1u};
+    FastDiv f{0u, 0u, d <= 1 ? 0xffffffffu : 0u};
     if (d <= 1) return f;
     unsigned s = 0;
     while ((1u << s) < (unsigned)d) ++s;
@@ -53,7 +54,7 @@ inline FastDiv fastdiv_make(int d) {
     return f;
 }
 __device__ __forceinline__ int fdiv(int n, const FastDiv& f) {
-    return f.d == 1u ? n : (int)(__umulhi((unsigned)n, f.mul) >> f.shift);
+    return (int)((__umulhi((unsigned)n, f.mul) >> f.shift) | ((unsigned)n & f.one));
 }
 
 // Fusion of a training-mode BatchNorm (+ LeakyReLU / ReLU) into its neighbours:
@@ -959,7 +960,10 @@ int launch_fwd(const float* X, const float* W, float* Y, const Geom& g_in, const
         MOVAE_NO_NORM("thin-channel output conv");
         return (g_last_kernel = "thin_out_fwd_k", thin::launch_thin_out_fwd(X, W, Y, g, ep, st));
     }
-    if (g.Cr % 4 == 0 && aligned16(X) && aligned16(W)) {  // fast path (igemm_v2.h)
+    // fast path (igemm_v2.h); its 32-bit buffer offsets need every row block's images and the weights within 2 GiB of their bases
+    const bool span_ok = v2::buf_span_ok((128L / ((long)g.Ho * g.Wo) + 2) * g.Hi * g.Wi * g.Cr) &&
+                         v2::buf_span_ok((long)g.Nn * (g.wlen ? g.wrow : Kl) + g.woff);
+    if (g.Cr % 4 == 0 && aligned16(X) && aligned16(W) && span_ok) {
         if (g.Nn <= 32) return (g_last_kernel = "igemm2_fwd<128,32>", v2::launch_fwd2<128, 32>(X, W, Y, g, ep, M, K, ws, ws_bytes, st));
         // 2x2 register tiling (64x64 per wave) once the 128x128 grid alone fills the chip
         if (g.Nn >= 128 && (Ml / 128) * (g.Nn / 128) >= big_tile_min()) return (g_last_kernel = "igemm2_fwd<128,128>", v2::launch_fwd2<128, 128>(X, W, Y, g, ep, M, K, ws, ws_bytes, st));
@@ -1020,7 +1024,10 @@ int launch_bwd(const float* X, const float* W, float* Y, const Geom& g, const Ep
         if (int rc = thin::launch_thin_out_tile<true>(X, W, Y, g, ep, st, &handled)) return rc;
         if (handled) return (g_last_kernel = "thin_out_tile_k<bwd>", MOVAE_OK);
     }
-    if (g.Cr % 4 == 0 && g.Nn % 4 == 0 && g.stride <= 2 && aligned16(X) && aligned16(W) && aligned16(Y)) {  // fast path (igemm_v2.h)
+    // fast path (igemm_v2.h); 32-bit buffer offsets: a row block's images (smallest output-parity class) and the weights within 2 GiB
+    const long hwc_min = (long)(g.Ho / g.stride > 0 ? g.Ho / g.stride : 1) * (g.Wo / g.stride > 0 ? g.Wo / g.stride : 1);
+    const bool span_ok = v2::buf_span_ok((128L / hwc_min + 2) * g.Hi * g.Wi * g.Cr) && v2::buf_span_ok((long)g.Cr * g.KH * g.KW * g.Nn);
+    if (g.Cr % 4 == 0 && g.Nn % 4 == 0 && g.stride <= 2 && aligned16(X) && aligned16(W) && aligned16(Y) && span_ok) {
         if (g.Nn <= 32) return (g_last_kernel = "igemm2_bwd<128,32>", v2::launch_bwd2<128, 32>(X, W, Y, g, ep, ws, ws_bytes, st));
         if (g.Nn >= 128 && (Mc / 128) * (g.Nn / 128) * g.stride * g.stride >= big_tile_min())
             return (g_last_kernel = "igemm2_bwd<128,128>", v2::launch_bwd2<128, 128>(X, W, Y, g, ep, ws, ws_bytes, st));
@@ -1095,7 +1102,9 @@ int launch_wgrad(const float* S, const float* Bg, float* const* dW, int G, long 
         return (g_last_kernel = "linear_small_k<TN>",
                 lin::launch_linear_small<2>(S, Bg, dW, colsum_S, G, s_gs, nullptr, g.Cs, g.Cb, (int)Kl, 0, 0.f, accumulate, st));
     }
-    const bool vec = g.Cs % 4 == 0 && g.Cb % 4 == 0 && aligned16(S) && aligned16(Bg) && s_gs % 4 == 0 && b_gs % 4 == 0;
+    // (the fast path's 32-bit buffer offsets: each group's two tensors below 2 GiB)
+    const bool vec = g.Cs % 4 == 0 && g.Cb % 4 == 0 && aligned16(S) && aligned16(Bg) && s_gs % 4 == 0 && b_gs % 4 == 0 &&
+                     v2::buf_span_ok(Kl * g.Cs) && v2::buf_span_ok((long)g.Nimg * g.Hb * g.Wb * g.Cb);
     const int N = g.KH * g.KW * g.Cb;
     if (vec && !(thin::thin_wgrad_ok(g) && ws)) {  // fast path (igemm_v2.h)
         if (N <= 32) return (g_last_kernel = "igemm2_wgrad<128,32>", v2::launch_wgrad2<128, 32>(S, Bg, dW, G, s_gs, b_gs, g, (int)Kl, accumulate, ws, ws_bytes, st));

@@ -108,6 +108,20 @@ __device__ __forceinline__ void mma_kk(const float* __restrict__ As, const float
 
 #define ZERO4 (f32x4{0.f, 0.f, 0.f, 0.f})
 
+// Gathers go through raw buffer loads: the descriptor spans 2 GiB from a block-uniform base, a lane whose element is padding /
+// past the tile's edge gets the offset BUF_OOB (outside the descriptor: the load returns zeros without touching memory).  No
+// branch around any load, 32-bit offsets instead of 64-bit pointers -- the k loop is one basic block the scheduler can spread
+// under the MFMAs.  (Host: buf_span_ok -- every valid offset stays below 2 GiB.)
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+constexpr int BUF_OOB = (int)0x80000000;
+__device__ __forceinline__ rsrc_t buf_rsrc(const float* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)0x80000000, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(rsrc_t r, int byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+inline bool buf_span_ok(long floats) { return floats * 4 < 0x7fffff00L; }
+
 // ------------------------------------------------------------------------------------------------
 // Kernel arguments as plain structs and kernel bodies as device functions of an explicit block index (bx, by, bz) and an
 // LDS base: the stand-alone kernels below pass blockIdx, the paired kernel (igemm2_pair) runs a dgrad body and a wgrad
@@ -151,29 +165,31 @@ __device__ __forceinline__ void igemm2_fwd_body(const FwdArgs& a, float* __restr
     constexpr int AC = BM / RPP, BC = BN / RPP;  // 16-byte chunks per thread
     const int kq = t % CPR, r8 = t / CPR;
 
-    const float* a_base[AC];
-    int a_h0[AC], a_w0[AC];
-    bool a_ok[AC];
+    // row i of this thread: byte offset of its (h0, w0) corner from the block's first image, and the corner itself for the
+    // padding test (a row past M gets a corner no tap brings back inside)
+    const int hw = g.Ho * g.Wo;
+    const int img0 = m0 / hw;
+    const rsrc_t xr = buf_rsrc(X + (long)img0 * g.Hi * g.Wi * g.Cr);
+    int a_off[AC], a_h0[AC], a_w0[AC];
 #pragma unroll
     for (int i = 0; i < AC; ++i) {
         const int m = m0 + r8 + RPP * i;
-        a_ok[i] = m < M;
-        const int mm = a_ok[i] ? m : 0;
-        const int hw = g.Ho * g.Wo;
+        const bool ok = m < M;
+        const int mm = ok ? m : m0;
         const int img = mm / hw, rem = mm - img * hw;
         const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
-        a_h0[i] = ho * g.stride - g.pad;
-        a_w0[i] = wo * g.stride - g.pad;
-        a_base[i] = X + (long)img * g.Hi * g.Wi * g.Cr;
+        const int h0 = ho * g.stride - g.pad, w0 = wo * g.stride - g.pad;
+        a_off[i] = ((((img - img0) * g.Hi + h0) * g.Wi + w0) * g.Cr) * 4;
+        a_h0[i] = ok ? h0 : -(1 << 20);
+        a_w0[i] = w0;
     }
-    const float* b_base[BC];
-    bool b_ok[BC];
     const int wrow = g.wlen ? g.wrow : K;  // floats per output channel in the stored weights (tap window: Geom)
+    const rsrc_t wr = buf_rsrc(W + g.woff);
+    int b_off[BC];
 #pragma unroll
     for (int i = 0; i < BC; ++i) {
         const int n = n0 + r8 + RPP * i;
-        b_ok[i] = n < N;
-        b_base[i] = W + (long)(b_ok[i] ? n : 0) * wrow + g.woff;
+        b_off[i] = n < N ? n * wrow * 4 : BUF_OOB;
     }
     const int nk_total = (K + BK2 - 1) / BK2;
     const int kt_begin = bz * ktiles_per_split;
@@ -187,18 +203,20 @@ __device__ __forceinline__ void igemm2_fwd_body(const FwdArgs& a, float* __restr
     const float nslope = a.nrm.slope;
     f32x4 nsa = ZERO4, nsb = ZERO4;
     unsigned amask = 0;
-    auto load_tile = [&](int kt) {
+    auto load_tile = [&](int kt) {  // (a k-tile at or past kt_end loads nothing: every offset is BUF_OOB)
         const int k = kt * BK2 + kq * 4;
-        const bool kv = k < K;
+        const bool kv = k < K && kt < kt_end;
         const int kk = kv ? k : 0;
         const int tap = fdiv(kk, a.fd_cr), c = kk - tap * g.Cr;
         const int kh = fdiv(tap, a.fd_kw), kw = tap - kh * g.KW;
+        const int khv = kv ? kh : -(1 << 20);
+        const int toff = ((kh * g.Wi + kw) * g.Cr + c) * 4;
         amask = 0;
 #pragma unroll
         for (int i = 0; i < AC; ++i) {
-            const int h = a_h0[i] + kh, w = a_w0[i] + kw;
-            const bool v = kv && a_ok[i] && h >= 0 && h < g.Hi && w >= 0 && w < g.Wi;
-            ra[i] = v ? *reinterpret_cast<const f32x4*>(a_base[i] + ((long)h * g.Wi + w) * g.Cr + c) : ZERO4;
+            const int h = a_h0[i] + khv, w = a_w0[i] + kw;
+            const bool v = (unsigned)h < (unsigned)g.Hi && (unsigned)w < (unsigned)g.Wi;
+            ra[i] = buf_load4(xr, v ? a_off[i] + toff : BUF_OOB);
             amask |= (v ? 1u : 0u) << i;
         }
         if (nsc) {
@@ -207,11 +225,11 @@ __device__ __forceinline__ void igemm2_fwd_body(const FwdArgs& a, float* __restr
         }
         int kb = kk;  // window row -> stored kernel row
         if (g.wlen) {
-            const int wr = fdiv(kk, a.fd_wlen);
-            kb = wr * g.wstride + (kk - wr * g.wlen);
+            const int wr_ = fdiv(kk, a.fd_wlen);
+            kb = wr_ * g.wstride + (kk - wr_ * g.wlen);
         }
 #pragma unroll
-        for (int i = 0; i < BC; ++i) rb[i] = (kv && b_ok[i]) ? *reinterpret_cast<const f32x4*>(b_base[i] + kb) : ZERO4;
+        for (int i = 0; i < BC; ++i) rb[i] = buf_load4(wr, kv ? b_off[i] + kb * 4 : BUF_OOB);
     };
 
     f32x16 acc[T::TM * T::TN];
@@ -234,34 +252,21 @@ __device__ __forceinline__ void igemm2_fwd_body(const FwdArgs& a, float* __restr
     // software pipeline: stage t is multiplied out of LDS buffer t&1 while the registers of stage t+1 are
     // written to the other buffer between the two MFMA halves and the loads of stage t+2 are issued; one
     // barrier per stage.
+    // (store and prefetch are unconditional -- past the end they move zeros / load nothing -- so the loop body is ONE basic block)
     const int nkt = kt_end - kt_begin;
-    if (T::DB) {
-        if (nkt > 0) {
-            load_tile(kt_begin);
-            store_tile(0);
-            __syncthreads();
-            if (nkt > 1) load_tile(kt_begin + 1);
-        }
-        for (int it = 0; it < nkt; ++it) {
-            const int cur = it & 1;
-            mma_rr<T::TM, T::TN, 0>(As + cur * ASZ, Bs + cur * BSZ, wm * T::TM * 32, wn * T::TN * 32, acc);
-            if (it + 1 < nkt) {
-                store_tile(cur ^ 1);
-                if (it + 2 < nkt) load_tile(kt_begin + it + 2);
-            }
-            mma_rr<T::TM, T::TN, 1>(As + cur * ASZ, Bs + cur * BSZ, wm * T::TM * 32, wn * T::TN * 32, acc);
-            __syncthreads();
-        }
-    } else {  // single LDS stage (128x128 tile): barrier, store, barrier, prefetch, multiply
-        if (nkt > 0) load_tile(kt_begin);
-        for (int it = 0; it < nkt; ++it) {
-            __syncthreads();
-            store_tile(0);
-            __syncthreads();
-            if (it + 1 < nkt) load_tile(kt_begin + it + 1);
-            mma_rr<T::TM, T::TN, 0>(As, Bs, wm * T::TM * 32, wn * T::TN * 32, acc);
-            mma_rr<T::TM, T::TN, 1>(As, Bs, wm * T::TM * 32, wn * T::TN * 32, acc);
-        }
+    if (nkt > 0) {
+        load_tile(kt_begin);
+        store_tile(0);
+        __syncthreads();
+        load_tile(kt_begin + 1);
+    }
+    for (int it = 0; it < nkt; ++it) {
+        const int cur = it & 1;
+        mma_rr<T::TM, T::TN, 0>(As + cur * ASZ, Bs + cur * BSZ, wm * T::TM * 32, wn * T::TN * 32, acc);
+        store_tile(cur ^ 1);
+        load_tile(kt_begin + it + 2);
+        mma_rr<T::TM, T::TN, 1>(As + cur * ASZ, Bs + cur * BSZ, wm * T::TM * 32, wn * T::TN * 32, acc);
+        __syncthreads();
     }
 
     const int lane = t & 63, half = lane >> 5, l31 = lane & 31;
@@ -346,7 +351,8 @@ struct BwdArgs {
     float* stats;  // [classes * gx * WM][2][N] or null (only without split-K)
     int stats_gx;  // row blocks per class (the launch's grid x) -- the partial index is (class * gx + bx) * WM + wave row
     BnBwd bb;      // backward sums of a fused BatchNorm (only without split-K; ppg = classes * (gx / groups) * WM)
-    FastDiv fd_cr;         // k loop: by g.Cr
+    FastDiv fd_cr;         // k loop: by g.Cr ...
+    FastDiv fd_nb[4];      // ... and, per output-parity class, by the class's tap columns nB
     FastDiv fd_hw[4], fd_w[4];  // epilogue, per output-parity class: by Hoc * Woc and by Woc
 };
 
@@ -407,27 +413,31 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
 
     constexpr int AC = BM / RPP;
     const int kq = t % CPR, r8 = t / CPR;
-    const float* a_base[AC];
-    int a_h0[AC], a_w0[AC];
-    bool a_ok[AC];
+    // gathered rows through a buffer descriptor based at the block's first image (see buf_rsrc)
+    const int hwc = Hoc * Woc;
+    const int img0 = m0 / hwc;
+    const rsrc_t xr = buf_rsrc(X + (long)img0 * g.Hi * g.Wi * g.Cr);
+    int a_off[AC], a_h0[AC], a_w0[AC];
 #pragma unroll
     for (int i = 0; i < AC; ++i) {
         const int m = m0 + r8 + RPP * i;
-        a_ok[i] = m < M;
-        const int mm = a_ok[i] ? m : 0;
-        const int hw = Hoc * Woc;
-        const int img = mm / hw, rem = mm - img * hw;
+        const bool ok = m < M;
+        const int mm = ok ? m : m0;
+        const int img = mm / hwc, rem = mm - img * hwc;
         const int hc = rem / Woc, wc = rem - hc * Woc;
-        a_h0[i] = hc + qh;
-        a_w0[i] = wc + qw;
-        a_base[i] = X + (long)img * g.Hi * g.Wi * g.Cr;
+        const int h0 = hc + qh, w0 = wc + qw;
+        a_off[i] = ((((img - img0) * g.Hi + h0) * g.Wi + w0) * g.Cr) * 4;
+        a_h0[i] = ok ? h0 : -(1 << 20);
+        a_w0[i] = w0;
     }
     constexpr int BQ = BN / 4;              // 16-byte chunks per k-row
     constexpr int BC = BK2 * BQ / 256;      // chunks per thread (2 for BN=64, 1 for BN=32)
     constexpr int KSTEP = 256 / BQ;         // k-rows covered per pass
     const int bq = t % BQ, bk = t / BQ;
     const int bn = n0 + bq * 4;
-    const bool bn_ok = bn < N;              // N % 4 == 0 on this path
+    const rsrc_t wr = buf_rsrc(W);
+    const int b_col = bn < N ? bn * 4 : BUF_OOB;  // N % 4 == 0 on this path
+    const FastDiv fd_nb = a.fd_nb[cls];
 
     f32x4 ra[AC], rb[BC];
     const float* __restrict__ nsc = a.nrm.scale;  // virtual operand: see igemm2_fwd_body
@@ -435,19 +445,24 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
     const float nslope = a.nrm.slope;
     f32x4 nsa = ZERO4, nsb = ZERO4;
     unsigned amask = 0;
-    auto load_tile = [&](int kt) {
+    const int nk_total = (K + BK2 - 1) / BK2;
+    const int kt_begin = split * ktiles_per_split;
+    const int kt_end = min(nk_total, kt_begin + ktiles_per_split);
+    auto load_tile = [&](int kt) {  // (a k-tile at or past kt_end loads nothing)
         {
             const int k = kt * BK2 + kq * 4;
-            const bool kv = k < K;
+            const bool kv = k < K && kt < kt_end;
             const int kk = kv ? k : 0;
             const int tt = fdiv(kk, a_.fd_cr), c = kk - tt * g.Cr;
-            const int a = nBd == 1 ? tt : (nBd == 2 ? tt >> 1 : tt / nBd), b = tt - a * nBd;
+            const int ta = fdiv(tt, fd_nb), tb = tt - ta * nBd;
+            const int tav = kv ? ta : (1 << 20);
+            const int toff = (c - (ta * g.Wi + tb) * g.Cr) * 4;
             amask = 0;
 #pragma unroll
             for (int i = 0; i < AC; ++i) {
-                const int h = a_h0[i] - a, w = a_w0[i] - b;
-                const bool v = kv && a_ok[i] && h >= 0 && h < g.Hi && w >= 0 && w < g.Wi;
-                ra[i] = v ? *reinterpret_cast<const f32x4*>(a_base[i] + ((long)h * g.Wi + w) * g.Cr + c) : ZERO4;
+                const int h = a_h0[i] - tav, w = a_w0[i] - tb;
+                const bool v = (unsigned)h < (unsigned)g.Hi && (unsigned)w < (unsigned)g.Wi;
+                ra[i] = buf_load4(xr, v ? a_off[i] + toff : BUF_OOB);
                 amask |= (v ? 1u : 0u) << i;
             }
             if (nsc) {
@@ -458,12 +473,12 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
 #pragma unroll
         for (int i = 0; i < BC; ++i) {
             const int k = kt * BK2 + bk + KSTEP * i;
-            const bool kv = k < K && bn_ok;
-            const int kk = k < K ? k : 0;
+            const bool kv = k < K && kt < kt_end;
+            const int kk = kv ? k : 0;
             const int tt = fdiv(kk, a_.fd_cr), c = kk - tt * g.Cr;
-            const int a = nBd == 1 ? tt : (nBd == 2 ? tt >> 1 : tt / nBd), b = tt - a * nBd;
-            const int kh = kh0 + s * a, kw = kw0 + s * b;
-            rb[i] = kv ? *reinterpret_cast<const f32x4*>(W + ((long)c * taps + kh * g.KW + kw) * N + bn) : ZERO4;
+            const int ta = fdiv(tt, fd_nb), tb = tt - ta * nBd;
+            const int kh = kh0 + s * ta, kw = kw0 + s * tb;
+            rb[i] = buf_load4(wr, kv ? ((c * taps + kh * g.KW + kw) * N) * 4 + b_col : BUF_OOB);
         }
     };
 
@@ -473,9 +488,6 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     const int wave = t >> 6, wm = wave / T::WN, wn = wave % T::WN;
-    const int nk_total = (K + BK2 - 1) / BK2;
-    const int kt_begin = split * ktiles_per_split;
-    const int kt_end = min(nk_total, kt_begin + ktiles_per_split);
     auto store_tile = [&](int buf) {
         if (nsc) {
 #pragma unroll
@@ -487,34 +499,20 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
 #pragma unroll
         for (int i = 0; i < BC; ++i) *reinterpret_cast<f32x4*>(Bs + buf * BSZ + (bk + KSTEP * i) * T::LDKB + bq * 4) = rb[i];
     };
-    const int nkt = kt_end - kt_begin;
-    if (T::DB) {
-        if (nkt > 0) {
-            load_tile(kt_begin);
-            store_tile(0);
-            __syncthreads();
-            if (nkt > 1) load_tile(kt_begin + 1);
-        }
-        for (int it = 0; it < nkt; ++it) {
-            const int cur = it & 1;
-            mma_rk<T::TM, T::TN, 0>(As + cur * ASZ, Bs + cur * BSZ, T::LDKB, wm * T::TM * 32, wn * T::TN * 32, acc);
-            if (it + 1 < nkt) {
-                store_tile(cur ^ 1);
-                if (it + 2 < nkt) load_tile(kt_begin + it + 2);
-            }
-            mma_rk<T::TM, T::TN, 1>(As + cur * ASZ, Bs + cur * BSZ, T::LDKB, wm * T::TM * 32, wn * T::TN * 32, acc);
-            __syncthreads();
-        }
-    } else {  // single LDS stage (128x128 tile): barrier, store, barrier, prefetch, multiply
-        if (nkt > 0) load_tile(kt_begin);
-        for (int it = 0; it < nkt; ++it) {
-            __syncthreads();
-            store_tile(0);
-            __syncthreads();
-            if (it + 1 < nkt) load_tile(kt_begin + it + 1);
-            mma_rk<T::TM, T::TN, 0>(As, Bs, T::LDKB, wm * T::TM * 32, wn * T::TN * 32, acc);
-            mma_rk<T::TM, T::TN, 1>(As, Bs, T::LDKB, wm * T::TM * 32, wn * T::TN * 32, acc);
-        }
+    const int nkt = kt_end - kt_begin;  // (one basic block per stage: see igemm2_fwd_body)
+    if (nkt > 0) {
+        load_tile(kt_begin);
+        store_tile(0);
+        __syncthreads();
+        load_tile(kt_begin + 1);
+    }
+    for (int it = 0; it < nkt; ++it) {
+        const int cur = it & 1;
+        mma_rk<T::TM, T::TN, 0>(As + cur * ASZ, Bs + cur * BSZ, T::LDKB, wm * T::TM * 32, wn * T::TN * 32, acc);
+        store_tile(cur ^ 1);
+        load_tile(kt_begin + it + 2);
+        mma_rk<T::TM, T::TN, 1>(As + cur * ASZ, Bs + cur * BSZ, T::LDKB, wm * T::TM * 32, wn * T::TN * 32, acc);
+        __syncthreads();
     }
 
     const int lane = t & 63, half = lane >> 5, l31 = lane & 31;
@@ -648,8 +646,9 @@ __device__ __forceinline__ void igemm2_wgrad_body(const WgArgs& a, float* __rest
     const int M = g.Cs, N = g.KH * g.KW * g.Cb;
     const int m0 = bx * BM, n0 = by * BN;
     const int grp = bz / Sp, split = bz - grp * Sp;
-    const float* __restrict__ Sm = a.Sm + grp * a.s_gs;
-    const float* __restrict__ Bg = a.Bg + grp * a.b_gs;
+    // both operands through buffer descriptors based at the group's tensors (see buf_rsrc; host: whole tensors below 2 GiB)
+    const rsrc_t sr = buf_rsrc(a.Sm + grp * a.s_gs);
+    const rsrc_t br = buf_rsrc(a.Bg + grp * a.b_gs);
     const int k_begin = split * kchunk, k_end = min(K, k_begin + kchunk);
     if (g.Hs == 1 && g.Ws == 1) {
         // a 1x1 small side meets tap (kh, kw) at big-side pixel (kh - pad, kw - pad) only: column tiles whose taps all fall
@@ -681,6 +680,12 @@ __device__ __forceinline__ void igemm2_wgrad_body(const WgArgs& a, float* __rest
     const int b_tap = (bn_ok ? bn : 0) / g.Cb, b_c = (bn_ok ? bn : 0) - b_tap * g.Cb;
     const int b_kh = b_tap / g.KW, b_kw = b_tap - b_kh * g.KW;
     const int hw = g.Hs * g.Ws;
+    const int a_col = am_ok ? am * 4 : BUF_OOB;
+    // big-side element of small-side pixel (img, hs, ws) under this thread's tap: byte offset
+    // img * s_img + hs * s_h + ws * s_w + b_const; rows / columns tested against the padding as unsigned compares
+    const int s_img = g.Hb * g.Wb * g.Cb * 4, s_h = g.stride * g.Wb * g.Cb * 4, s_w = g.stride * g.Cb * 4;
+    const int b_h0 = bn_ok ? b_kh - g.pad : -(1 << 20), b_w0 = b_kw - g.pad;
+    const int b_const = (((b_kh - g.pad) * g.Wb + (b_kw - g.pad)) * g.Cb + b_c) * 4;
 
     f32x4 ra[ACH], rb[BCH];
     // virtual activation operand (Norm): this thread's four channels are the same for every k, so scale / shift are loaded once;
@@ -696,27 +701,28 @@ __device__ __forceinline__ void igemm2_wgrad_body(const WgArgs& a, float* __rest
         nsb = *reinterpret_cast<const f32x4*>(a.nrm.shift + b_c);
     }
     unsigned vmask = 0;
-    auto load_tile = [&](int k0) {
-        vmask = 0;
+    auto load_tile = [&](int k0) {  // (a stage at or past k_end loads nothing)
+        unsigned va = 0, vb = 0;
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
             const int k = k0 + ak + AKS * i;
-            const bool v = k < k_end && am_ok;
-            ra[i] = v ? *reinterpret_cast<const f32x4*>(Sm + (long)k * M + am) : ZERO4;
-            if (nside == 1) vmask |= (v ? 1u : 0u) << i;
+            const bool v = k < k_end;
+            ra[i] = buf_load4(sr, v ? k * (M * 4) + a_col : BUF_OOB);
+            va |= ((v && am_ok) ? 1u : 0u) << i;
         }
 #pragma unroll
         for (int i = 0; i < BCH; ++i) {
             const int k = k0 + bk + BKS * i;
-            const bool kv = k < k_end && bn_ok;
-            const int kk = k < k_end ? k : k_begin;
+            const bool kv = k < k_end;
+            const int kk = kv ? k : k_begin;
             const int img = fdiv(kk, a.fd_hw), rem = kk - img * hw;
             const int hs = fdiv(rem, a.fd_ws), ws = rem - hs * g.Ws;
-            const int h = hs * g.stride - g.pad + b_kh, w = ws * g.stride - g.pad + b_kw;
-            const bool v = kv && h >= 0 && h < g.Hb && w >= 0 && w < g.Wb;
-            rb[i] = v ? *reinterpret_cast<const f32x4*>(Bg + (((long)img * g.Hb + h) * g.Wb + w) * g.Cb + b_c) : ZERO4;
-            if (nside == 2) vmask |= (v ? 1u : 0u) << i;
+            const int h = hs * g.stride + b_h0, w = ws * g.stride + b_w0;
+            const bool v = kv && (unsigned)h < (unsigned)g.Hb && (unsigned)w < (unsigned)g.Wb;
+            rb[i] = buf_load4(br, v ? img * s_img + hs * s_h + ws * s_w + b_const : BUF_OOB);
+            vb |= (v ? 1u : 0u) << i;
         }
+        vmask = nside == 1 ? va : vb;
     };
 
     f32x16 acc[T::TM * T::TN];
@@ -742,34 +748,20 @@ __device__ __forceinline__ void igemm2_wgrad_body(const WgArgs& a, float* __rest
 #pragma unroll
         for (int i = 0; i < BCH; ++i) *reinterpret_cast<f32x4*>(Bs + buf * BSZ + (bk + BKS * i) * T::LDKB + bq * 4) = rb[i];
     };
-    const int nkt = k_begin < k_end ? (k_end - k_begin + BK2 - 1) / BK2 : 0;
-    if (T::DB) {
-        if (nkt > 0) {
-            load_tile(k_begin);
-            store_tile(0);
-            __syncthreads();
-            if (nkt > 1) load_tile(k_begin + BK2);
-        }
-        for (int it = 0; it < nkt; ++it) {
-            const int cur = it & 1;
-            mma_kk<T::TM, T::TN, 0>(As + cur * ASZ, Bs + cur * BSZ, T::LDKA, T::LDKB, wm * T::TM * 32, wn * T::TN * 32, acc);
-            if (it + 1 < nkt) {
-                store_tile(cur ^ 1);
-                if (it + 2 < nkt) load_tile(k_begin + (it + 2) * BK2);
-            }
-            mma_kk<T::TM, T::TN, 1>(As + cur * ASZ, Bs + cur * BSZ, T::LDKA, T::LDKB, wm * T::TM * 32, wn * T::TN * 32, acc);
-            __syncthreads();
-        }
-    } else {  // single LDS stage (128x128 tile): barrier, store, barrier, prefetch, multiply
-        if (nkt > 0) load_tile(k_begin);
-        for (int it = 0; it < nkt; ++it) {
-            __syncthreads();
-            store_tile(0);
-            __syncthreads();
-            if (it + 1 < nkt) load_tile(k_begin + (it + 1) * BK2);
-            mma_kk<T::TM, T::TN, 0>(As, Bs, T::LDKA, T::LDKB, wm * T::TM * 32, wn * T::TN * 32, acc);
-            mma_kk<T::TM, T::TN, 1>(As, Bs, T::LDKA, T::LDKB, wm * T::TM * 32, wn * T::TN * 32, acc);
-        }
+    const int nkt = k_begin < k_end ? (k_end - k_begin + BK2 - 1) / BK2 : 0;  // (one basic block per stage: see igemm2_fwd_body)
+    if (nkt > 0) {
+        load_tile(k_begin);
+        store_tile(0);
+        __syncthreads();
+        load_tile(k_begin + BK2);
+    }
+    for (int it = 0; it < nkt; ++it) {
+        const int cur = it & 1;
+        mma_kk<T::TM, T::TN, 0>(As + cur * ASZ, Bs + cur * BSZ, T::LDKA, T::LDKB, wm * T::TM * 32, wn * T::TN * 32, acc);
+        store_tile(cur ^ 1);
+        load_tile(k_begin + (it + 2) * BK2);
+        mma_kk<T::TM, T::TN, 1>(As + cur * ASZ, Bs + cur * BSZ, T::LDKA, T::LDKB, wm * T::TM * 32, wn * T::TN * 32, acc);
+        __syncthreads();
     }
 
     const int lane = t & 63, half = lane >> 5, l31 = lane & 31;
@@ -1024,6 +1016,8 @@ int launch_bwd2(const float* X, const float* W, float* Y, const Geom& g, const E
         const int ph = c / s, pw = c % s;
         const int Hoc = c < ncls ? (g.Ho - ph + s - 1) / s : 1, Woc = c < ncls ? (g.Wo - pw + s - 1) / s : 1;
         a.fd_hw[c] = fastdiv_make(Hoc * Woc > 0 ? Hoc * Woc : 1), a.fd_w[c] = fastdiv_make(Woc > 0 ? Woc : 1);
+        const int kw0 = (pw + g.pad) % s, nB = kw0 < g.KW ? (g.KW - kw0 + s - 1) / s : 0;
+        a.fd_nb[c] = fastdiv_make(nB > 0 ? nB : 1);
     }
     a.nrm = g_fuse.nrm;
     a.stats_gx = gx;

@@ -136,3 +136,44 @@ def test_fused_path_really_runs_and_falls_back(gpu_device, monkeypatch):
     with torch.no_grad():
         o = st(x)
     assert isinstance(o, torch.Tensor) and "movae_bn_act_fwd" in calls and "movae_bn_finalize" not in calls
+
+
+# (kind, batch, size, cin, cout, k, stride, pad, out_pad): every BatchNorm producer of the C1 / C2 models at the config batch sizes
+STAT_SHAPES = [
+    ("conv", 256, 32, 3, 32, 3, 2, 1, 0), ("conv", 256, 16, 32, 64, 3, 2, 1, 0), ("conv", 256, 8, 64, 128, 3, 2, 1, 0),
+    ("conv", 256, 4, 128, 256, 3, 2, 1, 0), ("conv", 256, 2, 256, 512, 3, 2, 1, 0),
+    ("convT", 256, 1, 512, 256, 3, 2, 1, 1), ("convT", 256, 2, 256, 128, 3, 2, 1, 1), ("convT", 256, 4, 128, 64, 3, 2, 1, 1),
+    ("convT", 256, 8, 64, 32, 3, 2, 1, 1), ("convT", 256, 16, 32, 32, 3, 2, 1, 1),
+    ("conv", 128, 64, 3, 16, 3, 2, 1, 0), ("conv", 128, 32, 16, 32, 3, 2, 1, 0), ("convT", 128, 32, 16, 16, 3, 2, 1, 1),
+]
+
+
+@pytest.mark.parametrize("shape", STAT_SHAPES, ids=[f"{s[0]}{s[1]}x{s[2]}x{s[3]}to{s[4]}" for s in STAT_SHAPES])
+def test_fused_statistics_at_config_shapes(shape, gpu_device):
+    """The statistics the producer kernels emit (epilogue partials, split-K reduce, thin-channel tile sums, folded when there are
+    many) against fp64 statistics of the very y they were taken from: mean and 1/sqrt(var + eps) to fp32 rounding.  (The BatchNorm
+    backward amplifies an error in them a thousandfold at these shapes -- tests/test_hip_parity_full.py.)"""
+    import movae_amd  # noqa: F401
+    from movae_amd import nn as mnn, ops
+
+    kind, B, size, cin, cout, k, s, p, op = shape
+    torch.manual_seed(11)
+    conv = (mnn.Conv2d(cin, cout, k, s, p) if kind == "conv" else mnn.ConvTranspose2d(cin, cout, k, s, p, op)).to(gpu_device)
+    bn = mnn.BatchNorm2d(cout).to(gpu_device).train()
+    with torch.no_grad():
+        conv.bias.normal_(0.0, 1.0)  # a mean far from zero: E[y^2] - mean^2 must not lose it
+    x = torch.rand(B, size, size, cin, device=gpu_device) + 0.5
+    out = mnn.Stack(conv, bn, mnn.LeakyReLU()).to(gpu_device)(x)
+    assert isinstance(out, ops.LazyBN)
+    y = out.y.detach().double().reshape(-1, cout)
+    mean = y.mean(0)
+    var = ((y - mean) ** 2).mean(0)
+    rstd = 1.0 / torch.sqrt(var + bn.eps)
+    got_rstd = out.scale.detach().double()            # gamma = 1
+    got_mean = -out.shift.detach().double() / got_rstd  # beta = 0
+    # sum(y^2)/n - mean^2 in fp32 partials (folded in fp64) carries eps_fp32 * E[y^2] / var of cancellation: the bound is per channel
+    bound = (5e-7 * (1.0 + mean ** 2 / var)).cpu().numpy()
+    rel = ((got_rstd - rstd).abs() / rstd).cpu().numpy()
+    assert (rel <= bound).all(), f"1/sqrt(var + eps): worst {rel.max():.2e} (bound {bound[rel.argmax()]:.2e})"
+    merr = ((got_mean - mean).abs() / (mean.abs() + var.sqrt())).cpu().numpy()
+    assert merr.max() < 5e-7, f"mean: worst error {merr.max():.2e} of |mean| + std"
