@@ -13,6 +13,7 @@
 //   MFMA k assignment: lane half h consumes k = 16h + j at step j (both operands agree, so the
 //   contraction is unchanged).
 #pragma once
+#include <type_traits>
 
 namespace v2 {
 
@@ -108,6 +109,15 @@ __device__ __forceinline__ void mma_kk(const float* __restrict__ As, const float
 
 #define ZERO4 (f32x4{0.f, 0.f, 0.f, 0.f})
 
+// Stage order inside the (single basic block) k loop: first MFMA half | LDS stores of the prefetched stage | address arithmetic and
+// buffer loads of the stage after, free to spread under the second MFMA half.  Without the two fences the scheduler hoists the LDS
+// stores to the top of the stage and sinks the loads to its end -- eight MFMAs between a load and its use instead of sixty-four.
+#ifndef MOVAE_SCHED_PIN_OFF
+#define MOVAE_SCHED_PIN() __builtin_amdgcn_sched_barrier(0)
+#else
+#define MOVAE_SCHED_PIN() ((void)0)
+#endif
+
 // Gathers go through raw buffer loads: the descriptor spans 2 GiB from a block-uniform base, a lane whose element is padding /
 // past the tile's edge gets the offset BUF_OOB (outside the descriptor: the load returns zeros without touching memory).  No
 // branch around any load, 32-bit offsets instead of 64-bit pointers -- the k loop is one basic block the scheduler can spread
@@ -116,6 +126,9 @@ using rsrc_t = __amdgpu_buffer_rsrc_t;
 constexpr int BUF_OOB = (int)0x80000000;
 __device__ __forceinline__ rsrc_t buf_rsrc(const float* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)0x80000000, 0x00020000);
+}
+__device__ __forceinline__ rsrc_t buf_rsrc_if(const float* p, bool on) {  // on == false: an empty descriptor, every load returns zeros
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, on ? (int)0x80000000 : 0, 0x00020000);
 }
 __device__ __forceinline__ f32x4 buf_load4(rsrc_t r, int byte_off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
@@ -203,70 +216,108 @@ __device__ __forceinline__ void igemm2_fwd_body(const FwdArgs& a, float* __restr
     const float nslope = a.nrm.slope;
     f32x4 nsa = ZERO4, nsb = ZERO4;
     unsigned amask = 0;
-    auto load_tile = [&](int kt) {  // (a k-tile at or past kt_end loads nothing: every offset is BUF_OOB)
-        const int k = kt * BK2 + kq * 4;
-        const bool kv = k < K && kt < kt_end;
-        const int kk = kv ? k : 0;
-        const int tap = fdiv(kk, a.fd_cr), c = kk - tap * g.Cr;
-        const int kh = fdiv(tap, a.fd_kw), kw = tap - kh * g.KW;
-        const int khv = kv ? kh : -(1 << 20);
-        const int toff = ((kh * g.Wi + kw) * g.Cr + c) * 4;
-        amask = 0;
-#pragma unroll
-        for (int i = 0; i < AC; ++i) {
-            const int h = a_h0[i] + khv, w = a_w0[i] + kw;
-            const bool v = (unsigned)h < (unsigned)g.Hi && (unsigned)w < (unsigned)g.Wi;
-            ra[i] = buf_load4(xr, v ? a_off[i] + toff : BUF_OOB);
-            amask |= (v ? 1u : 0u) << i;
-        }
-        if (nsc) {
-            nsa = *reinterpret_cast<const f32x4*>(nsc + c);
-            nsb = *reinterpret_cast<const f32x4*>(nsh + c);
-        }
-        int kb = kk;  // window row -> stored kernel row
-        if (g.wlen) {
-            const int wr_ = fdiv(kk, a.fd_wlen);
-            kb = wr_ * g.wstride + (kk - wr_ * g.wlen);
-        }
-#pragma unroll
-        for (int i = 0; i < BC; ++i) rb[i] = buf_load4(wr, kv ? b_off[i] + kb * 4 : BUF_OOB);
-    };
-
     f32x16 acc[T::TM * T::TN];
 #pragma unroll
     for (int i = 0; i < T::TM * T::TN; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     const int wave = t >> 6, wm = wave / T::WN, wn = wave % T::WN;
-    auto store_tile = [&](int buf) {
-        if (nsc) {
-#pragma unroll
-            for (int i = 0; i < AC; ++i)
-                ra[i] = norm_apply_if((amask >> i) & 1u, ra[i], nsa, nsb, nslope);
+    // The k loop exists twice (PLAIN: no virtual operand, no tap window -- the common case, and free of their uniform branches, so
+    // each stage is one basic block; otherwise the general form): unswitched by hand, the compiler does not.
+    // KAL (PLAIN and Cr % BK2 == 0, every layer of 32+ channels): a k-stage lies inside ONE tap, so the tap decode is scalar
+    // arithmetic on the stage index and a lane's offsets are loop constants plus one scalar -- ~6 VALU per gathered row, 1 per
+    // weight row, instead of two divisions and five multiplications per lane and stage.
+    auto pipeline = [&](auto plain_c, auto kal_c) {
+        constexpr bool PLAIN = decltype(plain_c)::value, KAL = decltype(kal_c)::value;
+        int a_offq[AC], b_offq[BC];  // KAL: the lane's own k column folded in
+    #pragma unroll
+        for (int i = 0; i < AC; ++i) a_offq[i] = a_off[i] + kq * 16;
+    #pragma unroll
+        for (int i = 0; i < BC; ++i) b_offq[i] = b_off[i] + kq * 16;  // (BUF_OOB + small stays out of range)
+        auto load_tile = [&](int kt) {  // (a k-tile at or past kt_end loads nothing: every offset is BUF_OOB)
+            if constexpr (KAL) {
+                const bool kv = kt < kt_end;  // K % BK2 == 0: a stage is whole or past the end (then: empty descriptors)
+                const int k0 = kv ? kt * BK2 : 0;
+                const int tap = fdiv(k0, a.fd_cr), c0 = k0 - tap * g.Cr;
+                const int kh = fdiv(tap, a.fd_kw), kw = tap - kh * g.KW;
+                const int soff = ((kh * g.Wi + kw) * g.Cr + c0) * 4;
+                const rsrc_t xs = buf_rsrc_if(X + (long)img0 * g.Hi * g.Wi * g.Cr, kv), ws_ = buf_rsrc_if(W + g.woff, kv);
+    #pragma unroll
+                for (int i = 0; i < AC; ++i) {
+                    const int h = a_h0[i] + kh, w = a_w0[i] + kw;
+                    const bool v = (unsigned)h < (unsigned)g.Hi && (unsigned)w < (unsigned)g.Wi;
+                    ra[i] = buf_load4(xs, v ? a_offq[i] + soff : BUF_OOB);
+                }
+    #pragma unroll
+                for (int i = 0; i < BC; ++i) rb[i] = buf_load4(ws_, b_offq[i] + k0 * 4);
+                return;
+            }
+            const int k = kt * BK2 + kq * 4;
+            const bool kv = k < K && kt < kt_end;
+            const int kk = kv ? k : 0;
+            const int tap = fdiv(kk, a.fd_cr), c = kk - tap * g.Cr;
+            const int kh = fdiv(tap, a.fd_kw), kw = tap - kh * g.KW;
+            const int khv = kv ? kh : -(1 << 20);
+            const int toff = ((kh * g.Wi + kw) * g.Cr + c) * 4;
+            amask = 0;
+    #pragma unroll
+            for (int i = 0; i < AC; ++i) {
+                const int h = a_h0[i] + khv, w = a_w0[i] + kw;
+                const bool v = (unsigned)h < (unsigned)g.Hi && (unsigned)w < (unsigned)g.Wi;
+                ra[i] = buf_load4(xr, v ? a_off[i] + toff : BUF_OOB);
+                amask |= (v ? 1u : 0u) << i;
+            }
+            if (!PLAIN && nsc) {
+                nsa = *reinterpret_cast<const f32x4*>(nsc + c);
+                nsb = *reinterpret_cast<const f32x4*>(nsh + c);
+            }
+            int kb = kk;  // window row -> stored kernel row
+            if (!PLAIN && g.wlen) {
+                const int wr_ = fdiv(kk, a.fd_wlen);
+                kb = wr_ * g.wstride + (kk - wr_ * g.wlen);
+            }
+    #pragma unroll
+            for (int i = 0; i < BC; ++i) rb[i] = buf_load4(wr, kv ? b_off[i] + kb * 4 : BUF_OOB);
+        };
+
+        auto store_tile = [&](int buf) {
+            if (!PLAIN && nsc) {
+    #pragma unroll
+                for (int i = 0; i < AC; ++i)
+                    ra[i] = norm_apply_if((amask >> i) & 1u, ra[i], nsa, nsb, nslope);
+            }
+    #pragma unroll
+            for (int i = 0; i < AC; ++i) *reinterpret_cast<f32x4*>(As + buf * ASZ + (r8 + RPP * i) * LDR + kq * 4) = ra[i];
+    #pragma unroll
+            for (int i = 0; i < BC; ++i) *reinterpret_cast<f32x4*>(Bs + buf * BSZ + (r8 + RPP * i) * LDR + kq * 4) = rb[i];
+        };
+        // software pipeline: stage t is multiplied out of LDS buffer t&1 while the registers of stage t+1 are
+        // written to the other buffer between the two MFMA halves and the loads of stage t+2 are issued; one
+        // barrier per stage.
+        // (store and prefetch are unconditional -- past the end they move zeros / load nothing -- so the loop body is ONE basic block)
+        const int nkt = kt_end - kt_begin;
+        if (nkt > 0) {
+            load_tile(kt_begin);
+            store_tile(0);
+            __syncthreads();
+            load_tile(kt_begin + 1);
         }
-#pragma unroll
-        for (int i = 0; i < AC; ++i) *reinterpret_cast<f32x4*>(As + buf * ASZ + (r8 + RPP * i) * LDR + kq * 4) = ra[i];
-#pragma unroll
-        for (int i = 0; i < BC; ++i) *reinterpret_cast<f32x4*>(Bs + buf * BSZ + (r8 + RPP * i) * LDR + kq * 4) = rb[i];
+        for (int it = 0; it < nkt; ++it) {
+            const int cur = it & 1;
+            mma_rr<T::TM, T::TN, 0>(As + cur * ASZ, Bs + cur * BSZ, wm * T::TM * 32, wn * T::TN * 32, acc);
+            MOVAE_SCHED_PIN();
+            store_tile(cur ^ 1);
+            MOVAE_SCHED_PIN();
+            load_tile(kt_begin + it + 2);
+            mma_rr<T::TM, T::TN, 1>(As + cur * ASZ, Bs + cur * BSZ, wm * T::TM * 32, wn * T::TN * 32, acc);
+            __syncthreads();
+        }
     };
-    // software pipeline: stage t is multiplied out of LDS buffer t&1 while the registers of stage t+1 are
-    // written to the other buffer between the two MFMA halves and the loads of stage t+2 are issued; one
-    // barrier per stage.
-    // (store and prefetch are unconditional -- past the end they move zeros / load nothing -- so the loop body is ONE basic block)
-    const int nkt = kt_end - kt_begin;
-    if (nkt > 0) {
-        load_tile(kt_begin);
-        store_tile(0);
-        __syncthreads();
-        load_tile(kt_begin + 1);
-    }
-    for (int it = 0; it < nkt; ++it) {
-        const int cur = it & 1;
-        mma_rr<T::TM, T::TN, 0>(As + cur * ASZ, Bs + cur * BSZ, wm * T::TM * 32, wn * T::TN * 32, acc);
-        store_tile(cur ^ 1);
-        load_tile(kt_begin + it + 2);
-        mma_rr<T::TM, T::TN, 1>(As + cur * ASZ, Bs + cur * BSZ, wm * T::TM * 32, wn * T::TN * 32, acc);
-        __syncthreads();
+    if (!nsc && !g.wlen) {
+        if (g.Cr % BK2 == 0) pipeline(std::true_type{}, std::true_type{});
+        else pipeline(std::true_type{}, std::false_type{});
+    } else {
+        pipeline(std::false_type{}, std::false_type{});
     }
 
     const int lane = t & 63, half = lane >> 5, l31 = lane & 31;
@@ -448,71 +499,107 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
     const int nk_total = (K + BK2 - 1) / BK2;
     const int kt_begin = split * ktiles_per_split;
     const int kt_end = min(nk_total, kt_begin + ktiles_per_split);
-    auto load_tile = [&](int kt) {  // (a k-tile at or past kt_end loads nothing)
-        {
-            const int k = kt * BK2 + kq * 4;
-            const bool kv = k < K && kt < kt_end;
-            const int kk = kv ? k : 0;
-            const int tt = fdiv(kk, a_.fd_cr), c = kk - tt * g.Cr;
-            const int ta = fdiv(tt, fd_nb), tb = tt - ta * nBd;
-            const int tav = kv ? ta : (1 << 20);
-            const int toff = (c - (ta * g.Wi + tb) * g.Cr) * 4;
-            amask = 0;
-#pragma unroll
-            for (int i = 0; i < AC; ++i) {
-                const int h = a_h0[i] - tav, w = a_w0[i] - tb;
-                const bool v = (unsigned)h < (unsigned)g.Hi && (unsigned)w < (unsigned)g.Wi;
-                ra[i] = buf_load4(xr, v ? a_off[i] + toff : BUF_OOB);
-                amask |= (v ? 1u : 0u) << i;
-            }
-            if (nsc) {
-                nsa = *reinterpret_cast<const f32x4*>(nsc + c);
-                nsb = *reinterpret_cast<const f32x4*>(nsh + c);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < BC; ++i) {
-            const int k = kt * BK2 + bk + KSTEP * i;
-            const bool kv = k < K && kt < kt_end;
-            const int kk = kv ? k : 0;
-            const int tt = fdiv(kk, a_.fd_cr), c = kk - tt * g.Cr;
-            const int ta = fdiv(tt, fd_nb), tb = tt - ta * nBd;
-            const int kh = kh0 + s * ta, kw = kw0 + s * tb;
-            rb[i] = buf_load4(wr, kv ? ((c * taps + kh * g.KW + kw) * N) * 4 + b_col : BUF_OOB);
-        }
-    };
-
     f32x16 acc[T::TM * T::TN];
 #pragma unroll
     for (int i = 0; i < T::TM * T::TN; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     const int wave = t >> 6, wm = wave / T::WN, wn = wave % T::WN;
-    auto store_tile = [&](int buf) {
-        if (nsc) {
-#pragma unroll
-            for (int i = 0; i < AC; ++i)
-                ra[i] = norm_apply_if((amask >> i) & 1u, ra[i], nsa, nsb, nslope);
+    auto pipeline = [&](auto plain_c, auto kal_c) {  // (the k loop: general / plain / plain and k-aligned -- see igemm2_fwd_body)
+        constexpr bool PLAIN = decltype(plain_c)::value, KAL = decltype(kal_c)::value;
+        int a_offq[AC], b_thr[BC];  // KAL: loop-constant parts of the lane's offsets
+    #pragma unroll
+        for (int i = 0; i < AC; ++i) a_offq[i] = a_off[i] + kq * 16;
+    #pragma unroll
+        for (int i = 0; i < BC; ++i) b_thr[i] = (bk + KSTEP * i) * taps * N * 4 + b_col;  // (BUF_OOB + a valid offset stays out of range)
+        auto load_tile = [&](int kt) {  // (a k-tile at or past kt_end loads nothing)
+            if constexpr (KAL) {
+                const bool kv = kt < kt_end;
+                const int k0 = kv ? kt * BK2 : 0;
+                const int tt = fdiv(k0, a_.fd_cr), c0 = k0 - tt * g.Cr;
+                const int ta = fdiv(tt, fd_nb), tb = tt - ta * nBd;
+                const int soff = (c0 - (ta * g.Wi + tb) * g.Cr) * 4;
+                const int kh = kh0 + s * ta, kw = kw0 + s * tb;
+                const int wbase = ((c0 * taps + kh * g.KW + kw) * N) * 4;
+                const rsrc_t xs = buf_rsrc_if(X + (long)img0 * g.Hi * g.Wi * g.Cr, kv), ws_ = buf_rsrc_if(W, kv);
+    #pragma unroll
+                for (int i = 0; i < AC; ++i) {
+                    const int h = a_h0[i] - ta, w = a_w0[i] - tb;
+                    const bool v = (unsigned)h < (unsigned)g.Hi && (unsigned)w < (unsigned)g.Wi;
+                    ra[i] = buf_load4(xs, v ? a_offq[i] + soff : BUF_OOB);
+                }
+    #pragma unroll
+                for (int i = 0; i < BC; ++i) rb[i] = buf_load4(ws_, b_thr[i] + wbase);
+                return;
+            }
+            {
+                const int k = kt * BK2 + kq * 4;
+                const bool kv = k < K && kt < kt_end;
+                const int kk = kv ? k : 0;
+                const int tt = fdiv(kk, a_.fd_cr), c = kk - tt * g.Cr;
+                const int ta = fdiv(tt, fd_nb), tb = tt - ta * nBd;
+                const int tav = kv ? ta : (1 << 20);
+                const int toff = (c - (ta * g.Wi + tb) * g.Cr) * 4;
+                amask = 0;
+    #pragma unroll
+                for (int i = 0; i < AC; ++i) {
+                    const int h = a_h0[i] - tav, w = a_w0[i] - tb;
+                    const bool v = (unsigned)h < (unsigned)g.Hi && (unsigned)w < (unsigned)g.Wi;
+                    ra[i] = buf_load4(xr, v ? a_off[i] + toff : BUF_OOB);
+                    amask |= (v ? 1u : 0u) << i;
+                }
+                if (!PLAIN && nsc) {
+                    nsa = *reinterpret_cast<const f32x4*>(nsc + c);
+                    nsb = *reinterpret_cast<const f32x4*>(nsh + c);
+                }
+            }
+    #pragma unroll
+            for (int i = 0; i < BC; ++i) {
+                const int k = kt * BK2 + bk + KSTEP * i;
+                const bool kv = k < K && kt < kt_end;
+                const int kk = kv ? k : 0;
+                const int tt = fdiv(kk, a_.fd_cr), c = kk - tt * g.Cr;
+                const int ta = fdiv(tt, fd_nb), tb = tt - ta * nBd;
+                const int kh = kh0 + s * ta, kw = kw0 + s * tb;
+                rb[i] = buf_load4(wr, kv ? ((c * taps + kh * g.KW + kw) * N) * 4 + b_col : BUF_OOB);
+            }
+        };
+
+        auto store_tile = [&](int buf) {
+            if (!PLAIN && nsc) {
+    #pragma unroll
+                for (int i = 0; i < AC; ++i)
+                    ra[i] = norm_apply_if((amask >> i) & 1u, ra[i], nsa, nsb, nslope);
+            }
+    #pragma unroll
+            for (int i = 0; i < AC; ++i) *reinterpret_cast<f32x4*>(As + buf * ASZ + (r8 + RPP * i) * LDR + kq * 4) = ra[i];
+    #pragma unroll
+            for (int i = 0; i < BC; ++i) *reinterpret_cast<f32x4*>(Bs + buf * BSZ + (bk + KSTEP * i) * T::LDKB + bq * 4) = rb[i];
+        };
+        const int nkt = kt_end - kt_begin;  // (one basic block per stage: see igemm2_fwd_body)
+        if (nkt > 0) {
+            load_tile(kt_begin);
+            store_tile(0);
+            __syncthreads();
+            load_tile(kt_begin + 1);
         }
-#pragma unroll
-        for (int i = 0; i < AC; ++i) *reinterpret_cast<f32x4*>(As + buf * ASZ + (r8 + RPP * i) * LDR + kq * 4) = ra[i];
-#pragma unroll
-        for (int i = 0; i < BC; ++i) *reinterpret_cast<f32x4*>(Bs + buf * BSZ + (bk + KSTEP * i) * T::LDKB + bq * 4) = rb[i];
+        for (int it = 0; it < nkt; ++it) {
+            const int cur = it & 1;
+            mma_rk<T::TM, T::TN, 0>(As + cur * ASZ, Bs + cur * BSZ, T::LDKB, wm * T::TM * 32, wn * T::TN * 32, acc);
+            MOVAE_SCHED_PIN();
+            store_tile(cur ^ 1);
+            MOVAE_SCHED_PIN();
+            load_tile(kt_begin + it + 2);
+            MOVAE_SCHED_PIN();  // (measured: the gather issued BEFORE the second half beats spreading it under it, this form only)
+            mma_rk<T::TM, T::TN, 1>(As + cur * ASZ, Bs + cur * BSZ, T::LDKB, wm * T::TM * 32, wn * T::TN * 32, acc);
+            __syncthreads();
+        }
     };
-    const int nkt = kt_end - kt_begin;  // (one basic block per stage: see igemm2_fwd_body)
-    if (nkt > 0) {
-        load_tile(kt_begin);
-        store_tile(0);
-        __syncthreads();
-        load_tile(kt_begin + 1);
-    }
-    for (int it = 0; it < nkt; ++it) {
-        const int cur = it & 1;
-        mma_rk<T::TM, T::TN, 0>(As + cur * ASZ, Bs + cur * BSZ, T::LDKB, wm * T::TM * 32, wn * T::TN * 32, acc);
-        store_tile(cur ^ 1);
-        load_tile(kt_begin + it + 2);
-        mma_rk<T::TM, T::TN, 1>(As + cur * ASZ, Bs + cur * BSZ, T::LDKB, wm * T::TM * 32, wn * T::TN * 32, acc);
-        __syncthreads();
+    if (!nsc) {
+        if (g.Cr % BK2 == 0) pipeline(std::true_type{}, std::true_type{});
+        else pipeline(std::true_type{}, std::false_type{});
+    } else {
+        pipeline(std::false_type{}, std::false_type{});
     }
 
     const int lane = t & 63, half = lane >> 5, l31 = lane & 31;
@@ -701,68 +788,121 @@ __device__ __forceinline__ void igemm2_wgrad_body(const WgArgs& a, float* __rest
         nsb = *reinterpret_cast<const f32x4*>(a.nrm.shift + b_c);
     }
     unsigned vmask = 0;
-    auto load_tile = [&](int k0) {  // (a stage at or past k_end loads nothing)
-        unsigned va = 0, vb = 0;
-#pragma unroll
-        for (int i = 0; i < ACH; ++i) {
-            const int k = k0 + ak + AKS * i;
-            const bool v = k < k_end;
-            ra[i] = buf_load4(sr, v ? k * (M * 4) + a_col : BUF_OOB);
-            va |= ((v && am_ok) ? 1u : 0u) << i;
-        }
-#pragma unroll
-        for (int i = 0; i < BCH; ++i) {
-            const int k = k0 + bk + BKS * i;
-            const bool kv = k < k_end;
-            const int kk = kv ? k : k_begin;
-            const int img = fdiv(kk, a.fd_hw), rem = kk - img * hw;
-            const int hs = fdiv(rem, a.fd_ws), ws = rem - hs * g.Ws;
-            const int h = hs * g.stride + b_h0, w = ws * g.stride + b_w0;
-            const bool v = kv && (unsigned)h < (unsigned)g.Hb && (unsigned)w < (unsigned)g.Wb;
-            rb[i] = buf_load4(br, v ? img * s_img + hs * s_h + ws * s_w + b_const : BUF_OOB);
-            vb |= (v ? 1u : 0u) << i;
-        }
-        vmask = nside == 1 ? va : vb;
-    };
-
     f32x16 acc[T::TM * T::TN];
 #pragma unroll
     for (int i = 0; i < T::TM * T::TN; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     const int wave = t >> 6, wm = wave / T::WN, wn = wave % T::WN;
-    auto store_tile = [&](int buf) {
-        // (two separate ifs with a compiler barrier between them: as an if / else over equally long arrays the two arms are merged
-        // into one loop over a run-time selected array, which moves ra / rb to scratch memory)
-        if (nside == 1) {
-#pragma unroll
-            for (int i = 0; i < ACH; ++i) ra[i] = norm_apply_if((vmask >> i) & 1u, ra[i], nsa, nsb, nslope);
+    auto pipeline = [&](auto plain_c) {  // (the k loop with and without the virtual operand: see igemm2_fwd_body)
+        constexpr bool PLAIN = decltype(plain_c)::value;
+        // PLAIN stages the gathered operand one PIXEL per lane and stage (8 lanes share a pixel, each with BCH column quads, i.e.
+        // BCH taps / channel groups that are loop constants): the pixel -> (image, row, column) decode -- two divisions, three
+        // multiplications -- happens once per lane and stage instead of once per 16-byte chunk.
+        constexpr int PL = 8;                       // lanes per pixel row
+        const int pq = t % PL, pk = t / PL;         // column-quad phase, pixel row of the stage (256 / 8 = BK2 rows)
+        static_assert(256 / PL == BK2 && BQ % PL == 0 && BQ / PL == BCH, "one pixel row per lane");
+        int p_h0[BCH], p_w0[BCH], p_const[BCH];
+        int a_thr[ACH];
+        if constexpr (PLAIN) {
+    #pragma unroll
+            for (int i = 0; i < BCH; ++i) {
+                const int n = n0 + (pq + PL * i) * 4;
+                const bool ok = n < N;
+                const int tap = (ok ? n : 0) / g.Cb, c = (ok ? n : 0) - tap * g.Cb;
+                const int kh = tap / g.KW, kw = tap - kh * g.KW;
+                p_h0[i] = ok ? kh - g.pad : -(1 << 20);
+                p_w0[i] = kw - g.pad;
+                p_const[i] = (((kh - g.pad) * g.Wb + (kw - g.pad)) * g.Cb + c) * 4;
+            }
+    #pragma unroll
+            for (int i = 0; i < ACH; ++i) a_thr[i] = (ak + AKS * i) * (M * 4) + a_col;  // (BUF_OOB + a valid offset stays out of range)
         }
-        asm volatile("");
-        if (nside == 2) {
-#pragma unroll
-            for (int i = 0; i < BCH; ++i) rb[i] = norm_apply_if((vmask >> i) & 1u, rb[i], nsa, nsb, nslope);
+        auto load_tile = [&](int k0) {  // (a stage at or past k_end loads nothing)
+            if constexpr (PLAIN) {
+                const int kM = k0 * (M * 4);
+    #pragma unroll
+                for (int i = 0; i < ACH; ++i) ra[i] = buf_load4(sr, k0 + ak + AKS * i < k_end ? a_thr[i] + kM : BUF_OOB);
+                const int k = k0 + pk;
+                const bool kv = k < k_end;
+                const int kk = kv ? k : k_begin;
+                const int img = fdiv(kk, a.fd_hw), rem = kk - img * hw;
+                const int hs = fdiv(rem, a.fd_ws), ws = rem - hs * g.Ws;
+                const int hS = kv ? hs * g.stride : -(1 << 20), wS = ws * g.stride;
+                const int base = img * s_img + hs * s_h + ws * s_w;
+    #pragma unroll
+                for (int i = 0; i < BCH; ++i) {
+                    const int h = hS + p_h0[i], w = wS + p_w0[i];
+                    const bool v = (unsigned)h < (unsigned)g.Hb && (unsigned)w < (unsigned)g.Wb;
+                    rb[i] = buf_load4(br, v ? base + p_const[i] : BUF_OOB);
+                }
+                return;
+            }
+            unsigned va = 0, vb = 0;
+    #pragma unroll
+            for (int i = 0; i < ACH; ++i) {
+                const int k = k0 + ak + AKS * i;
+                const bool v = k < k_end;
+                ra[i] = buf_load4(sr, v ? k * (M * 4) + a_col : BUF_OOB);
+                va |= ((v && am_ok) ? 1u : 0u) << i;
+            }
+    #pragma unroll
+            for (int i = 0; i < BCH; ++i) {
+                const int k = k0 + bk + BKS * i;
+                const bool kv = k < k_end;
+                const int kk = kv ? k : k_begin;
+                const int img = fdiv(kk, a.fd_hw), rem = kk - img * hw;
+                const int hs = fdiv(rem, a.fd_ws), ws = rem - hs * g.Ws;
+                const int h = hs * g.stride + b_h0, w = ws * g.stride + b_w0;
+                const bool v = kv && (unsigned)h < (unsigned)g.Hb && (unsigned)w < (unsigned)g.Wb;
+                rb[i] = buf_load4(br, v ? img * s_img + hs * s_h + ws * s_w + b_const : BUF_OOB);
+                vb |= (v ? 1u : 0u) << i;
+            }
+            if (!PLAIN) vmask = nside == 1 ? va : vb;
+        };
+
+        auto store_tile = [&](int buf) {
+            // (two separate ifs with a compiler barrier between them: as an if / else over equally long arrays the two arms are merged
+            // into one loop over a run-time selected array, which moves ra / rb to scratch memory)
+            if (!PLAIN && nside == 1) {
+    #pragma unroll
+                for (int i = 0; i < ACH; ++i) ra[i] = norm_apply_if((vmask >> i) & 1u, ra[i], nsa, nsb, nslope);
+            }
+            asm volatile("");
+            if (!PLAIN && nside == 2) {
+    #pragma unroll
+                for (int i = 0; i < BCH; ++i) rb[i] = norm_apply_if((vmask >> i) & 1u, rb[i], nsa, nsb, nslope);
+            }
+    #pragma unroll
+            for (int i = 0; i < ACH; ++i) *reinterpret_cast<f32x4*>(As + buf * ASZ + (ak + AKS * i) * T::LDKA + aq * 4) = ra[i];
+            if constexpr (PLAIN) {
+    #pragma unroll
+                for (int i = 0; i < BCH; ++i) *reinterpret_cast<f32x4*>(Bs + buf * BSZ + pk * T::LDKB + (pq + PL * i) * 4) = rb[i];
+                return;
+            }
+    #pragma unroll
+            for (int i = 0; i < BCH; ++i) *reinterpret_cast<f32x4*>(Bs + buf * BSZ + (bk + BKS * i) * T::LDKB + bq * 4) = rb[i];
+        };
+        const int nkt = k_begin < k_end ? (k_end - k_begin + BK2 - 1) / BK2 : 0;  // (one basic block per stage: see igemm2_fwd_body)
+        if (nkt > 0) {
+            load_tile(k_begin);
+            store_tile(0);
+            __syncthreads();
+            load_tile(k_begin + BK2);
         }
-#pragma unroll
-        for (int i = 0; i < ACH; ++i) *reinterpret_cast<f32x4*>(As + buf * ASZ + (ak + AKS * i) * T::LDKA + aq * 4) = ra[i];
-#pragma unroll
-        for (int i = 0; i < BCH; ++i) *reinterpret_cast<f32x4*>(Bs + buf * BSZ + (bk + BKS * i) * T::LDKB + bq * 4) = rb[i];
+        for (int it = 0; it < nkt; ++it) {
+            const int cur = it & 1;
+            mma_kk<T::TM, T::TN, 0>(As + cur * ASZ, Bs + cur * BSZ, T::LDKA, T::LDKB, wm * T::TM * 32, wn * T::TN * 32, acc);
+            MOVAE_SCHED_PIN();
+            store_tile(cur ^ 1);
+            MOVAE_SCHED_PIN();
+            load_tile(k_begin + (it + 2) * BK2);
+            mma_kk<T::TM, T::TN, 1>(As + cur * ASZ, Bs + cur * BSZ, T::LDKA, T::LDKB, wm * T::TM * 32, wn * T::TN * 32, acc);
+            __syncthreads();
+        }
     };
-    const int nkt = k_begin < k_end ? (k_end - k_begin + BK2 - 1) / BK2 : 0;  // (one basic block per stage: see igemm2_fwd_body)
-    if (nkt > 0) {
-        load_tile(k_begin);
-        store_tile(0);
-        __syncthreads();
-        load_tile(k_begin + BK2);
-    }
-    for (int it = 0; it < nkt; ++it) {
-        const int cur = it & 1;
-        mma_kk<T::TM, T::TN, 0>(As + cur * ASZ, Bs + cur * BSZ, T::LDKA, T::LDKB, wm * T::TM * 32, wn * T::TN * 32, acc);
-        store_tile(cur ^ 1);
-        load_tile(k_begin + (it + 2) * BK2);
-        mma_kk<T::TM, T::TN, 1>(As + cur * ASZ, Bs + cur * BSZ, T::LDKA, T::LDKB, wm * T::TM * 32, wn * T::TN * 32, acc);
-        __syncthreads();
-    }
+    if (nside == 0) pipeline(std::true_type{});
+    else pipeline(std::false_type{});
 
     const int lane = t & 63, half = lane >> 5, l31 = lane & 31;
     float* dst = to_slab ? out + (long)bz * M * N : a.tab.p[grp];

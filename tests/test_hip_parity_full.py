@@ -300,13 +300,20 @@ def test_full_size_aggregated_step_matches_oracle(tag, gpu_device, monkeypatch):
         with masked(kinks.nchw()):
             _, _, g64, i64 = t64.grads(x64, e64)
         with masked(own.seen):
-            _, _, g64o, _ = t64o.grads(x64, e64)
+            _, _, g64o, i64o = t64o.grads(x64, e64)
     Go = (i64["G"] if i64 is not None else oinfo["G"]).double().numpy()
     assert seen["m"] == oinfo["J"].shape[1], "shared-parameter Jacobian width"
     # an off-diagonal entry is an inner product of two long vectors that may nearly cancel: its noise scales with the two norms
     dg = np.sqrt(np.abs(np.diag(Go)))
     gerr = np.abs(seen["G"].numpy() - Go) / np.maximum(np.outer(dg, dg), 1e-30)
-    assert gerr.max() < (2e-3 if vq else 5e-4), f"Gramian: worst |dG_ij| / sqrt(G_ii G_jj) = {gerr.max():.2e}\n{seen['G'].numpy()}\n{Go}"
+    glim = 2e-3 if vq else 5e-4
+    if not vq:  # the fp32 oracle's own Gramian error against float64 is the yardstick where a row is ill-conditioned in fp32 (C5's
+        # total-correlation row: a log-sum-exp over the batch's pairwise densities; the fp32 oracle is 2e-3 off there)
+        Goo = i64o["G"].double().numpy()
+        gora = np.abs(oinfo["G"].double().numpy() - Goo) / np.maximum(np.outer(dg, dg), 1e-30)
+        glim = np.maximum(glim, 4.0 * gora)
+        print(f"[{tag} {agg}] Gramian error / sqrt(G_ii G_jj): HIP worst {gerr.max():.2e}, fp32 oracle worst {gora.max():.2e}")
+    assert (gerr <= glim).all(), f"Gramian: worst |dG_ij| / sqrt(G_ii G_jj) = {gerr.max():.2e}\n{seen['G'].numpy()}\n{Go}"
     w_o = np.asarray(oinfo["w"], dtype=np.float64)
     # Aligned-MTL / MGDA weights are ill-conditioned functions of G (eigen-decomposition, a vertex search): looser
     cond = agg.startswith(("aligned", "mgda"))
