@@ -37,6 +37,11 @@ def main():
                     derived[c + "/SQ_WAVE_CYCLES"] = round(m[c] / wc, 4)
         if m.get("SQ_LDS_IDX_ACTIVE") and "SQ_LDS_BANK_CONFLICT" in m:
             derived["SQ_LDS_BANK_CONFLICT/SQ_LDS_IDX_ACTIVE"] = round(m["SQ_LDS_BANK_CONFLICT"] / m["SQ_LDS_IDX_ACTIVE"], 4)
+        if m.get("SQ_BUSY_CYCLES") and m.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+            # SQ_BUSY_CYCLES is summed over the 32 shader engines (8 XCDs x 4), SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs
+            derived["mfma_pipe_utilisation"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (m["SQ_BUSY_CYCLES"] / 32.0 * 1024.0), 4)
+        if m.get("SQ_INSTS_MFMA") and m.get("SQ_INSTS_VALU"):
+            derived["valu_insts_per_mfma"] = round((m["SQ_INSTS_VALU"] - m["SQ_INSTS_MFMA"]) / m["SQ_INSTS_MFMA"], 3)
         doc[k] = {"launches": max(cnt[k].values()), "mean_per_launch": {c: round(v) for c, v in m.items()}, "ratios": derived}
     with open(out, "w") as f:
         json.dump(doc, f, indent=1)
