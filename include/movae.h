@@ -124,7 +124,8 @@ int movae_act_bwd(const float* dy, const float* out, float* dx, size_t n, int ac
 /* dpre = dy * act'(out) for `groups` (<= 8) stacked cotangents [groups][rows][c] of one forward (out is shared) AND, in the
  * same pass, dbias[g][c] (+)= sum_rows dpre -- the bias gradient of the conv whose epilogue applied the activation
  * (models/betatc_vae.py:104-110, vq_vae2.py:36-47: Conv2d(bias) -> LeakyReLU / ReLU).  c %% 4 == 0; dbias: HOST array
- * of device pointers. */
+ * of device pointers, or NULL: only dpre (one launch for all groups; the conv weight-gradient entry points form the column
+ * sums of dpre themselves while they stage it). */
 int movae_act_bwd_bias_grouped(int groups, const float* dy, const float* out, float* dpre, float* const* dbias,
                                int rows, int c, int act, float slope, int accumulate,
                                void* ws, size_t ws_bytes, movae_stream_t stream);

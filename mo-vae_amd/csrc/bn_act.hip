@@ -548,7 +548,7 @@ __global__ __launch_bounds__(256) void bn_bwd_small(const float* __restrict__ do
 // sums; this finishes them.  One wave per channel: lanes stride over the partials, fp64 shuffle fold; then everything the
 // consumers need: the saved statistics for the backward, the folded affine map x_hat*gamma+beta = scale*y + shift that the next
 // conv applies while it loads y, and nn.BatchNorm2d's running statistics / num_batches_tracked.
-__global__ __launch_bounds__(64) void bn_finalize_k(const float* __restrict__ part, int parts, int rows, int C,
+__global__ __launch_bounds__(256) void bn_finalize_k(const float* __restrict__ part, int parts, int rows, int C,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                     float momentum, float* __restrict__ save_mean, float* __restrict__ save_rstd,
                                                     float* __restrict__ scale, float* __restrict__ shift,
@@ -556,13 +556,14 @@ __global__ __launch_bounds__(64) void bn_finalize_k(const float* __restrict__ pa
                                                     long long* __restrict__ nbt) {
     const int c = blockIdx.x;
     if (nbt && c == 0 && threadIdx.x == 0) nbt[0] += 1;
+    __shared__ double sh[8];
     double s = 0.0, q = 0.0;
-    for (int p = threadIdx.x; p < parts; p += 64) {
+    for (int p = threadIdx.x; p < parts; p += 256) {  // (a block per channel: up to FOLD_ABOVE partials without a fold launch)
         s += (double)part[((long)p * 2 + 0) * C + c];
         q += (double)part[((long)p * 2 + 1) * C + c];
     }
-    s = wave_sum(s);
-    q = wave_sum(q);
+    s = block_sum_256(s, sh);
+    q = block_sum_256(q, sh + 4);
     if (threadIdx.x != 0) return;
     const double mean = s / rows;
     double var = q / rows - mean * mean;
@@ -631,7 +632,10 @@ __global__ __launch_bounds__(256) void bn_partials_fold_k(const float* __restric
 inline const float* fold_partials(const float* part, size_t cap_floats, int* parts, int groups, int c, hipStream_t st) {
     const int P = *parts, E = 2 * c;
     const int nb = 64;
-    if (P <= 256 || (size_t)groups * P * E + (size_t)groups * nb * E > cap_floats) return part;
+    // (the finalize kernels take a 256-thread block per channel: up to 2048 partials -- 8 strided pairs per thread -- cost less than
+    // a fold launch and its dependent kernel boundary)
+    static const int fold_above = getenv("MOVAE_BN_FOLD_ABOVE") ? atoi(getenv("MOVAE_BN_FOLD_ABOVE")) : 2048;
+    if (P <= fold_above || (size_t)groups * P * E + (size_t)groups * nb * E > cap_floats) return part;
     float* dst = const_cast<float*>(part) + (size_t)groups * P * E;
     hipLaunchKernelGGL(bn_partials_fold_k, dim3(nb, groups), dim3(256), 0, st, part, P, E, dst);
     *parts = nb;
@@ -643,19 +647,20 @@ inline const float* fold_partials(const float* part, size_t cap_floats, int* par
 //   dbeta = S1,  dgamma = sum d * x_hat = rstd * (S2 - mean * S1)
 //   dy = gamma * rstd * (d - S1/M - x_hat * dgamma/M) = k1 * d + c2 * y + c3,
 //   k1 = gamma * rstd,  c2 = -k1 * rstd * dgamma / M,  c3 = -k1 * S1 / M - c2 * mean          coef[g][0..2][C]
-__global__ __launch_bounds__(64) void bn_bwd_finalize_k(const float* __restrict__ part, int ppg, int rows, int C,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_k(const float* __restrict__ part, int ppg, int rows, int C,
                                                         const float* __restrict__ gamma, const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, BnOut out, float* __restrict__ coef,
                                                         int accumulate) {
     const int c = blockIdx.x, g = blockIdx.y;
+    __shared__ double sh[8];
     double s1 = 0.0, s2 = 0.0;
-    for (int p = threadIdx.x; p < ppg; p += 64) {
+    for (int p = threadIdx.x; p < ppg; p += 256) {
         const long q = (long)g * ppg + p;
         s1 += (double)part[(q * 2 + 0) * C + c];
         s2 += (double)part[(q * 2 + 1) * C + c];
     }
-    s1 = wave_sum(s1);
-    s2 = wave_sum(s2);
+    s1 = block_sum_256(s1, sh);
+    s2 = block_sum_256(s2, sh + 4);
     if (threadIdx.x != 0) return;
     const double m = mean[c], r = rstd[c], ga = gamma[c];
     const double dgam = r * (s2 - m * s1);
@@ -854,7 +859,7 @@ int movae_bn_finalize(const float* stats, size_t stats_cap, int parts, int rows,
     MOVAE_CHECK_ARG(stats && gamma && beta && save_mean && save_rstd && scale && shift, "movae_bn_finalize: null pointer");
     MOVAE_CHECK_ARG(parts > 0 && rows > 0 && c > 0, "movae_bn_finalize: bad shape parts=%d rows=%d c=%d", parts, rows, c);
     stats = fold_partials(stats, stats_cap, &parts, 1, c, (hipStream_t)stream);
-    hipLaunchKernelGGL(bn_finalize_k, dim3(c), dim3(64), 0, (hipStream_t)stream, stats, parts, rows, c, gamma, beta, eps, momentum,
+    hipLaunchKernelGGL(bn_finalize_k, dim3(c), dim3(256), 0, (hipStream_t)stream, stats, parts, rows, c, gamma, beta, eps, momentum,
                        save_mean, save_rstd, scale, shift, running_mean, running_var, num_batches_tracked);
     MOVAE_CHECK_LAUNCH("bn_finalize");
     return MOVAE_OK;
@@ -881,7 +886,7 @@ int movae_bn_bwd_finalize(const float* bn_part, size_t bn_cap, int ppg, int grou
         tab.dgamma[g] = (g < groups && dgamma) ? dgamma[g] : nullptr;
         tab.dbeta[g] = (g < groups && dbeta) ? dbeta[g] : nullptr;
     }
-    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(c, groups), dim3(64), 0, (hipStream_t)stream, bn_part, ppg, rows, c, gamma, save_mean,
+    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(c, groups), dim3(256), 0, (hipStream_t)stream, bn_part, ppg, rows, c, gamma, save_mean,
                        save_rstd, tab, coef, accumulate);
     MOVAE_CHECK_LAUNCH("bn_bwd_finalize");
     return MOVAE_OK;

@@ -579,9 +579,11 @@ __global__ __launch_bounds__(256) void igemm_wgrad(const float* __restrict__ S, 
 // out[i] = (accumulate ? out[i] : 0) + sum_z slab[z][i], then optional bias (per column n = i % N) + activation
 // Block = 16 split-lanes x 16 consecutive outputs: lane (sl, il) sums slabs sl, sl+16, ... of output i0+il
 // (64-byte coalesced rows), then the 16 split-lanes are folded with 4 shuffles.  Deterministic.
+// (all three plain reduces: outputs [0, n1) go to `out`, the tail [n1, total) to `out2` -- the bias-gradient partials a weight-
+// gradient slab carries behind its M * N floats; n1 == total, out2 == null otherwise)
 __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ slab, float* __restrict__ out, long total,
                                                      int S, int N, const float* __restrict__ bias, int act, float slope,
-                                                     int accumulate) {
+                                                     int accumulate, float* __restrict__ out2, long n1) {
     const int il = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const long i = (long)blockIdx.x * 16 + il;
     float v = 0.f;
@@ -598,7 +600,8 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ s
         v = (sh[0][il] + sh[1][il]) + (sh[2][il] + sh[3][il]);
         if (bias) v += bias[i % N];
         v = apply_act(v, act, slope);
-        out[i] = accumulate ? out[i] + v : v;
+        float* o = i < n1 ? out + i : out2 + (i - n1);
+        *o = accumulate ? *o + v : v;
     }
 }
 
@@ -606,7 +609,7 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ s
 // flight per lane; the 16 split-lanes of a wave fold with shuffles, the 4 waves through LDS.  Deterministic.
 __global__ __launch_bounds__(256) void splitk_reduce_wide(const float* __restrict__ slab, float* __restrict__ out, long total,
                                                           int S, int N, const float* __restrict__ bias, int act, float slope,
-                                                          int accumulate) {
+                                                          int accumulate, float* __restrict__ out2, long n1) {
     const int il = threadIdx.x & 3, sl = threadIdx.x >> 2;
     const long i = ((long)blockIdx.x * 4 + il) * 4;
     f32x4 acc[4];
@@ -639,28 +642,30 @@ __global__ __launch_bounds__(256) void splitk_reduce_wide(const float* __restric
     __syncthreads();
     if (threadIdx.x < 4 && i < total) {
         v = (sh[0][il] + sh[1][il]) + (sh[2][il] + sh[3][il]);
-        f32x4 o = accumulate ? *reinterpret_cast<const f32x4*>(out + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+        float* dst = i < n1 ? out + i : out2 + (i - n1);  // (n1 % 4 == 0: a quad never straddles the two)
+        f32x4 o = accumulate ? *reinterpret_cast<const f32x4*>(dst) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float r = v[j];
             if (bias) r += bias[(i + j) % N];
             o[j] += apply_act(r, act, slope);
         }
-        *reinterpret_cast<f32x4*>(out + i) = o;
+        *reinterpret_cast<f32x4*>(dst) = o;
     }
 }
 
 // few slabs over many outputs: one thread per output, grid-stride
 __global__ __launch_bounds__(256) void splitk_reduce_flat(const float* __restrict__ slab, float* __restrict__ out, long total,
                                                           int S, int N, const float* __restrict__ bias, int act, float slope,
-                                                          int accumulate) {
+                                                          int accumulate, float* __restrict__ out2, long n1) {
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         float v = 0.f;
         for (int z = 0; z < S; ++z) v += slab[(long)z * total + i];
         if (bias) v += bias[i % N];
         v = apply_act(v, act, slope);
-        out[i] = accumulate ? out[i] + v : v;
+        float* o = i < n1 ? out + i : out2 + (i - n1);
+        *o = accumulate ? *o + v : v;
     }
 }
 
@@ -760,21 +765,23 @@ const char* g_last_kernel = "";  // movae_bench_last_kernel(): main kernel chose
 int g_force_split = 0;           // movae_bench_force_split(): > 0 pins the split-K factor (tuning sweeps)
 bool g_bench_main_only = false;  // movae_bench_main_kernel_only(): time the MFMA kernel without its epilogue launches
 
-inline int launch_reduce(const float* slab, float* out, long total, int S, int N, const float* bias, int act, float slope,
-                         int accumulate, hipStream_t st) {
+inline int launch_reduce(const float* slab, float* out, long n1, int S, int N, const float* bias, int act, float slope,
+                         int accumulate, hipStream_t st, float* out2 = nullptr, long n2 = 0) {
     if (g_bench_main_only) return MOVAE_OK;
-    if (S >= 64 && total % 4 == 0 && total <= (1L << 20) &&
-        ((reinterpret_cast<uintptr_t>(slab) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+    if (!out2) n2 = 0;
+    const long total = n1 + n2;  // floats per slab: n1 outputs for `out`, then n2 for `out2`
+    if (S >= 64 && total % 4 == 0 && n1 % 4 == 0 && total <= (1L << 20) &&
+        ((reinterpret_cast<uintptr_t>(slab) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(out2)) & 15) == 0) {
         hipLaunchKernelGGL(splitk_reduce_wide, dim3(ceil_div(total, 16)), dim3(256), 0, st, slab, out, total, S, N, bias, act,
-                           slope, accumulate);
+                           slope, accumulate, out2, n1);
     } else if (S >= 8 && total <= (1L << 20)) {
         hipLaunchKernelGGL(splitk_reduce, dim3(ceil_div(total, 16)), dim3(256), 0, st, slab, out, total, S, N, bias, act, slope,
-                           accumulate);
+                           accumulate, out2, n1);
     } else {
         long gq = (total + 255) / 256;
         if (gq > 4096) gq = 4096;
         hipLaunchKernelGGL(splitk_reduce_flat, dim3((int)gq), dim3(256), 0, st, slab, out, total, S, N, bias, act, slope,
-                           accumulate);
+                           accumulate, out2, n1);
     }
     MOVAE_CHECK_LAUNCH("splitk_reduce");
     return MOVAE_OK;
@@ -1109,12 +1116,20 @@ int launch_wgrad(const float* S, const float* Bg, float* const* dW, int G, long 
                      v2::buf_span_ok(Kl * g.Cs) && v2::buf_span_ok((long)g.Nimg * g.Hb * g.Wb * g.Cb);
     const int N = g.KH * g.KW * g.Cb;
     if (vec && !(thin::thin_wgrad_ok(g) && ws)) {  // fast path (igemm_v2.h)
-        if (N <= 32) return (g_last_kernel = "igemm2_wgrad<128,32>", v2::launch_wgrad2<128, 32>(S, Bg, dW, G, s_gs, b_gs, g, (int)Kl, accumulate, ws, ws_bytes, st));
+        // the column sums of S (bias gradient) ride along: the by == 0 blocks stage every S value of their split anyway
+        float* const* cs = nullptr;
+        if (colsum_S && !(g_fuse.nrm.scale && g_fuse.nrm_side == 1)) {
+            cs = colsum_S;
+            for (int i = 0; i < G; ++i)
+                if (!colsum_S[i]) cs = nullptr;
+        }
+        if (colsum_done) *colsum_done = cs != nullptr;
+        if (N <= 32) return (g_last_kernel = "igemm2_wgrad<128,32>", v2::launch_wgrad2<128, 32>(S, Bg, dW, G, s_gs, b_gs, g, (int)Kl, accumulate, ws, ws_bytes, st, cs));
         // <= 32 rows of dW (32-channel layers): a 64-row tile would multiply half a tile of padding
-        if (g.Cs <= 32 && N >= 128) return (g_last_kernel = "igemm2_wgrad<32,128>", v2::launch_wgrad2<32, 128>(S, Bg, dW, G, s_gs, b_gs, g, (int)Kl, accumulate, ws, ws_bytes, st));
+        if (g.Cs <= 32 && N >= 128) return (g_last_kernel = "igemm2_wgrad<32,128>", v2::launch_wgrad2<32, 128>(S, Bg, dW, G, s_gs, b_gs, g, (int)Kl, accumulate, ws, ws_bytes, st, cs));
         if (g.Cs >= 128 && (long)(g.Cs / 128) * (N / 128) * (Kl / 512) * G >= big_tile_min())
-            return (g_last_kernel = "igemm2_wgrad<128,128>", v2::launch_wgrad2<128, 128>(S, Bg, dW, G, s_gs, b_gs, g, (int)Kl, accumulate, ws, ws_bytes, st));
-        return (g_last_kernel = "igemm2_wgrad<64,64>", v2::launch_wgrad2<64, 64>(S, Bg, dW, G, s_gs, b_gs, g, (int)Kl, accumulate, ws, ws_bytes, st));
+            return (g_last_kernel = "igemm2_wgrad<128,128>", v2::launch_wgrad2<128, 128>(S, Bg, dW, G, s_gs, b_gs, g, (int)Kl, accumulate, ws, ws_bytes, st, cs));
+        return (g_last_kernel = "igemm2_wgrad<64,64>", v2::launch_wgrad2<64, 64>(S, Bg, dW, G, s_gs, b_gs, g, (int)Kl, accumulate, ws, ws_bytes, st, cs));
     }
     if (thin::thin_wgrad_ok(g) && ws)
         return (g_last_kernel = "thin_wgrad", thin::launch_thin_wgrad_grouped(S, Bg, dW, G, s_gs, b_gs, g, (int)Kl, accumulate, ws, ws_bytes, st));

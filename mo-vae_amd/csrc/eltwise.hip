@@ -67,6 +67,20 @@ __global__ void act_bwd_k(const float* __restrict__ dy, const float* __restrict_
     }
 }
 
+// `groups` stacked cotangents of one forward: out is shared, blockIdx.y = group (n4 = float4 quads per group)
+__global__ void act_bwd_grouped_k(const float* __restrict__ dy, const float* __restrict__ out, float* __restrict__ dx, long n4,
+                                  int act, float slope) {
+    const long stride = (long)gridDim.x * blockDim.x, off = (long)blockIdx.y * n4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const f32x4 g = reinterpret_cast<const f32x4*>(dy)[off + i];
+        const f32x4 o = reinterpret_cast<const f32x4*>(out)[i];
+        f32x4 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = g[j] * act_grad_from_out(o[j], act, slope);
+        reinterpret_cast<f32x4*>(dx)[off + i] = r;
+    }
+}
+
 template <bool VEC>
 __global__ void axpby_k(float alpha, const float* __restrict__ a, float beta, const float* __restrict__ b,
                         float* __restrict__ y, long n) {
@@ -321,8 +335,14 @@ int movae_copy_channels(const float* src, float* dst, int rows, int c_src, int c
 int movae_act_bwd_bias_grouped(int groups, const float* dy, const float* out, float* dpre, float* const* dbias, int rows, int c,
                                int act, float slope, int accumulate, void* ws, size_t ws_bytes, movae_stream_t stream) {
     MOVAE_WS_SCRATCH(ws, ws_bytes);
-    MOVAE_CHECK_ARG(dy && out && dpre && dbias && rows > 0 && c > 0 && groups >= 1 && groups <= 8, "movae_act_bwd_bias: bad argument");
+    MOVAE_CHECK_ARG(dy && out && dpre && rows > 0 && c > 0 && groups >= 1 && groups <= 8, "movae_act_bwd_bias: bad argument");
     MOVAE_CHECK_ARG(c % 4 == 0 && al16(dy, out, dpre), "movae_act_bwd_bias: needs c %% 4 == 0 and 16-byte aligned tensors");
+    if (!dbias) {  // no bias gradient wanted here (the weight-gradient kernel sums dpre itself): the grouped activation backward alone
+        const long n4 = (long)rows * c / 4;
+        hipLaunchKernelGGL(act_bwd_grouped_k, dim3(grid_for(n4), groups), dim3(256), 0, (hipStream_t)stream, dy, out, dpre, n4, act, slope);
+        MOVAE_CHECK_LAUNCH("act_bwd_grouped");
+        return MOVAE_OK;
+    }
     const int cq = c / 4;
     const int CQB = pow2_ge(cq) < 256 ? pow2_ge(cq) : 256;
     const int RG4 = 256 / CQB;

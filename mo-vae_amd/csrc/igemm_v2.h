@@ -712,6 +712,12 @@ struct WgArgs {
     Norm nrm;      // virtual activation operand ...
     int nrm_side;  // ... 1: the small-side operand Sm (transposed-conv x), 2: the gathered operand Bg (conv x); 0: none
     FastDiv fd_hw, fd_ws;  // k loop (pixel -> image, row, column): by g.Hs * g.Ws and by g.Ws
+    // Column sums of the small-side operand, sum_k Sm[k][m] (the bias gradient when Sm is dy), from the by == 0 blocks, which stage
+    // every Sm value of their split once anyway: cs.p[group] (or null) are the destinations; with slabs the partial goes behind the
+    // slab's M * N weight-gradient floats (slab_stride = M * N + M) and the split-K reduce folds it like the rest.
+    WOut cs;
+    int cs_on;
+    long slab_stride;
 };
 
 template <int BM, int BN>
@@ -746,8 +752,8 @@ __device__ __forceinline__ void igemm2_wgrad_body(const WgArgs& a, float* __rest
             const int h = tp / g.KW - g.pad, w = tp % g.KW - g.pad;
             any = any || (h >= 0 && h < g.Hb && w >= 0 && w < g.Wb);
         }
-        if (!any) {
-            float* dst0 = to_slab ? out + (long)bz * M * N : a.tab.p[grp];
+        if (!any && !(a.cs_on && by == 0)) {
+            float* dst0 = to_slab ? out + (long)bz * a.slab_stride : a.tab.p[grp];
             for (int i = t; i < BM * BN; i += 256) {  // scalar stores: a Jacobian-row destination is only 4-byte aligned
                 const int m = m0 + i / BN, n = n0 + i % BN;
                 if (m < M && n < N) dst0[(long)m * N + n] = 0.f;
@@ -794,8 +800,9 @@ __device__ __forceinline__ void igemm2_wgrad_body(const WgArgs& a, float* __rest
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     const int wave = t >> 6, wm = wave / T::WN, wn = wave % T::WN;
-    auto pipeline = [&](auto plain_c) {  // (the k loop with and without the virtual operand: see igemm2_fwd_body)
-        constexpr bool PLAIN = decltype(plain_c)::value;
+    f32x4 csum = ZERO4;  // CS: this lane's share of the column sums of Sm (its 4 columns, its k rows)
+    auto pipeline = [&](auto plain_c, auto cs_c) {  // (the k loop with and without the virtual operand: see igemm2_fwd_body)
+        constexpr bool PLAIN = decltype(plain_c)::value, CS = decltype(cs_c)::value;
         // PLAIN stages the gathered operand one PIXEL per lane and stage (8 lanes share a pixel, each with BCH column quads, i.e.
         // BCH taps / channel groups that are loop constants): the pixel -> (image, row, column) decode -- two divisions, three
         // multiplications -- happens once per lane and stage instead of once per 16-byte chunk.
@@ -873,6 +880,10 @@ __device__ __forceinline__ void igemm2_wgrad_body(const WgArgs& a, float* __rest
     #pragma unroll
                 for (int i = 0; i < BCH; ++i) rb[i] = norm_apply_if((vmask >> i) & 1u, rb[i], nsa, nsb, nslope);
             }
+            if constexpr (CS) {  // (rows past k_end and columns past M were loaded as zeros)
+    #pragma unroll
+                for (int i = 0; i < ACH; ++i) csum += ra[i];
+            }
     #pragma unroll
             for (int i = 0; i < ACH; ++i) *reinterpret_cast<f32x4*>(As + buf * ASZ + (ak + AKS * i) * T::LDKA + aq * 4) = ra[i];
             if constexpr (PLAIN) {
@@ -901,11 +912,30 @@ __device__ __forceinline__ void igemm2_wgrad_body(const WgArgs& a, float* __rest
             __syncthreads();
         }
     };
-    if (nside == 0) pipeline(std::true_type{});
-    else pipeline(std::false_type{});
+    const bool cs_blk = a.cs_on && by == 0;  // (host: only with a plain Sm operand, i.e. nside != 1)
+    if (nside == 0) {
+        if (cs_blk) pipeline(std::true_type{}, std::true_type{});
+        else pipeline(std::true_type{}, std::false_type{});
+    } else {
+        if (cs_blk) pipeline(std::false_type{}, std::true_type{});
+        else pipeline(std::false_type{}, std::false_type{});
+    }
+    if (cs_blk) {  // fold the AKS k-lanes of every column through LDS (free after the loop's last barrier), fixed order
+        // (the prologue's stage-0 store ran once per stage like all others: every staged value was added exactly once)
+        float* fs = smem;
+        *reinterpret_cast<f32x4*>(fs + ak * BM + aq * 4) = csum;
+        __syncthreads();
+        if (t < BM && m0 + t < M) {
+            float v = 0.f;
+    #pragma unroll
+            for (int i = 0; i < AKS; ++i) v += fs[i * BM + t];
+            if (to_slab) out[(long)bz * a.slab_stride + (long)M * N + m0 + t] = v;
+            else if (a.cs.p[grp]) a.cs.p[grp][m0 + t] = v;
+        }
+    }
 
     const int lane = t & 63, half = lane >> 5, l31 = lane & 31;
-    float* dst = to_slab ? out + (long)bz * M * N : a.tab.p[grp];
+    float* dst = to_slab ? out + (long)bz * a.slab_stride : a.tab.p[grp];
 #pragma unroll
     for (int tn = 0; tn < T::TN; ++tn) {
         const int n = n0 + wn * T::TN * 32 + tn * 32 + l31;
@@ -1219,16 +1249,17 @@ inline void launch_pair(const PendingDgrad& p, const WgArgs& wa, int wgx, int wg
 
 template <int BM, int BN>
 int launch_wgrad2(const float* Sm, const float* Bg, float* const* dW, int G, long s_gs, long b_gs, const WGeom& g, int K,
-                  int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+                  int accumulate, void* ws, size_t ws_bytes, hipStream_t st, float* const* colsum = nullptr) {
     const int M = g.Cs, N = g.KH * g.KW * g.Cb;
+    const long stride = (long)M * N + (colsum ? M : 0);  // floats per slab
     const int gx = ceil_div(M, BM), gy = ceil_div(N, BN);
     // the G groups run side by side, so the split factor is chosen for G times the tiles
     int Sp = choose_split(FORM_WGRAD, BM * BN, BK2, pair_tiles((long)gx * gy * G, g_pending.active && pair_wgrad_tile<BM, BN>()),
-                          ceil_div(K, BK2), (size_t)M * N * sizeof(float) * G, ws_bytes, ws != nullptr);
+                          ceil_div(K, BK2), (size_t)stride * sizeof(float) * G, ws_bytes, ws != nullptr);
     const int kchunk = ceil_div(ceil_div(K, Sp), BK2) * BK2;
     Sp = ceil_div(K, kchunk);
     const bool slab = Sp > 1 || accumulate;
-    if (slab && (!ws || (size_t)M * N * sizeof(float) * Sp * G > ws_bytes)) {
+    if (slab && (!ws || (size_t)stride * sizeof(float) * Sp * G > ws_bytes)) {
         movae_set_error("wgrad: workspace too small (%zu bytes) for %d x %d splits of %dx%d", ws_bytes, G, Sp, M, N);
         return MOVAE_EINVAL;
     }
@@ -1239,6 +1270,9 @@ int launch_wgrad2(const float* Sm, const float* Bg, float* const* dW, int G, lon
     a.fd_hw = fastdiv_make(g.Hs * g.Ws), a.fd_ws = fastdiv_make(g.Ws);
     a.nrm = g_fuse.nrm;  // virtual activation operand: Sm (transposed-conv x) or Bg (conv x), as the entry point says
     a.nrm_side = g_fuse.nrm_side;
+    a.cs_on = colsum ? 1 : 0;
+    a.slab_stride = stride;
+    for (int i = 0; i < 8; ++i) a.cs.p[i] = (colsum && i < G) ? colsum[i] : nullptr;
     PendingDgrad& p = g_pending;
     if (p.active && pair_wgrad_tile<BM, BN>() && (long)p.gx * p.gy * p.gz + (long)gx * gy * Sp * G < 0x7fffffffL) {
         p.active = false;
@@ -1266,7 +1300,9 @@ int launch_wgrad2(const float* Sm, const float* Bg, float* const* dW, int G, lon
     }
     if (slab)
         for (int i = 0; i < G; ++i)
-            if (int rc = launch_reduce(out + (long)i * Sp * M * N, dW[i], (long)M * N, Sp, N, nullptr, 0, 0.f, accumulate, st)) return rc;
+            if (int rc = launch_reduce(out + (long)i * Sp * stride, dW[i], (long)M * N, Sp, N, nullptr, 0, 0.f, accumulate, st,
+                                       colsum ? colsum[i] : nullptr, colsum ? M : 0))
+                return rc;
     return MOVAE_OK;
 }
 

@@ -523,6 +523,9 @@ class Conv(Function):
                 _call("movae_act_bwd_bias_grouped", G, dy.data_ptr(), y.data_ptr(), dpre.data_ptr(),
                       (C.c_void_p * G)(*[t.data_ptr() for t in db_done]), y.numel() // co, co, L.ACT[ctx.act], float(ctx.slope), 0,
                       wsp, wsb, st)
+            elif co % 4 == 0 and dy.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0:  # all groups in one launch, no bias sums
+                _call("movae_act_bwd_bias_grouped", G, dy.data_ptr(), y.data_ptr(), dpre.data_ptr(), None, y.numel() // co, co,
+                      L.ACT[ctx.act], float(ctx.slope), 0, wsp, wsb, st)
             else:
                 for g in range(G):
                     _call("movae_act_bwd", dy[g].data_ptr(), y.data_ptr(), dpre[g].data_ptr(), y.numel(), L.ACT[ctx.act],
@@ -578,7 +581,12 @@ class Conv(Function):
 
 
 def _fuse_bias_grad(ctx, dy, y, co):
-    """The conv applied an activation in its epilogue and its bias needs a gradient: one fused pass (eltwise.hip)."""
+    """The conv applied an activation in its epilogue and its bias needs a gradient: one fused pass (eltwise.hip) -- unless the
+    weight-gradient kernel forms the column sums of dy itself while it stages dy (conv, 4-aligned channels: the implicit-GEMM
+    wgrad; movae_conv2d_wgrad* falls back to the stand-alone column sum when its kernel cannot)."""
+    ci = ctx.geom[3]
+    if not ctx.transposed and ci % 4 == 0 and co % 4 == 0:
+        return False
     return (ctx.has_bias and ctx.needs_input_grad[2] and not ctx.bias_grad_is_zero and co % 4 == 0 and
             dy.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0)
 
