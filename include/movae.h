@@ -316,6 +316,15 @@ typedef struct movae_fuse {
     float* bn_part;
     size_t bn_cap;         /* floats available at bn_part */
     int bn_ppg;            /* OUT: partial pairs per group and channel */
+    /* input-gradient passes, alternatively: dx is the gradient w.r.t. the OUTPUT of the epilogue activation of the layer before
+     * (Conv2d(bias) -> LeakyReLU / ReLU -> this layer, models/betatc_vae.py:104-110, vq_vae.py:36-47), whose stored output is
+     * ep_act_y [n][hi][wi][ci] (shared by the `groups` cotangents).  The epilogue / split-K reduce then stores
+     * dx * act'(ep_act_y) -- the gradient w.r.t. that layer's PRE-activation -- and sets ep_act_done = 1; 0 on return: not applied
+     * (kernel without the epilogue), dx is the plain input gradient and the caller runs movae_act_bwd. */
+    const float* ep_act_y;
+    int ep_act;            /* MOVAE_ACT_* of that layer */
+    float ep_slope;
+    int ep_act_done;       /* OUT */
 } movae_fuse_t;
 int movae_conv2d_fwd_f(const float* x, const float* w, const float* bias, float* y,
                        int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad,

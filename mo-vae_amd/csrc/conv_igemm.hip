@@ -37,6 +37,17 @@ struct Epilogue {
     float slope;
 };
 
+// The result is the gradient w.r.t. the OUTPUT of an activation -- the epilogue activation of the layer before, whose stored output
+// is y (same layout as the result; shared by the cotangent groups, per_group floats each): multiply by act'(.) taken from that
+// output, so the layer before starts its backward from the pre-activation gradient and runs no activation-backward pass.
+struct ActMul {
+    const float* y;  // null: off
+    int act;
+    float slope;
+    long per_group;  // floats of y
+    int gx_per_group;  // BWD-form kernel: row blocks per group and class (0: one group)
+};
+
 // Division by a launch-invariant divisor inside the k loops (tap / pixel decoding of the gathers): n / d for 0 <= n < 2^31 as
 // one v_mul_hi + one shift instead of the ~35-instruction software division (the 128x128 kernels issued 4-8 VALU instructions
 // per MFMA, most of them these divisions; PMC: profiles/r02_pmc_igemm128.json).  m = ceil(2^(31+s) / d), s = ceil(log2 d):
@@ -125,6 +136,10 @@ struct FuseCtx {
     size_t bn_cap = 0;
     int bn_groups = 1;
     int bn_ppg = 0;                   // out: partial pairs per group and column (0 = none)
+    // activation derivative of the layer before, applied by the input-gradient pass's epilogue / reduce (ActMul)
+    ActMul am{nullptr, 0, 0.f, 0, 0};
+    int am_groups = 1;
+    bool am_done = false;             // out
 };
 static thread_local FuseCtx g_fuse;
 
@@ -583,7 +598,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad(const float* __restrict__ S, 
 // gradient slab carries behind its M * N floats; n1 == total, out2 == null otherwise)
 __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ slab, float* __restrict__ out, long total,
                                                      int S, int N, const float* __restrict__ bias, int act, float slope,
-                                                     int accumulate, float* __restrict__ out2, long n1) {
+                                                     int accumulate, float* __restrict__ out2, long n1, ActMul am) {
     const int il = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const long i = (long)blockIdx.x * 16 + il;
     float v = 0.f;
@@ -599,7 +614,7 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ s
     if (threadIdx.x < 16 && i < total) {
         v = (sh[0][il] + sh[1][il]) + (sh[2][il] + sh[3][il]);
         if (bias) v += bias[i % N];
-        v = apply_act(v, act, slope);
+        v = am.y ? v * act_grad_from_out(am.y[i % am.per_group], am.act, am.slope) : apply_act(v, act, slope);
         float* o = i < n1 ? out + i : out2 + (i - n1);
         *o = accumulate ? *o + v : v;
     }
@@ -609,7 +624,7 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ s
 // flight per lane; the 16 split-lanes of a wave fold with shuffles, the 4 waves through LDS.  Deterministic.
 __global__ __launch_bounds__(256) void splitk_reduce_wide(const float* __restrict__ slab, float* __restrict__ out, long total,
                                                           int S, int N, const float* __restrict__ bias, int act, float slope,
-                                                          int accumulate, float* __restrict__ out2, long n1) {
+                                                          int accumulate, float* __restrict__ out2, long n1, ActMul am) {
     const int il = threadIdx.x & 3, sl = threadIdx.x >> 2;
     const long i = ((long)blockIdx.x * 4 + il) * 4;
     f32x4 acc[4];
@@ -648,7 +663,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_wide(const float* __restric
         for (int j = 0; j < 4; ++j) {
             float r = v[j];
             if (bias) r += bias[(i + j) % N];
-            o[j] += apply_act(r, act, slope);
+            o[j] += am.y ? r * act_grad_from_out(am.y[(i + j) % am.per_group], am.act, am.slope) : apply_act(r, act, slope);
         }
         *reinterpret_cast<f32x4*>(dst) = o;
     }
@@ -657,13 +672,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_wide(const float* __restric
 // few slabs over many outputs: one thread per output, grid-stride
 __global__ __launch_bounds__(256) void splitk_reduce_flat(const float* __restrict__ slab, float* __restrict__ out, long total,
                                                           int S, int N, const float* __restrict__ bias, int act, float slope,
-                                                          int accumulate, float* __restrict__ out2, long n1) {
+                                                          int accumulate, float* __restrict__ out2, long n1, ActMul am) {
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         float v = 0.f;
         for (int z = 0; z < S; ++z) v += slab[(long)z * total + i];
         if (bias) v += bias[i % N];
-        v = apply_act(v, act, slope);
+        v = am.y ? v * act_grad_from_out(am.y[i % am.per_group], am.act, am.slope) : apply_act(v, act, slope);
         float* o = i < n1 ? out + i : out2 + (i - n1);
         *o = accumulate ? *o + v : v;
     }
@@ -676,7 +691,7 @@ struct ClsSplit {
 };
 __global__ __launch_bounds__(256) void splitk_reduce_cls(const float* __restrict__ slab, float* __restrict__ out, long total, int N,
                                                          int Ho, int Wo, int stride, ClsSplit scls, const float* __restrict__ bias,
-                                                         int act, float slope) {
+                                                         int act, float slope, ActMul am) {
     const long nv = total / 4, gstride = (long)gridDim.x * blockDim.x;
     for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nv; q += gstride) {
         const long i = q * 4, p = i / N;
@@ -685,8 +700,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_cls(const float* __restrict
         const int S = scls.s[(ho % stride) * stride + (wo % stride)];
         f32x4 v = *reinterpret_cast<const f32x4*>(slab + i);
         for (int z = 1; z < S; ++z) v += *reinterpret_cast<const f32x4*>(slab + (long)z * total + i);
+        if (am.y) {
+            const f32x4 y4 = *reinterpret_cast<const f32x4*>(am.y + i % am.per_group);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j] + (bias ? bias[n + j] : 0.f), act, slope);
+            for (int j = 0; j < 4; ++j) v[j] *= act_grad_from_out(y4[j], am.act, am.slope);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j] + (bias ? bias[n + j] : 0.f), act, slope);
+        }
         *reinterpret_cast<f32x4*>(out + i) = v;
     }
 }
@@ -766,22 +787,22 @@ int g_force_split = 0;           // movae_bench_force_split(): > 0 pins the spli
 bool g_bench_main_only = false;  // movae_bench_main_kernel_only(): time the MFMA kernel without its epilogue launches
 
 inline int launch_reduce(const float* slab, float* out, long n1, int S, int N, const float* bias, int act, float slope,
-                         int accumulate, hipStream_t st, float* out2 = nullptr, long n2 = 0) {
+                         int accumulate, hipStream_t st, float* out2 = nullptr, long n2 = 0, ActMul am = ActMul{nullptr, 0, 0.f, 0, 0}) {
     if (g_bench_main_only) return MOVAE_OK;
     if (!out2) n2 = 0;
     const long total = n1 + n2;  // floats per slab: n1 outputs for `out`, then n2 for `out2`
     if (S >= 64 && total % 4 == 0 && n1 % 4 == 0 && total <= (1L << 20) &&
         ((reinterpret_cast<uintptr_t>(slab) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(out2)) & 15) == 0) {
         hipLaunchKernelGGL(splitk_reduce_wide, dim3(ceil_div(total, 16)), dim3(256), 0, st, slab, out, total, S, N, bias, act,
-                           slope, accumulate, out2, n1);
+                           slope, accumulate, out2, n1, am);
     } else if (S >= 8 && total <= (1L << 20)) {
         hipLaunchKernelGGL(splitk_reduce, dim3(ceil_div(total, 16)), dim3(256), 0, st, slab, out, total, S, N, bias, act, slope,
-                           accumulate, out2, n1);
+                           accumulate, out2, n1, am);
     } else {
         long gq = (total + 255) / 256;
         if (gq > 4096) gq = 4096;
         hipLaunchKernelGGL(splitk_reduce_flat, dim3((int)gq), dim3(256), 0, st, slab, out, total, S, N, bias, act, slope,
-                           accumulate, out2, n1);
+                           accumulate, out2, n1, am);
     }
     MOVAE_CHECK_LAUNCH("splitk_reduce");
     return MOVAE_OK;
@@ -1185,14 +1206,18 @@ struct FuseScope {
 inline void fuse_bn_install(movae_fuse_t* f, int groups) {
     if (!f) return;
     f->bn_ppg = 0;
+    f->ep_act_done = 0;
+    if (f->ep_act_y && f->ep_act != MOVAE_ACT_NONE && groups >= 1 && (reinterpret_cast<uintptr_t>(f->ep_act_y) & 15) == 0)
+        g_fuse.am = ActMul{f->ep_act_y, f->ep_act, f->ep_slope, 0, 0}, g_fuse.am_groups = groups, g_fuse.am_done = false;
     if (f->bn_y && f->bn_scale && f->bn_shift && f->bn_part && f->bn_cap > 0 && groups >= 1) {
         g_fuse.bn_y = f->bn_y, g_fuse.bn_scale = f->bn_scale, g_fuse.bn_shift = f->bn_shift, g_fuse.bn_slope = f->bn_slope;
         g_fuse.bn_part = f->bn_part, g_fuse.bn_cap = f->bn_cap, g_fuse.bn_groups = groups;
     }
 }
 inline void fuse_bn_collect(movae_fuse_t* f) {
-    if (f) f->bn_ppg = g_fuse.bn_ppg;
+    if (f) f->bn_ppg = g_fuse.bn_ppg, f->ep_act_done = g_fuse.am_done ? 1 : 0;
     g_fuse.bn_y = nullptr, g_fuse.bn_part = nullptr, g_fuse.bn_ppg = 0, g_fuse.bn_groups = 1;
+    g_fuse.am.y = nullptr, g_fuse.am_groups = 1, g_fuse.am_done = false;
 }
 #define MOVAE_CHECK_FUSE(f, c)                                                                                                   \
     MOVAE_CHECK_ARG(!(f) || !(f)->in_scale ||                                                                                    \

@@ -151,6 +151,7 @@ struct FwdArgs {
     float* stats;  // column partial sums of the stored result [gx * WM][2][N], or null (only without split-K)
     BnBwd bb;      // the result is a fused BatchNorm's output gradient: its backward sums (only without split-K)
     FastDiv fd_cr, fd_kw, fd_wlen;  // divisions of the k loop: by g.Cr, g.KW, g.wlen
+    ActMul am;     // the stored result is multiplied by the previous layer's activation derivative (only without split-K: else the reduce)
 };
 
 template <int BM, int BN>
@@ -326,9 +327,10 @@ __device__ __forceinline__ void igemm2_fwd_body(const FwdArgs& a, float* __restr
     // Fused BatchNorm side products of the stores (never both): `stats` = column sums (v, v^2) of what is stored (the host asks
     // only with act == none); `bb` = the stored value is dout of a fused BatchNorm over bb.y: sums (d, d * y).  One partial pair
     // per wave and column; the two lane halves fold with one shuffle.  (No row block straddles two cotangent groups: host.)
-    const bool st_on = a.stats && !to_slab, bb_on = a.bb.y && !to_slab;
+    const bool st_on = a.stats && !to_slab, bb_on = a.bb.y && !to_slab, am_on = a.am.y && !to_slab;
     const long pidx = (long)bx * T::WM + wm;
-    const int yrow0 = bb_on ? m0 % a.bb.rows_per_group : 0;  // the block's first row inside its group
+    // the block's first row inside its cotangent group (bb / am: the auxiliary tensor is shared by the groups)
+    const int yrow0 = bb_on ? m0 % a.bb.rows_per_group : (am_on ? (int)(m0 % (a.am.per_group / N)) : 0);
 #pragma unroll
     for (int tn = 0; tn < T::TN; ++tn) {
         const int n = n0 + wn * T::TN * 32 + tn * 32 + l31;
@@ -339,8 +341,8 @@ __device__ __forceinline__ void igemm2_fwd_body(const FwdArgs& a, float* __restr
         // all of the column's y values are requested BEFORE the first store: `out` and `y` may alias as far as the compiler
         // knows, so a load placed after a store waits for it -- sixteen serial round trips per tile otherwise
         float yv[T::TM * 16];
-        if (bb_on) {
-            const float* __restrict__ yp = a.bb.y;
+        if (bb_on || am_on) {
+            const float* __restrict__ yp = bb_on ? a.bb.y : a.am.y;
 #pragma unroll
             for (int tm = 0; tm < T::TM; ++tm)
 #pragma unroll
@@ -357,7 +359,8 @@ __device__ __forceinline__ void igemm2_fwd_body(const FwdArgs& a, float* __restr
                 const int m = m0 + ml;
                 const float v = acc[tm * T::TN + tn][r];
                 if (m < M) {
-                    const float o = to_slab ? v : apply_act(v + bv, ep.act, ep.slope);
+                    const float o = to_slab ? v
+                                  : (am_on ? v * act_grad_from_out(yv[tm * 16 + r], a.am.act, a.am.slope) : apply_act(v + bv, ep.act, ep.slope));
                     out[(long)m * N + n] = o;
                     if (st_on) {
                         s1 += o;
@@ -405,6 +408,7 @@ struct BwdArgs {
     FastDiv fd_cr;         // k loop: by g.Cr ...
     FastDiv fd_nb[4];      // ... and, per output-parity class, by the class's tap columns nB
     FastDiv fd_hw[4], fd_w[4];  // epilogue, per output-parity class: by Hoc * Woc and by Woc
+    ActMul am;             // see FwdArgs
 };
 
 template <int BM, int BN>
@@ -606,9 +610,10 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
     const bool to_slab = slab != nullptr;
     float* out = to_slab ? slab + (long)split * total : Y;
     // fused BatchNorm side products of the stores (see igemm2_fwd_body); the output pixel p is computed once for both
-    const bool st_on = a.stats && !to_slab, bb_on = a.bb.y && !to_slab;
+    const bool st_on = a.stats && !to_slab, bb_on = a.bb.y && !to_slab, am_on = a.am.y && !to_slab;
     long pidx = ((long)cls * a.stats_gx + bx) * T::WM + wm;
     long ybase = 0;  // first pixel of the block's cotangent group
+    if (am_on && a.am.gx_per_group > 0) ybase = (long)(bx / a.am.gx_per_group) * (a.am.per_group / N);
     if (bb_on) {
         // classes are equally large and no row block straddles two cotangent groups (host): group gi owns bpg row blocks of
         // every class; its partials are [gi * ppg, (gi + 1) * ppg), ordered (class, block in group, wave row)
@@ -638,8 +643,8 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
         }
     // BnBwd: every y value is requested before the first store (see igemm2_fwd_body)
     float yv[T::TM * 16 * T::TN];
-    if (bb_on) {
-        const float* __restrict__ yp = a.bb.y;
+    if (bb_on || am_on) {
+        const float* __restrict__ yp = bb_on ? a.bb.y : a.am.y;
 #pragma unroll
         for (int i = 0; i < T::TM * 16; ++i)
 #pragma unroll
@@ -661,7 +666,9 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
                 if (n >= N) continue;
                 const float bv = (!to_slab && ep.bias) ? ep.bias[n] : 0.f;
                 const float v = acc[tm * T::TN + tn][r];
-                const float o = to_slab ? v : apply_act(v + bv, ep.act, ep.slope);
+                const float o = to_slab ? v
+                              : (am_on ? v * act_grad_from_out(yv[(tm * 16 + r) * T::TN + tn], a.am.act, a.am.slope)
+                                       : apply_act(v + bv, ep.act, ep.slope));
                 out[p * N + n] = o;
                 if (st_on) {
                     s1[tn] += o;
@@ -1007,6 +1014,7 @@ struct PendingDgrad {
     long total = 0;
     BnBwd rbb{};          // rbb.y != null: the reduce also emits the fused BatchNorm's backward sums (rows per block: rbb_rpb)
     int rbb_rpb = 0;
+    ActMul ram{nullptr, 0, 0.f, 0, 0};  // ram.y != null: the reduce multiplies by the previous layer's activation derivative
 };
 static thread_local PendingDgrad g_pending;
 static thread_local bool g_pair_collect = false;
@@ -1033,7 +1041,7 @@ inline int finish_pending(hipStream_t st) {  // the stashed dgrad's reduce
             MOVAE_CHECK_LAUNCH("splitk_reduce_stats (bn bwd)");
             return MOVAE_OK;
         }
-        return launch_reduce(a.slab, a.Y, (long)a.M * a.g.Nn, p.S, a.g.Nn, a.ep.bias, a.ep.act, a.ep.slope, 0, st);
+        return launch_reduce(a.slab, a.Y, (long)a.M * a.g.Nn, p.S, a.g.Nn, a.ep.bias, a.ep.act, a.ep.slope, 0, st, nullptr, 0, p.ram);
     }
     const BwdArgs& a = p.ba;
     if (p.rbb.y) {
@@ -1044,7 +1052,7 @@ inline int finish_pending(hipStream_t st) {  // the stashed dgrad's reduce
     long gq = (a.total / 4 + 255) / 256;
     if (gq > 4096) gq = 4096;
     hipLaunchKernelGGL(splitk_reduce_cls, dim3((unsigned)gq), dim3(256), 0, st, a.slab, a.Y, a.total, a.g.Nn, a.g.Ho, a.g.Wo, a.g.stride,
-                       a.scls, a.ep.bias, a.ep.act, a.ep.slope);
+                       a.scls, a.ep.bias, a.ep.act, a.ep.slope, p.ram);
     MOVAE_CHECK_LAUNCH("splitk_reduce_cls");
     return MOVAE_OK;
 }
@@ -1097,11 +1105,23 @@ int launch_fwd2(const float* X, const float* W, float* Y, const Geom& g, const E
             plan_reduce_bnbwd(M, g.Nn, &rbb, &rbb_rpb);
         }
     }
+    // the previous layer's activation derivative on the result: in the epilogue (unsplit) or in the reduce
+    ActMul ram{nullptr, 0, 0.f, 0, 0};
+    if (g_fuse.am.y && ep.act == MOVAE_ACT_NONE && !ep.bias && !rbb.y && !a.bb.y && M % g_fuse.am_groups == 0) {
+        const long rpg = M / g_fuse.am_groups;
+        if (g_fuse.am_groups == 1 || rpg % BM == 0 || S > 1) {
+            ActMul am = g_fuse.am;
+            am.per_group = rpg * g.Nn;
+            if (S == 1) a.am = am;
+            else ram = am;
+            g_fuse.am_done = true;
+        }
+    }
     if (g_pair_collect && pair_dgrad_tile<BM, BN>()) {
         PendingDgrad& p = g_pending;
         p.active = true;
         p.form = 0, p.bm = BM, p.bn = BN, p.fa = a, p.gx = gx, p.gy = gy, p.gz = S;
-        p.rbb = rbb, p.rbb_rpb = rbb_rpb;
+        p.rbb = rbb, p.rbb_rpb = rbb_rpb, p.ram = ram;
         p.reduce = S > 1, p.S = S, p.total = (long)M * g.Nn;
         p.ws_used = S > 1 ? (size_t)M * g.Nn * sizeof(float) * S : 0;
         return MOVAE_OK;
@@ -1118,7 +1138,7 @@ int launch_fwd2(const float* X, const float* W, float* Y, const Geom& g, const E
             MOVAE_CHECK_LAUNCH("splitk_reduce_stats");
             return MOVAE_OK;
         }
-        return launch_reduce(slab, Y, (long)M * g.Nn, S, g.Nn, ep.bias, ep.act, ep.slope, 0, st);
+        return launch_reduce(slab, Y, (long)M * g.Nn, S, g.Nn, ep.bias, ep.act, ep.slope, 0, st, nullptr, 0, ram);
     }
     return MOVAE_OK;
 }
@@ -1209,11 +1229,31 @@ int launch_bwd2(const float* X, const float* W, float* Y, const Geom& g, const E
             plan_reduce_bnbwd(pix, g.Nn, &rbb, &rbb_rpb);
         }
     }
+    ActMul ram{nullptr, 0, 0.f, 0, 0};  // (see launch_fwd2)
+    if (g_fuse.am.y && ep.act == MOVAE_ACT_NONE && !ep.bias && !rbb.y && !a.bb.y) {
+        const long pix = (long)g.Nimg * g.Ho * g.Wo;
+        const int G = g_fuse.am_groups;
+        if (pix % G == 0) {
+            ActMul am = g_fuse.am;
+            am.per_group = pix / G * g.Nn;
+            bool ok = true;
+            if (Sreal == 1 && G > 1) {  // epilogue: whole row blocks per group and class (equally large classes)
+                const long rows_c = pix / ncls / G;
+                ok = g.Ho % s == 0 && g.Wo % s == 0 && pix % ((long)ncls * G) == 0 && rows_c % BM == 0;
+                am.gx_per_group = ok ? (int)(rows_c / BM) : 0;
+            }
+            if (ok) {
+                if (Sreal == 1) a.am = am;
+                else ram = am;
+                g_fuse.am_done = true;
+            }
+        }
+    }
     if (g_pair_collect && pair_dgrad_tile<BM, BN>()) {
         PendingDgrad& p = g_pending;
         p.active = true;
         p.form = 1, p.bm = BM, p.bn = BN, p.ba = a, p.gx = gx, p.gy = gy, p.gz = zsum;
-        p.rbb = rbb, p.rbb_rpb = rbb_rpb;
+        p.rbb = rbb, p.rbb_rpb = rbb_rpb, p.ram = ram;
         p.reduce = Sreal > 1, p.S = Sreal, p.total = total;
         p.ws_used = Sreal > 1 ? (size_t)total * sizeof(float) * Sreal : 0;
         return MOVAE_OK;
@@ -1233,7 +1273,7 @@ int launch_bwd2(const float* X, const float* W, float* Y, const Geom& g, const E
         long gq = (total / 4 + 255) / 256;
         if (gq > 4096) gq = 4096;
         hipLaunchKernelGGL(splitk_reduce_cls, dim3((unsigned)gq), dim3(256), 0, st, slab, Y, total, g.Nn, g.Ho, g.Wo, s, scls, ep.bias,
-                           ep.act, ep.slope);
+                           ep.act, ep.slope, ram);
         MOVAE_CHECK_LAUNCH("splitk_reduce_cls");
     }
     return MOVAE_OK;

@@ -138,16 +138,24 @@ class Stack(tnn.Sequential):
     """nn.Sequential (same child names, hence same state_dict keys) whose forward fuses
     conv -> [batchnorm] -> activation runs into the conv / batch-norm kernels' epilogues."""
 
-    def forward(self, x):
+    def forward(self, x, act_in=None):
         """x: an NHWC tensor or an ops.LazyBN (the unmaterialised output of a fused BatchNorm); may return either -- a LazyBN
         leaves a Stack only when its last module is a fused BatchNorm (+ activation), and is handed on to Stacks and convs
-        as it is; every other module receives the materialised tensor."""
+        as it is; every other module receives the materialised tensor.
+
+        Activation links (ops.ActLink): the output of a conv + activation pair that is handed to exactly one next conv (the next
+        module of this Stack, or the first conv of the Stack that follows in an enclosing Stack: `act_in` / `self._out_link`)
+        lets that conv's input-gradient pass apply the activation derivative, so the pair's backward has no pass of its own."""
         mods = list(self)
         i, n = 0, len(mods)
+        link = act_in  # the link whose activation output `x` currently is (None: x is something else)
+        self._out_link = None
         while i < n:
             m = mods[i]
             if isinstance(m, Stack):
-                x = m(x)
+                x = m(x, link)
+                link = m._out_link
+                m._out_link = None
                 i += 1
             elif isinstance(m, (Conv2d, ConvTranspose2d)):
                 nxt = mods[i + 1] if i + 1 < n else None
@@ -155,23 +163,29 @@ class Stack(tnn.Sequential):
                     act = mods[i + 2] if i + 2 < n and isinstance(mods[i + 2], _Act) else None
                     kind = act.kind if act is not None else None
                     if FUSE_BN and nxt.training and kind in (None, "lrelu", "relu") and m.out_channels % 4 == 0:
-                        fusion = ops.ConvFusion(want_stats=True)
+                        fusion = ops.ConvFusion(want_stats=True, act_in=link)
                         if isinstance(x, ops.LazyBN):
                             fusion.in_scale, fusion.in_shift, fusion.in_slope, fusion.link = x.scale, x.shift, x.slope, x.link
                             x = x.y
                         x = nxt.forward_lazy(m(x, None, True, fusion), kind, fusion)
                     else:
-                        x = nxt(m(x, None, nxt.training), kind)
+                        x = nxt(m(x, None, nxt.training, ops.ConvFusion(act_in=link) if link is not None else None), kind)
+                    link = None
                     i += 3 if act is not None else 2
                 elif isinstance(nxt, _Act):
-                    x = m(x, nxt.kind)
+                    out = ops.ActLink() if (nxt.kind in ("lrelu", "relu") and not isinstance(x, ops.LazyBN)) else None
+                    x = m(x, nxt.kind, False, ops.ConvFusion(act_in=link, act_out=out) if (link is not None or out is not None) else None)
+                    link = out
                     i += 2
                 else:
-                    x = m(x)
+                    x = m(x, None, False, ops.ConvFusion(act_in=link) if link is not None else None)
+                    link = None
                     i += 1
             else:
                 x = m(ops.materialize(x))
+                link = None
                 i += 1
+        self._out_link = link
         return x
 
 

@@ -264,16 +264,33 @@ def join_wgrad():
         L.DEFER.join()
 
 
+class ActLink:
+    """Shared by a conv whose epilogue applied an activation (the producer) and the ONE conv that consumes its output (nn.Stack
+    hands it to the next module only, so the output has no other reader): the consumer's input-gradient pass multiplies its
+    result by act'(y) in the epilogue / split-K reduce (movae_fuse_t::ep_act_*) and records the tensor it produced in `applied`;
+    the producer's backward, handed that very tensor, starts from the pre-activation gradient -- no activation-backward pass."""
+    __slots__ = ("y", "act", "slope", "applied")
+
+    def __init__(self):
+        self.y, self.act, self.slope, self.applied = None, None, 0.0, None
+
+
+#: MOVAE_FUSE_ACT=0: every conv runs its own activation-backward pass (A/B knob)
+FUSE_ACT = __import__("os").environ.get("MOVAE_FUSE_ACT", "1") != "0"
+
+
 class ConvFusion:
     """What a conv call is asked to fuse of its neighbouring BatchNorms (include/movae.h: movae_fuse_t).
     in_*: the input is the RAW output y of a producer conv whose BatchNorm + activation this conv applies while loading,
     x = leaky_relu(in_scale[c] * y + in_shift[c], in_slope).  want_stats: the epilogue (or split-K reduce) also emits the
     per-channel partial sums of this conv's own output for the BatchNorm that follows it: `stats` / `parts` on return."""
-    __slots__ = ("in_scale", "in_shift", "in_slope", "want_stats", "stats", "parts", "link")
+    __slots__ = ("in_scale", "in_shift", "in_slope", "want_stats", "stats", "parts", "link", "act_in", "act_out")
 
-    def __init__(self, in_scale=None, in_shift=None, in_slope=1.0, want_stats=False, link=None):
+    def __init__(self, in_scale=None, in_shift=None, in_slope=1.0, want_stats=False, link=None, act_in=None, act_out=None):
         self.in_scale, self.in_shift, self.in_slope, self.want_stats = in_scale, in_shift, float(in_slope), want_stats
         self.stats, self.parts = None, 0
+        #: ActLink of the producer whose activation output is this conv's input / ActLink this conv fills for its consumer
+        self.act_in, self.act_out = act_in, act_out
         #: dict shared with the BatchNormLazy node whose output this conv consumes: the conv's backward leaves that
         #: BatchNorm's backward sums here (emitted by the input-gradient epilogue), the BatchNorm's backward picks them up
         self.link = link
@@ -286,9 +303,12 @@ FUSE_NORM = __import__("os").environ.get("MOVAE_FUSE_NORM", "1") != "0"
 FUSE_STATS = __import__("os").environ.get("MOVAE_FUSE_STATS", "1") != "0"
 
 
-def _fuse_struct(in_norm, stats=None, bn=None):
-    """bn = (y, scale, shift, slope, part): the dispatched input-gradient pass also emits the BatchNorm backward sums."""
+def _fuse_struct(in_norm, stats=None, bn=None, ep=None):
+    """bn = (y, scale, shift, slope, part): the dispatched input-gradient pass also emits the BatchNorm backward sums.
+    ep = ActLink: its epilogue multiplies by the producer's activation derivative."""
     f = L.MovaeFuse()
+    if ep is not None:
+        f.ep_act_y, f.ep_act, f.ep_slope = ep.y.data_ptr(), L.ACT[ep.act], float(ep.slope)
     if in_norm is not None:
         f.in_scale, f.in_shift, f.in_slope = in_norm[0].data_ptr(), in_norm[1].data_ptr(), float(in_norm[2])
     if stats is not None:
@@ -313,6 +333,32 @@ def _bn_request(ctx, x, in_norm, G):
     rows = x.numel() // c
     part = torch.empty(G * (rows // 8 + 64) * 2 * c, dtype=torch.float32, device=x.device)
     return (x, in_norm[0], in_norm[1], in_norm[2], part)
+
+
+def _act_request(ctx, x, bn):
+    """The ActLink whose activation derivative this conv's input-gradient pass should apply, or None."""
+    link = getattr(ctx, "act_in", None)
+    if (not FUSE_ACT or link is None or link.y is None or bn is not None or not ctx.needs_input_grad[0] or
+            link.y.shape != x.shape or link.y.data_ptr() != x.data_ptr()):
+        return None
+    return link
+
+
+def _act_publish(link, f, dx):
+    if link is not None and f is not None and int(f.ep_act_done):
+        link.applied = dx.data_ptr()
+
+
+def _act_take(ctx, dy):
+    """True when dy already is the PRE-activation gradient (the consumer's epilogue applied act'(y) -- ActLink)."""
+    link = getattr(ctx, "act_out", None)
+    if link is None or link.applied is None:
+        return False
+    ap, link.applied = link.applied, None
+    if ap != dy.data_ptr():
+        raise RuntimeError("activation derivative was fused into the consumer's input gradient, but a different tensor reached the "
+                           "producer's backward (its output has another reader?): set MOVAE_FUSE_ACT=0")
+    return True
 
 
 def _bn_publish(ctx, f, bn, dx, G):
@@ -385,6 +431,11 @@ class Conv(Function):
         ctx.bias_grad_is_zero = bias_grad_is_zero
         ctx.in_slope = in_norm[2] if in_norm is not None else None
         ctx.bn_link = fusion.link if (fusion is not None and in_norm is not None) else None
+        ctx.act_in = fusion.act_in if (fusion is not None and in_norm is None) else None
+        ctx.act_out = None
+        if fusion is not None and fusion.act_out is not None and L.ACT[act]:
+            ctx.act_out = fusion.act_out
+            ctx.act_out.y, ctx.act_out.act, ctx.act_out.slope, ctx.act_out.applied = y.detach(), act, slope, None
         ctx.save_for_backward(x, w, y if L.ACT[act] else None, b, *(in_norm[:2] if in_norm is not None else ()))
         return y
 
@@ -396,7 +447,7 @@ class Conv(Function):
         return sv[0], sv[1], sv[2], sv[3], in_norm
 
     @staticmethod
-    def _wgrad_call(name, in_norm, geom, args, bn=None):
+    def _wgrad_call(name, in_norm, geom, args, bn=None, ep=None):
         """One weight-gradient (or paired dgrad + wgrad) call; with a virtual activation operand the *_f form, falling back
         to a materialised activation where the dispatched kernel cannot apply the transform.  args: (head, x_index, tail).
         bn: BatchNorm-backward request for the paired call's dgrad (_bn_request).  Returns (x as used, fuse struct or None)."""
@@ -406,10 +457,10 @@ class Conv(Function):
             head[xi] = scale_shift_act(head[xi], *in_norm)
             in_norm = None
         ptrs = lambda h: [t.data_ptr() if isinstance(t, torch.Tensor) else t for t in h]  # noqa: E731
-        if in_norm is None and bn is None:
+        if in_norm is None and bn is None and ep is None:
             _call(name, *ptrs(head), *tail)
             return head[xi], None
-        f = _fuse_struct(in_norm, None, bn)
+        f = _fuse_struct(in_norm, None, bn, ep)
         try:
             _call(name + "_f", *ptrs(head), *tail, C.byref(f))
             return head[xi], f
@@ -433,7 +484,7 @@ class Conv(Function):
         st = _st(dy)
         wsp, wsb = _ws(dy)
         db_done = None
-        if L.ACT[ctx.act]:
+        if L.ACT[ctx.act] and not _act_take(ctx, dy):
             dpre = torch.empty_like(dy)
             if _fuse_bias_grad(ctx, dy, y, co):
                 # activation backward and the bias gradient (column sums of dpre) in one pass over dy
@@ -456,18 +507,20 @@ class Conv(Function):
             side.wait_stream(main)
         pair = need_w and ctx.needs_input_grad[0] and not fork  # both gradients, one stream: one call, one main launch
         bn = _bn_request(ctx, x, in_norm, 1)
+        ep = _act_request(ctx, x, bn)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             wm = weight_mem(w)
             if not pair:
-                if bn is None:
+                if bn is None and ep is None:
                     _call(pre + "dgrad", dy.data_ptr(), wm.data_ptr(), dx.data_ptr(), n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad,
                           wsp, wsb, st)
                 else:
-                    f = _fuse_struct(None, None, bn)
+                    f = _fuse_struct(None, None, bn, ep)
                     _call(pre + "dgrad_f", dy.data_ptr(), wm.data_ptr(), dx.data_ptr(), n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad,
                           wsp, wsb, st, C.byref(f), 1)
                     _bn_publish(ctx, f, bn, dx, 1)
+                    _act_publish(ep, f, dx)
         if fork:
             ws2 = L.workspace(dy.device, slot=1)
             wsp, wsb, st = ws2.data_ptr(), ws2.numel(), side.cuda_stream
@@ -492,8 +545,9 @@ class Conv(Function):
             tail = (n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, acc, wsp, wsb, st)
             if pair:
                 x, f = Conv._wgrad_call(pre + "dgrad_wgrad_grouped", in_norm, ctx.geom,
-                                        ((1, dy, wm, x, dx, (C.c_void_p * 1)(dwm.data_ptr()), dbp), 3, tail), bn)
+                                        ((1, dy, wm, x, dx, (C.c_void_p * 1)(dwm.data_ptr()), dbp), 3, tail), bn, ep)
                 _bn_publish(ctx, f, bn, dx, 1)
+                _act_publish(ep, f, dx)
             else:
                 x, _ = Conv._wgrad_call(pre + "wgrad_grouped", in_norm, ctx.geom, ((1, dy, x, (C.c_void_p * 1)(dwm.data_ptr()), dbp), 2, tail))
             dw = dwm.permute(0, 3, 1, 2)
@@ -516,7 +570,7 @@ class Conv(Function):
         st = _st(dy)
         wsp, wsb = _ws(dy)
         db_done = None
-        if L.ACT[ctx.act]:
+        if L.ACT[ctx.act] and not _act_take(ctx, dy):
             dpre = torch.empty_like(dy)
             if _fuse_bias_grad(ctx, dy, y, co):
                 db_done = [_sink_row(g, b, (co,)) for g in range(G)]
@@ -538,18 +592,20 @@ class Conv(Function):
         defer = L.DEFER if need_w else None
         pair = need_w and ctx.needs_input_grad[0] and defer is None
         bn = _bn_request(ctx, x, in_norm, G)
+        ep = _act_request(ctx, x, bn)
         if ctx.needs_input_grad[0]:
             dx = torch.empty((G,) + tuple(x.shape), dtype=x.dtype, device=x.device)
             wm = weight_mem(w)
             if not pair:
-                if bn is None:
+                if bn is None and ep is None:
                     _call(pre + "dgrad", dy.data_ptr(), wm.data_ptr(), dx.data_ptr(), G * n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad,
                           wsp, wsb, st)
                 else:
-                    f = _fuse_struct(None, None, bn)
+                    f = _fuse_struct(None, None, bn, ep)
                     _call(pre + "dgrad_f", dy.data_ptr(), wm.data_ptr(), dx.data_ptr(), G * n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad,
                           wsp, wsb, st, C.byref(f), G)
                     _bn_publish(ctx, f, bn, dx, G)
+                    _act_publish(ep, f, dx)
         if defer is not None:  # the grouped wgrad goes to the side stream (see wgrad_side_stream)
             side = L.side_stream(dy.device)
             side.wait_stream(torch.cuda.current_stream(dy.device))
@@ -569,8 +625,9 @@ class Conv(Function):
             tail = (n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, 0, wsp, wsb, st)
             if pair:
                 x, f = Conv._wgrad_call(pre + "dgrad_wgrad_grouped", in_norm, ctx.geom,
-                                        ((G, dy, wm, x, dx, arr(*[t.data_ptr() for t in dwm]), dbp), 3, tail), bn)
+                                        ((G, dy, wm, x, dx, arr(*[t.data_ptr() for t in dwm]), dbp), 3, tail), bn, ep)
                 _bn_publish(ctx, f, bn, dx, G)
+                _act_publish(ep, f, dx)
             else:
                 x, _ = Conv._wgrad_call(pre + "wgrad_grouped", in_norm, ctx.geom, ((G, dy, x, arr(*[t.data_ptr() for t in dwm]), dbp), 2, tail))
             dw = [t.permute(0, 3, 1, 2) for t in dwm]

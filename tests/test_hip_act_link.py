@@ -1,0 +1,102 @@
+"""The activation derivative of a conv + activation pair applied by the NEXT conv's input-gradient epilogue (ops.ActLink,
+movae_fuse_t::ep_act_*): chains of nn.Stack modules against the plain PyTorch fp32 chain on the CPU, through every kernel form
+that takes part (FWD / BWD gather, unsplit epilogue and split-K reduce, paired launch, nested Stacks), plus the fallback where the
+consumer's kernel has no such epilogue.  GPU only."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(got, want, what, rtol=1e-3, atol=1e-4):
+    got, want = got.detach().cpu().float().numpy(), want.detach().cpu().float().numpy()
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=atol * max(1.0, float(np.abs(want).max())), err_msg=what)
+
+
+# (name, batch, size, [(kind, cin, cout, k, stride, pad, out_pad, act)], nested)
+CHAINS = [
+    ("enc3", 8, 16, [("conv", 8, 16, 3, 2, 1, 0, "lrelu"), ("conv", 16, 32, 3, 2, 1, 0, "lrelu"), ("conv", 32, 64, 3, 1, 1, 0, None)], False),
+    ("enc3_nested", 8, 16, [("conv", 8, 16, 3, 2, 1, 0, "lrelu"), ("conv", 16, 32, 3, 2, 1, 0, "lrelu"), ("conv", 32, 64, 3, 1, 1, 0, "relu")], True),
+    ("dec3", 8, 4, [("convT", 32, 32, 3, 2, 1, 1, "lrelu"), ("convT", 32, 16, 3, 2, 1, 1, "relu"), ("conv", 16, 8, 3, 1, 1, 0, None)], True),
+    # deep + tiny spatial extent: split-K on every pass (the reduce applies the derivative)
+    ("deep_split", 4, 2, [("conv", 256, 256, 3, 1, 1, 0, "lrelu"), ("conv", 256, 128, 3, 1, 1, 0, "lrelu"), ("conv", 128, 64, 1, 1, 0, 0, None)], False),
+    # big tiles, unsplit epilogue
+    ("wide", 16, 16, [("conv", 64, 128, 3, 1, 1, 0, "relu"), ("conv", 128, 128, 3, 1, 1, 0, "lrelu"), ("convT", 128, 64, 4, 2, 1, 0, None)], False),
+    # consumer without the epilogue (3-channel thin kernel): the producer runs its own activation backward
+    ("thin_consumer", 4, 16, [("conv", 16, 16, 3, 1, 1, 0, "lrelu"), ("conv", 16, 3, 3, 1, 1, 0, None)], False),
+]
+
+
+def _build(spec, nested):
+    from movae_amd import nn as mnn
+
+    mods, groups = [], []
+    for kind, cin, cout, k, s, p, op, act in spec:
+        conv = mnn.Conv2d(cin, cout, k, s, p) if kind == "conv" else mnn.ConvTranspose2d(cin, cout, k, s, p, op)
+        layer = [conv] + ([mnn.LeakyReLU() if act == "lrelu" else mnn.ReLU()] if act else [])
+        groups.append(layer)
+        mods.extend(layer)
+    return (mnn.Stack(*[mnn.Stack(*g) for g in groups]) if nested else mnn.Stack(*mods)), [g[0] for g in groups]
+
+
+@pytest.mark.parametrize("case", CHAINS, ids=[c[0] for c in CHAINS])
+@pytest.mark.parametrize("fused", [True, False])
+def test_conv_act_conv_chain(case, fused, gpu_device, monkeypatch):
+    import movae_amd  # noqa: F401
+    from movae_amd import _lib as L, ops
+
+    name, B, size, spec, nested = case
+    monkeypatch.setattr(ops, "FUSE_ACT", fused)
+    calls = []
+    monkeypatch.setattr(L, "TRACE", lambda nm, a: calls.append(nm))
+    torch.manual_seed(7)
+    stack, convs = _build(spec, nested)
+    stack = stack.to(gpu_device)
+    x = torch.randn(B, spec[0][1], size, size)
+    # ---- PyTorch fp32 reference on the CPU ----
+    xr = x.clone().requires_grad_(True)
+    ws = [(c.weight.detach().cpu().contiguous().clone().requires_grad_(True), c.bias.detach().cpu().clone().requires_grad_(True)) for c in convs]
+    h = xr
+    for (kind, cin, cout, k, s, p, op, act), (w, b) in zip(spec, ws):
+        h = F.conv2d(h, w, b, stride=s, padding=p) if kind == "conv" else F.conv_transpose2d(h, w, b, stride=s, padding=p, output_padding=op)
+        if act:
+            h = F.leaky_relu(h, 0.01) if act == "lrelu" else F.relu(h)
+    cot = torch.randn(h.shape, generator=torch.Generator().manual_seed(3))
+    (h * cot).sum().backward()
+    # ---- HIP ----
+    xh = x.to(gpu_device).requires_grad_(True)
+    out = stack(ops.to_nhwc(xh)).permute(0, 3, 1, 2)
+    _close(out, h, f"{name}: output", rtol=5e-4, atol=5e-5)
+    calls.clear()
+    (out * cot.to(gpu_device)).sum().backward()
+    _close(xh.grad, xr.grad, f"{name}: dx")
+    for i, (c, (w, b)) in enumerate(zip(convs, ws)):
+        _close(c.weight.grad, w.grad, f"{name}: dW{i}")
+        _close(c.bias.grad, b.grad, f"{name}: db{i}")
+    n_act = sum(1 for sp in spec if sp[7])
+    n_bwd = sum(1 for nm in calls if nm.startswith("movae_act_bwd"))
+    if not fused:
+        assert n_bwd == n_act, calls
+    elif name == "thin_consumer":
+        assert n_bwd == 1, calls  # the 3-channel consumer's kernel has no such epilogue: the producer's own pass ran
+    else:
+        last_has_act = spec[-1][7] is not None  # the chain's last activation has no consumer inside the Stack
+        assert n_bwd == (1 if last_has_act else 0), calls
+
+
+def test_two_readers_fail_loudly(gpu_device):
+    """The link is only valid when the consumer is the only reader of the producer's output; nn.Stack guarantees that.  Used by hand
+    with a second reader, the producer's backward must refuse rather than apply the derivative to a sum that already holds it."""
+    import movae_amd  # noqa: F401
+    from movae_amd import nn as mnn, ops
+
+    torch.manual_seed(0)
+    c1, c2 = mnn.Conv2d(8, 16, 3, 1, 1).to(gpu_device), mnn.Conv2d(16, 16, 3, 1, 1).to(gpu_device)
+    x = torch.randn(2, 8, 8, 8, device=gpu_device)
+    link = ops.ActLink()
+    y1 = c1(x, "lrelu", False, ops.ConvFusion(act_out=link))
+    y2 = c2(y1, None, False, ops.ConvFusion(act_in=link))
+    with pytest.raises(RuntimeError, match="another reader"):
+        (y2.sum() + y1.sum()).backward()
