@@ -602,6 +602,127 @@ __global__ __launch_bounds__(256) void thin_wgrad_sweep_k(const float* __restric
     }
 }
 
+// MFMA variant of the sweep (preferred where it applies): the weight gradient of a thin-channel layer is the GEMM
+//   dW[c][tap * TC + j] = sum_pixels Wide[p][c] * ThinPatch[p][tap * TC + j]            (M = 32 wide channels, N = TAPS * TC <= 64)
+// and a v_mfma_f32_32x32x2_f32 step consumes two pixels: lane (half h, l) supplies A = Wide[p + h][c = l] (conflict-free
+// ds_read_b32 of the staged wide tile) and, per 32-column tile, B = the thin pixel's channel j under tap (kh, kw) with
+// (tap, j) = column l -- one gathered ds_read_b32 at a lane-constant offset from the pixel's corner.  Three LDS reads per two
+// MFMAs where the sweep kernel issued (1 + TAPS) reads per TAPS * TC FMAs and was bound by the LDS return bandwidth of its
+// broadcast ds_read_b128 (C5 first layer, 4x4 taps: 217 us for 92 MB of operands).  Same tiling, staging, slab row per block and
+// deterministic reduce as the sweep kernel; the four waves take every fourth pixel pair and fold through LDS.
+template <int TC, int KH, int KW, bool REV>
+__global__ __launch_bounds__(256) void thin_wgrad_mfma_k(const float* __restrict__ Wide, const float* __restrict__ Thin,
+                                                         float* __restrict__ slab, int Hw, int Ww, int Cw, int Ht, int Wt,
+                                                         int stride, int pad, int TH, int TW, int tiles_h, int tiles_w,
+                                                         int Cs, int Cb, long wide_gs, long thin_gs, long slab_gs, Norm nrm, int ntiles) {
+    constexpr int TAPS = KH * KW, NA = TAPS * TC, NT = (NA + 31) / 32;
+    static_assert(NT <= 2, "at most 64 columns");
+    Wide += blockIdx.z * wide_gs;
+    Thin += blockIdx.z * thin_gs;
+    slab += blockIdx.z * slab_gs;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int t = threadIdx.x;
+    const int BH = REV ? TH + KH - 1 : (TH - 1) * stride + KH, BW = REV ? TW + KW - 1 : (TW - 1) * stride + KW;
+    const int npix = TH * TW;
+    float* wideT = lds;                                 // [npix + 1][32] (one zero pixel behind the tile); reused for the fold
+    const int wide_floats = max((npix + 1) * 32, 4 * NT * 1024);
+    float* thinF = lds + wide_floats;                   // [BH * BW] pixels padded to 4 channels
+    const int c0 = blockIdx.y * 32;
+    const int lane = t & 63, half = lane >> 5, l31 = lane & 31, wave = t >> 6;
+    // column n = tile * 32 + l31 -> (tap, j): the float offset of that element from the thin pixel under the wide pixel's corner
+    int delta[NT];
+    float keep[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const int n = u * 32 + l31, nn = n < NA ? n : 0;
+        const int tap = nn / TC, j = nn - tap * TC, kh = tap / KW, kw = tap - kh * KW;
+        delta[u] = ((REV ? KH - 1 - kh : kh) * BW + (REV ? KW - 1 - kw : kw)) * 4 + j;
+        keep[u] = n < NA ? 1.f : 0.f;
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+    const int step = REV ? 1 : stride;
+    // persistent: the block walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and keeps ONE accumulator set -- one fold, one slab
+    // row and one reduce input per block instead of per tile (the per-tile epilogue and the 8192-slab reduce were the cost)
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int b = tile;
+        const int tw = b % tiles_w;
+        b /= tiles_w;
+        const int th = b % tiles_h, img = b / tiles_h;
+        const int y0 = th * TH, x0 = tw * TW;
+        __syncthreads();  // the previous tile's readers are done
+        {
+            const float* Wb = Wide + (long)img * Hw * Ww * Cw + c0;
+            const int q = t & 7;
+            for (int pix = t >> 3; pix < npix + 1; pix += 32) {
+                const int py = pix / TW, px = pix - py * TW;
+                const int y = y0 + py, x = x0 + px;
+                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (pix < npix && y < Hw && x < Ww) {
+                    v = *reinterpret_cast<const f32x4*>(Wb + ((long)y * Ww + x) * Cw + q * 4);
+                    if (nrm.scale)
+                        v = norm_apply(v, *reinterpret_cast<const f32x4*>(nrm.scale + c0 + q * 4),
+                                       *reinterpret_cast<const f32x4*>(nrm.shift + c0 + q * 4), nrm.slope);
+                }
+                *reinterpret_cast<f32x4*>(wideT + pix * 32 + q * 4) = v;
+            }
+            const float* Tb = Thin + (long)img * Ht * Wt * TC;
+            const int ty0 = REV ? y0 + pad - (KH - 1) : y0 * stride - pad, tx0 = REV ? x0 + pad - (KW - 1) : x0 * stride - pad;
+            for (int pix = t; pix < BH * BW; pix += 256) {
+                const int r = pix / BW, c = pix - r * BW;
+                const int y = ty0 + r, x = tx0 + c;
+                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (y >= 0 && y < Ht && x >= 0 && x < Wt) {
+                    const float* src = Tb + ((long)y * Wt + x) * TC;
+#pragma unroll
+                    for (int j = 0; j < TC; ++j) v[j] = src[j];
+                }
+                *reinterpret_cast<f32x4*>(thinF + pix * 4) = v;
+            }
+        }
+        __syncthreads();
+        // this lane's pixel of the wave's first pair; every iteration moves on by 8 pixels (4 waves x 2)
+        int p = 2 * wave + half;
+        int py = p / TW, px = p - py * TW;
+        for (; p - half < npix; p += 8) {  // (p - half: both halves of a wave leave the loop together)
+            const int pc = p < npix ? p : npix;  // past the tile: the zero pixel
+            const float a = wideT[pc * 32 + l31];
+            const int base = p < npix ? ((py * step) * BW + px * step) * 4 : 0;
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                const float bv = thinF[base + delta[u]] * keep[u];
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[u], 0, 0, 0);
+            }
+            px += 8;
+            while (px >= TW) px -= TW, ++py;
+        }
+    }
+    // fold the four waves through LDS (the wide tile is dead), then this block's slab row
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wideT[((wave * NT + u) * 16 + r) * 64 + lane] = acc[u][r];
+    __syncthreads();
+    const int N = TAPS * Cb;
+    float* out = slab + (long)blockIdx.x * Cs * N;
+    for (int idx = t; idx < NT * 1024; idx += 256) {
+        const int u = idx >> 10, r = (idx >> 6) & 15, ln = idx & 63;
+        const int n = u * 32 + (ln & 31);
+        if (n >= NA) continue;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v += wideT[((w * NT + u) * 16 + r) * 64 + ln];
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+        const int tap = n / TC, j = n - tap * TC, c = c0 + m;
+        const long o = REV ? ((long)j * TAPS + tap) * Cb + c : ((long)c * TAPS + tap) * Cb + j;
+        out[o] = v;
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------
 inline bool thin_in_ok(const Geom& g) { return g.Cr <= 4 && g.Nn >= 8 && g.KH * g.KW * g.Cr * 64 * 4 <= 48 * 1024; }
 
@@ -725,21 +846,32 @@ int launch_thin_wgrad_impl(const float* S, const float* Bg, float* const* dW, in
             const int Hw = thin_small ? g.Hb : g.Hs, Ww = thin_small ? g.Wb : g.Ws;
             const int Ht = thin_small ? g.Hs : g.Hb, Wt = thin_small ? g.Ws : g.Wb;
             const int TW = Ww < 32 ? Ww : 32;
-            int TH = 256 / TW;
+            static const int tile_px = getenv("MOVAE_THIN_TILE_PX") ? atoi(getenv("MOVAE_THIN_TILE_PX")) : 256;
+            int TH = tile_px / TW;
+            if (TH < 1) TH = 1;
             if (TH > Hw) TH = Hw;
             const int taps = g.KH * g.KW, na = taps * 3;
+            static const bool use_mfma = !getenv("MOVAE_THIN_WGRAD_SWEEP");  // (A/B knob: the VALU sweep kernel)
             auto lds_bytes = [&](int th, int tw) {
                 const int bh = thin_small ? th + g.KH - 1 : (th - 1) * g.stride + g.KH;
                 const int bw = thin_small ? tw + g.KW - 1 : (tw - 1) * g.stride + g.KW;
-                const long tile_f = (long)th * tw * 32, fold_f = 8L * 32 * ((na + 1) / 2);
+                long tile_f = (long)th * tw * 32, fold_f = 8L * 32 * ((na + 1) / 2);
+                if (use_mfma) tile_f += 32, fold_f = 4L * ((na + 31) / 32) * 1024;
                 const long wide_f = tile_f > fold_f ? tile_f : fold_f;
                 return (wide_f + (long)bh * bw * 4) * 4;
             };
             while (lds_bytes(TH, TW) > 60 * 1024 && TH > 1) TH = (TH + 1) / 2;
             const int tiles_h = ceil_div(Hw, TH), tiles_w = ceil_div(Ww, TW);
-            const long nblk = (long)g.Nimg * tiles_h * tiles_w;
+            const long ntiles = (long)g.Nimg * tiles_h * tiles_w;
+            // MFMA kernel: persistent blocks (one slab row each), about four per CU and (wide slice, group)
+            static const int persist = getenv("MOVAE_THIN_PERSIST") ? atoi(getenv("MOVAE_THIN_PERSIST")) : 1024;
+            long nblk = ntiles;
+            if (use_mfma) {
+                const long cap = persist / ((long)(wide / 32) * G) > 64 ? persist / ((long)(wide / 32) * G) : 64;
+                if (nblk > cap) nblk = cap;
+            }
             const size_t per1 = (size_t)M * N * sizeof(float);
-            if (lds_bytes(TH, TW) <= 60 * 1024 && nblk <= 0x7fffffffL && per1 * (size_t)nblk * G <= ws_bytes) {
+            if (lds_bytes(TH, TW) <= 60 * 1024 && ntiles <= 0x7fffffffL && per1 * (size_t)nblk * G <= ws_bytes) {
                 float* slab = static_cast<float*>(ws);
                 const dim3 grid((unsigned)nblk, wide / 32, G);
                 const long slab_gs = (long)nblk * M * N;
@@ -759,12 +891,22 @@ int launch_thin_wgrad_impl(const float* S, const float* Bg, float* const* dW, in
 #define MOVAE_SW(K, REVV)                                                                                                      \
     hipLaunchKernelGGL((thin_wgrad_sweep_k<3, K, K, REVV>), grid, dim3(256), shb, st, Wd, Tn, slab, Hw, Ww, wide, Ht, Wt, g.stride, \
                        g.pad, TH, TW, tiles_h, tiles_w, g.Cs, g.Cb, wide_gs, thin_gs, slab_gs, wide_nrm)
-                if (thin_small) {
+#define MOVAE_MF(K, REVV)                                                                                                      \
+    hipLaunchKernelGGL((thin_wgrad_mfma_k<3, K, K, REVV>), grid, dim3(256), shb, st, Wd, Tn, slab, Hw, Ww, wide, Ht, Wt, g.stride, \
+                       g.pad, TH, TW, tiles_h, tiles_w, g.Cs, g.Cb, wide_gs, thin_gs, slab_gs, wide_nrm, (int)ntiles)
+                if (use_mfma) {
+                    if (thin_small) {
+                        if (k33) MOVAE_MF(3, true); else MOVAE_MF(4, true);
+                    } else {
+                        if (k33) MOVAE_MF(3, false); else MOVAE_MF(4, false);
+                    }
+                } else if (thin_small) {
                     if (k33) MOVAE_SW(3, true); else MOVAE_SW(4, true);
                 } else {
                     if (k33) MOVAE_SW(3, false); else MOVAE_SW(4, false);
                 }
 #undef MOVAE_SW
+#undef MOVAE_MF
                 MOVAE_CHECK_LAUNCH("thin_wgrad_sweep");
                 for (int i = 0; i < G; ++i)
                     if (int rc = launch_reduce(slab + i * slab_gs, dW[i], (long)M * N, (int)nblk, N, nullptr, 0, 0.f, accumulate, st))

@@ -40,6 +40,11 @@ C3BIG = [("conv", 128, 16, 16, 256, 16, 16, 256, 3, 1, 1), ("conv", 128, 32, 32,
          ("convT", 128, 16, 16, 256, 32, 32, 128, 4, 2, 1)]
 
 
+# the 3-channel image ends of C5 (BetaTC-VAE 256x256, bs 32) and C3 (thin_* kernels)
+THIN = [("conv", 32, 256, 256, 3, 128, 128, 32, 4, 2, 1), ("conv", 32, 256, 256, 32, 256, 256, 3, 3, 1, 1),
+        ("conv", 128, 64, 64, 3, 32, 32, 128, 4, 2, 1), ("convT", 128, 32, 32, 128, 64, 64, 3, 4, 2, 1)]
+
+
 def time_call(fn, args, reps):
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -78,7 +83,7 @@ def main():
     lib = L.load()
     dev = torch.device("cuda:0")
     ws = L.workspace(dev)
-    shapes = {"c2": C2, "c3": C3, "c3big": C3BIG}[a.shapes]
+    shapes = {"c2": C2, "c3": C3, "c3big": C3BIG, "thin": THIN}[a.shapes]
     tot = 0.0
     for i, (kind, n, hi, wi, ci, ho, wo, co, k, s, p) in enumerate(shapes):
         if a.index is not None and i not in a.index:
