@@ -477,7 +477,11 @@ def main():
                        "timed_blocks": {"n": len(ts), "steps_each": args.steps, "ms_per_step_min": ts[0] / args.steps * 1e3,
                                         "ms_per_step_median": elapsed / args.steps * 1e3, "ms_per_step_max": ts[-1] / args.steps * 1e3},
                        "distinct_batches": len(pool),
-                       "step_gflop": cfg["flops_per_img"] * cfg["batch"] / 1e9},
+                       "step_gflop": cfg["flops_per_img"] * cfg["batch"] / 1e9,
+                       "parity": ("fp32 end to end (the reference's arithmetic; BASELINE's bf16 leg is not built); models / losses / "
+                                  "MGDA / Aligned-MTL pinned by golden vectors of the reference, UPGrad + mtl_backward restate torchjd "
+                                  "(absent: docstring KAT, unit-weights invariant, scipy cross-check); element-wise vs the oracle at "
+                                  "this shape and the 1-epoch ELBO trajectory: tests/test_hip_parity_full.py")},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
