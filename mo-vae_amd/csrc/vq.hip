@@ -10,20 +10,31 @@
 namespace {
 
 constexpr int CH = 128;        // codes staged per chunk
-constexpr int ROWS_PER_BLOCK = 128;
+// rows per block: 64, or 32 when there are few rows (a block per CU at least; measured: 8192 rows 41.6 -> 33.6 us with 32)
+inline int vq_rows_per_block(int rows) { return rows <= 16384 ? 32 : 64; }
 
-template <int D>
+// Block = ROWS_PER_BLOCK (32 | 64) latent rows x all K codes.  Waves (rw, cw): rw = which 32 rows, cw = which share of every
+// staged chunk's four 32-code tiles -- the waves of a row group hold disjoint code sets and merge their arg-min through LDS
+// (lower distance, then lower index: torch.argmin's first-index rule).  64 rows per block put two blocks on a CU even at C3's 32768 rows
+// (one 128-row block per CU left the chunk staging and the gather epilogue -- 75 of 91 us -- with nothing to overlap with);
+// the chunk is staged with 16-byte loads and its squared norms are folded from the values in flight.
+template <int D, int ROWS_PER_BLOCK>
 __global__ __launch_bounds__(256) void vq_nearest_mfma(const float* __restrict__ x, const float* __restrict__ e,
                                                        float* __restrict__ q, int64_t* __restrict__ idx,
                                                        double* __restrict__ sse_part, int* __restrict__ used, int rows,
                                                        int K) {
+    constexpr int NRW = ROWS_PER_BLOCK / 32, NCW = 4 / NRW, TPW = 4 / NCW;  // row groups, code splits, 32-code tiles per wave and chunk
     constexpr int LD = D + 1;
+    constexpr int QR = D / 4;  // 16-byte pieces (threads) per code row while staging: 2 .. 32, a power of two
     __shared__ float Es[CH * LD];
     __shared__ float ee[CH];
     __shared__ double shd[4];
+    __shared__ float mbest[NCW][ROWS_PER_BLOCK];
+    __shared__ int mbesti[NCW][ROWS_PER_BLOCK];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    const int rowbase = blockIdx.x * ROWS_PER_BLOCK + wave * 32;
+    const int rw = wave % NRW, cw = wave / NRW;
+    const int rowbase = blockIdx.x * ROWS_PER_BLOCK + rw * 32;
     const int row = rowbase + l31;
     const bool rv = row < rows;
     float xf[D / 2];
@@ -39,20 +50,23 @@ __global__ __launch_bounds__(256) void vq_nearest_mfma(const float* __restrict__
     int besti = 0;
     for (int c0 = 0; c0 < K; c0 += CH) {
         __syncthreads();
-        for (int i = t; i < CH * D; i += 256) {
-            const int r = i / D, d = i - r * D;
-            Es[r * LD + d] = (c0 + r < K) ? e[(long)(c0 + r) * D + d] : 0.f;
-        }
-        __syncthreads();
-        if (t < CH) {
-            float s = 0.f;
-#pragma unroll 8
-            for (int d = 0; d < D; ++d) s += Es[t * LD + d] * Es[t * LD + d];
-            ee[t] = s;
+        for (int i = t; i < CH * QR; i += 256) {
+            const int r = i / QR, qd = i - r * QR;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c0 + r < K) v = *reinterpret_cast<const f32x4*>(e + (long)(c0 + r) * D + qd * 4);
+            float* dst = Es + r * LD + qd * 4;
+            dst[0] = v[0], dst[1] = v[1], dst[2] = v[2], dst[3] = v[3];
+            float sq = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+#pragma unroll
+            for (int o = 1; o < QR; o <<= 1) sq += __shfl_xor(sq, o, 64);  // the QR lanes of one code row are neighbours
+            if (qd == 0) ee[r] = sq;
         }
         __syncthreads();
         const int ntile = min(CH, K - c0);
-        for (int ct = 0; ct * 32 < ntile; ++ct) {
+#pragma unroll
+        for (int cj = 0; cj < TPW; ++cj) {
+            const int ct = cw * TPW + cj;
+            if (ct * 32 >= ntile) break;  // (wave-uniform)
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -73,7 +87,7 @@ __global__ __launch_bounds__(256) void vq_nearest_mfma(const float* __restrict__
             }
         }
     }
-    {   // merge the two halves of the wave (same latent row, disjoint code sets)
+    {   // merge the two halves of the wave (same latent row, disjoint code sets) ...
         const float ob = __shfl_xor(best, 32, 64);
         const int oi = __shfl_xor(besti, 32, 64);
         if (ob < best || (ob == best && oi < besti)) {
@@ -81,22 +95,38 @@ __global__ __launch_bounds__(256) void vq_nearest_mfma(const float* __restrict__
             besti = oi;
         }
     }
-    if (rv && half == 0) {
-        idx[row] = besti;
-        used[besti] = 1;
-    }
-    // gather q = E[idx] and accumulate sum (q - x)^2
-    double sse = 0.0;
-    for (int r = 0; r < 32; ++r) {
-        const int rr = rowbase + r;
-        if (rr >= rows) break;
-        const int bi = __shfl(besti, r, 64);
-        for (int d = lane; d < D; d += 64) {
-            const float qv = e[(long)bi * D + d];
-            const float dv = qv - x[(long)rr * D + d];
-            q[(long)rr * D + d] = qv;
-            sse += (double)(dv * dv);
+    // ... and the NCW waves of the row group
+    if (half == 0) mbest[cw][rw * 32 + l31] = best, mbesti[cw][rw * 32 + l31] = besti;
+    __syncthreads();
+    if (cw == 0 && half == 0) {
+#pragma unroll
+        for (int o = 1; o < NCW; ++o) {
+            const float ob = mbest[o][rw * 32 + l31];
+            const int oi = mbesti[o][rw * 32 + l31];
+            if (ob < best || (ob == best && oi < besti)) best = ob, besti = oi;
         }
+        mbesti[0][rw * 32 + l31] = besti;
+        if (rv) {
+            idx[row] = besti;
+            used[besti] = 1;
+        }
+    }
+    __syncthreads();
+    // gather q = E[idx] and accumulate sum (q - x)^2: every wave takes a quarter of the block's rows, four rows in flight
+    double sse = 0.0;
+    constexpr int RPW = ROWS_PER_BLOCK / 4;
+    const int r0 = blockIdx.x * ROWS_PER_BLOCK + wave * RPW;
+#pragma unroll 4
+    for (int r = 0; r < RPW; ++r) {
+        const int rr = r0 + r;
+        const int bi = mbesti[0][wave * RPW + r];
+        if (rr < rows)
+            for (int d = lane; d < D; d += 64) {
+                const float qv = e[(long)bi * D + d];
+                const float dv = qv - x[(long)rr * D + d];
+                q[(long)rr * D + d] = qv;
+                sse += (double)(dv * dv);
+            }
     }
     sse = block_sum_256(sse, shd);
     if (t == 0) sse_part[blockIdx.x] = sse;
@@ -287,7 +317,10 @@ __global__ __launch_bounds__(256) void vq_embed_final_k(const float* __restrict_
 template <int D>
 void launch_mfma(const float* x, const float* e, float* q, int64_t* idx, double* part, int* used, int rows, int K, int nblk,
                  hipStream_t st) {
-    hipLaunchKernelGGL(vq_nearest_mfma<D>, dim3(nblk), dim3(256), 0, st, x, e, q, idx, part, used, rows, K);
+    if (vq_rows_per_block(rows) == 32)
+        hipLaunchKernelGGL((vq_nearest_mfma<D, 32>), dim3(nblk), dim3(256), 0, st, x, e, q, idx, part, used, rows, K);
+    else
+        hipLaunchKernelGGL((vq_nearest_mfma<D, 64>), dim3(nblk), dim3(256), 0, st, x, e, q, idx, part, used, rows, K);
 }
 
 // de[k] = f * sum_{rows r with idx[r] == k} (q[r] - x[r])   (x may be null: plain sum of q's rows; ge null: f = 1)
@@ -333,7 +366,7 @@ int movae_vq_nearest_fwd(const float* x, const float* e, float* q, int64_t* idx,
     MOVAE_CHECK_ARG(rows > 0 && k > 0 && d > 0, "movae_vq_nearest_fwd: bad shape rows=%d k=%d d=%d", rows, k, d);
     hipStream_t st = (hipStream_t)stream;
     const bool mfma = d == 8 || d == 16 || d == 32 || d == 64 || d == 128;
-    const int nblk = mfma ? ceil_div(rows, ROWS_PER_BLOCK) : ceil_div(rows, 256);
+    const int nblk = mfma ? ceil_div(rows, vq_rows_per_block(rows)) : ceil_div(rows, 256);
     const size_t need = (size_t)nblk * sizeof(double) + (size_t)k * sizeof(int);
     MOVAE_CHECK_ARG(ws && ws_bytes >= need, "movae_vq_nearest_fwd: workspace too small (%zu < %zu)", ws_bytes, need);
     double* part = static_cast<double*>(ws);
