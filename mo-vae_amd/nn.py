@@ -181,6 +181,12 @@ class Stack(tnn.Sequential):
                     x = m(x, None, False, ops.ConvFusion(act_in=link) if link is not None else None)
                     link = None
                     i += 1
+            elif (isinstance(m, _Act) and m.kind in ("lrelu", "relu") and i + 1 < n and isinstance(mods[i + 1], (Conv2d, ConvTranspose2d))
+                  and not isinstance(x, ops.LazyBN)):
+                # a stand-alone activation whose output only the next conv reads: that conv's input gradient applies its derivative
+                link = ops.ActLink()
+                x = ops.activation(x, m.kind, LRELU_SLOPE, link)
+                i += 1
             else:
                 x = m(ops.materialize(x))
                 link = None

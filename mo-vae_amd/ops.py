@@ -880,42 +880,58 @@ def batch_norm_act(y, gamma, beta, running_mean, running_var, training, eps=1e-5
 
 # ---------------------------------------------------------------------------------------------
 class Activation(Function):
+    """A stand-alone activation.  act_out (ActLink or None): the output has exactly one reader, a conv whose input-gradient pass
+    may apply this activation's derivative itself (nn.Stack arranges that); the backward then passes the gradient through."""
+
     @staticmethod
-    def forward(ctx, x, act, slope):
+    def forward(ctx, x, act, slope, act_out=None):
         ctx.set_materialize_grads(False)  # an absent cotangent arrives as None: no zero-fill, no kernels on zeros
         L.require_gpu(x)
         x = _c(x)
         y = torch.empty_like(x)
         _call("movae_act_fwd", x.data_ptr(), y.data_ptr(), x.numel(), L.ACT[act], float(slope), _st(x))
         ctx.act, ctx.slope = act, slope
+        ctx.act_out = act_out
+        if act_out is not None:
+            act_out.y, act_out.act, act_out.slope, act_out.applied = y.detach(), act, slope, None
         ctx.save_for_backward(y)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         if dy is None:
-            return (None,) * 3
+            return (None,) * 4
         (y,) = ctx.saved_tensors
         dy = _c(dy)
+        if _act_take(ctx, dy):
+            return dy, None, None, None
         dx = torch.empty_like(dy)
         _call("movae_act_bwd", dy.data_ptr(), y.data_ptr(), dx.data_ptr(), dy.numel(), L.ACT[ctx.act], float(ctx.slope), _st(dy))
-        return dx, None, None
+        return dx, None, None, None
 
     @staticmethod
     def backward_batched(ctx, G, dy):
         (y,) = ctx.saved_tensors
         dy = _stacked(dy, G)
+        if _act_take(ctx, dy):
+            return dy, None, None, None
         dx = torch.empty_like(dy)
-        for g in range(G):
-            _call("movae_act_bwd", dy[g].data_ptr(), y.data_ptr(), dx[g].data_ptr(), y.numel(), L.ACT[ctx.act], float(ctx.slope),
-                  _st(dy))
-        return dx, None, None
+        c = y.shape[-1]
+        if c % 4 == 0 and dy.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0:  # all groups in one launch
+            wsp, wsb = _ws(dy)
+            _call("movae_act_bwd_bias_grouped", G, dy.data_ptr(), y.data_ptr(), dx.data_ptr(), None, y.numel() // c, c, L.ACT[ctx.act],
+                  float(ctx.slope), 0, wsp, wsb, _st(dy))
+        else:
+            for g in range(G):
+                _call("movae_act_bwd", dy[g].data_ptr(), y.data_ptr(), dx[g].data_ptr(), y.numel(), L.ACT[ctx.act], float(ctx.slope),
+                      _st(dy))
+        return dx, None, None, None
 
 
-def activation(x, act, slope=0.01):
+def activation(x, act, slope=0.01, act_out=None):
     if not L.ACT[act]:
         return x
-    return Activation.apply(x, act, slope)
+    return Activation.apply(x, act, slope, act_out)
 
 
 class Add(Function):

@@ -100,3 +100,42 @@ def test_two_readers_fail_loudly(gpu_device):
     y2 = c2(y1, None, False, ops.ConvFusion(act_in=link))
     with pytest.raises(RuntimeError, match="another reader"):
         (y2.sum() + y1.sum()).backward()
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_vqvae2_resblock_standalone_relu(fused, gpu_device, monkeypatch):
+    """models/vq_vae2.py ResBlock: ReLU -> Conv3x3 -> ReLU -> Conv1x1, plus the input (which therefore has two readers -- the link
+    concerns the stand-alone ReLU's OUTPUT, read by the 3x3 conv only).  Two blocks in a row, against the PyTorch chain."""
+    import movae_amd  # noqa: F401
+    from movae_amd import _lib as L, nn as mnn, ops
+    from movae_amd.models.vq_vae2 import ResBlock
+
+    monkeypatch.setattr(ops, "FUSE_ACT", fused)
+    calls = []
+    monkeypatch.setattr(L, "TRACE", lambda nm, a: calls.append(nm))
+    torch.manual_seed(5)
+    blocks = mnn.Stack(ResBlock(32, 16), ResBlock(32, 16), mnn.ReLU()).to(gpu_device)
+    x = torch.randn(4, 32, 8, 8)
+    xr = x.clone().requires_grad_(True)
+    h, ws = xr, []
+    for rb in list(blocks)[:2]:
+        c3, c1 = rb.conv[1], rb.conv[3]
+        w = [t.detach().cpu().contiguous().clone().requires_grad_(True) for t in (c3.weight, c3.bias, c1.weight, c1.bias)]
+        ws.append(w)
+        h = h + F.conv2d(F.relu(F.conv2d(F.relu(h), w[0], w[1], padding=1)), w[2], w[3])
+    h = F.relu(h)
+    cot = torch.randn(h.shape, generator=torch.Generator().manual_seed(2))
+    (h * cot).sum().backward()
+    xh = x.to(gpu_device).requires_grad_(True)
+    out = blocks(ops.to_nhwc(xh)).permute(0, 3, 1, 2)
+    _close(out, h, "output", rtol=5e-4, atol=5e-5)
+    calls.clear()
+    (out * cot.to(gpu_device)).sum().backward()
+    _close(xh.grad, xr.grad, "dx")
+    for i, (rb, w) in enumerate(zip(list(blocks)[:2], ws)):
+        for got, want, nm in ((rb.conv[1].weight.grad, w[0].grad, "dW3"), (rb.conv[1].bias.grad, w[1].grad, "db3"),
+                              (rb.conv[3].weight.grad, w[2].grad, "dW1"), (rb.conv[3].bias.grad, w[3].grad, "db1")):
+            _close(got, want, f"block {i} {nm}")
+    n_bwd = sum(1 for nm in calls if nm.startswith("movae_act_bwd"))
+    # unfused: 2 blocks x (stand-alone ReLU + epilogue ReLU) + the trailing ReLU; fused: only the trailing one (no conv reads it)
+    assert n_bwd == (1 if fused else 5), calls
