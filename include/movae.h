@@ -324,7 +324,11 @@ typedef struct movae_fuse {
     const float* ep_act_y;
     int ep_act;            /* MOVAE_ACT_* of that layer */
     float ep_slope;
-    int ep_act_done;       /* OUT */
+    int ep_act_done;       /* OUT: everything asked of the epilogue (ep_act_y and / or ep_res) was applied */
+    /* ... and / or the layer is the first of a residual block's branch (out = branch(x) + x, models/vq_vae.py:127-145,
+     * vq_vae2.py:13-28): ep_res [groups][n][hi][wi][ci] -- the gradient w.r.t. the block's output, i.e. the identity branch's
+     * share -- is added to dx, which then is the block's complete input gradient. */
+    const float* ep_res;
 } movae_fuse_t;
 int movae_conv2d_fwd_f(const float* x, const float* w, const float* bias, float* y,
                        int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad,

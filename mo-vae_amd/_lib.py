@@ -27,7 +27,8 @@ class MovaeFuse(C.Structure):
                 ("stats_cap", C.c_size_t), ("stats_parts", C.c_int),
                 ("bn_y", C.c_void_p), ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p), ("bn_slope", C.c_float), ("bn_part", C.c_void_p),
                 ("bn_cap", C.c_size_t), ("bn_ppg", C.c_int),
-                ("ep_act_y", C.c_void_p), ("ep_act", C.c_int), ("ep_slope", C.c_float), ("ep_act_done", C.c_int)]
+                ("ep_act_y", C.c_void_p), ("ep_act", C.c_int), ("ep_slope", C.c_float), ("ep_act_done", C.c_int),
+                ("ep_res", C.c_void_p)]
 
 
 _conv_fwd = [_p, _p, _p, _p] + [_i] * 11 + [_i, _f, _p, _z, _p]

@@ -41,12 +41,21 @@ struct Epilogue {
 // is y (same layout as the result; shared by the cotangent groups, per_group floats each): multiply by act'(.) taken from that
 // output, so the layer before starts its backward from the pre-activation gradient and runs no activation-backward pass.
 struct ActMul {
-    const float* y;  // null: off
+    const float* y;  // null: no derivative factor
     int act;
     float slope;
     long per_group;  // floats of y
     int gx_per_group;  // BWD-form kernel: row blocks per group and class (0: one group)
+    // ... and / or `res` (layout and size of the result, cotangent groups included) is ADDED to it: the identity branch of a
+    // residual block, so the block's input gradient leaves this kernel complete (no accumulation launch by the autograd engine)
+    const float* res;
 };
+__device__ __forceinline__ bool actmul_on(const ActMul& am) { return am.y != nullptr || am.res != nullptr; }
+__device__ __forceinline__ float actmul_apply(const ActMul& am, float v, long i) {  // i: index into the result
+    if (am.y) v *= act_grad_from_out(am.y[i % am.per_group], am.act, am.slope);
+    if (am.res) v += am.res[i];
+    return v;
+}
 
 // Division by a launch-invariant divisor inside the k loops (tap / pixel decoding of the gathers): n / d for 0 <= n < 2^31 as
 // one v_mul_hi + one shift instead of the ~35-instruction software division (the 128x128 kernels issued 4-8 VALU instructions
@@ -137,7 +146,7 @@ struct FuseCtx {
     int bn_groups = 1;
     int bn_ppg = 0;                   // out: partial pairs per group and column (0 = none)
     // activation derivative of the layer before, applied by the input-gradient pass's epilogue / reduce (ActMul)
-    ActMul am{nullptr, 0, 0.f, 0, 0};
+    ActMul am{nullptr, 0, 0.f, 0, 0, nullptr};
     int am_groups = 1;
     bool am_done = false;             // out
 };
@@ -614,7 +623,7 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ s
     if (threadIdx.x < 16 && i < total) {
         v = (sh[0][il] + sh[1][il]) + (sh[2][il] + sh[3][il]);
         if (bias) v += bias[i % N];
-        v = am.y ? v * act_grad_from_out(am.y[i % am.per_group], am.act, am.slope) : apply_act(v, act, slope);
+        v = actmul_on(am) ? actmul_apply(am, v, i) : apply_act(v, act, slope);
         float* o = i < n1 ? out + i : out2 + (i - n1);
         *o = accumulate ? *o + v : v;
     }
@@ -663,7 +672,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_wide(const float* __restric
         for (int j = 0; j < 4; ++j) {
             float r = v[j];
             if (bias) r += bias[(i + j) % N];
-            o[j] += am.y ? r * act_grad_from_out(am.y[(i + j) % am.per_group], am.act, am.slope) : apply_act(r, act, slope);
+            o[j] += actmul_on(am) ? actmul_apply(am, r, i + j) : apply_act(r, act, slope);
         }
         *reinterpret_cast<f32x4*>(dst) = o;
     }
@@ -678,7 +687,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_flat(const float* __restric
         float v = 0.f;
         for (int z = 0; z < S; ++z) v += slab[(long)z * total + i];
         if (bias) v += bias[i % N];
-        v = am.y ? v * act_grad_from_out(am.y[i % am.per_group], am.act, am.slope) : apply_act(v, act, slope);
+        v = actmul_on(am) ? actmul_apply(am, v, i) : apply_act(v, act, slope);
         float* o = i < n1 ? out + i : out2 + (i - n1);
         *o = accumulate ? *o + v : v;
     }
@@ -700,10 +709,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_cls(const float* __restrict
         const int S = scls.s[(ho % stride) * stride + (wo % stride)];
         f32x4 v = *reinterpret_cast<const f32x4*>(slab + i);
         for (int z = 1; z < S; ++z) v += *reinterpret_cast<const f32x4*>(slab + (long)z * total + i);
-        if (am.y) {
-            const f32x4 y4 = *reinterpret_cast<const f32x4*>(am.y + i % am.per_group);
+        if (actmul_on(am)) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] *= act_grad_from_out(y4[j], am.act, am.slope);
+            for (int j = 0; j < 4; ++j) v[j] = actmul_apply(am, v[j], i + j);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j] + (bias ? bias[n + j] : 0.f), act, slope);
@@ -787,7 +795,7 @@ int g_force_split = 0;           // movae_bench_force_split(): > 0 pins the spli
 bool g_bench_main_only = false;  // movae_bench_main_kernel_only(): time the MFMA kernel without its epilogue launches
 
 inline int launch_reduce(const float* slab, float* out, long n1, int S, int N, const float* bias, int act, float slope,
-                         int accumulate, hipStream_t st, float* out2 = nullptr, long n2 = 0, ActMul am = ActMul{nullptr, 0, 0.f, 0, 0}) {
+                         int accumulate, hipStream_t st, float* out2 = nullptr, long n2 = 0, ActMul am = ActMul{nullptr, 0, 0.f, 0, 0, nullptr}) {
     if (g_bench_main_only) return MOVAE_OK;
     if (!out2) n2 = 0;
     const long total = n1 + n2;  // floats per slab: n1 outputs for `out`, then n2 for `out2`
@@ -1207,8 +1215,11 @@ inline void fuse_bn_install(movae_fuse_t* f, int groups) {
     if (!f) return;
     f->bn_ppg = 0;
     f->ep_act_done = 0;
-    if (f->ep_act_y && f->ep_act != MOVAE_ACT_NONE && groups >= 1 && (reinterpret_cast<uintptr_t>(f->ep_act_y) & 15) == 0)
-        g_fuse.am = ActMul{f->ep_act_y, f->ep_act, f->ep_slope, 0, 0}, g_fuse.am_groups = groups, g_fuse.am_done = false;
+    const bool want_act = f->ep_act_y && f->ep_act != MOVAE_ACT_NONE;
+    if ((want_act || f->ep_res) && groups >= 1 &&
+        ((reinterpret_cast<uintptr_t>(f->ep_act_y) | reinterpret_cast<uintptr_t>(f->ep_res)) & 15) == 0)
+        g_fuse.am = ActMul{want_act ? f->ep_act_y : nullptr, f->ep_act, f->ep_slope, 0, 0, f->ep_res}, g_fuse.am_groups = groups,
+        g_fuse.am_done = false;
     if (f->bn_y && f->bn_scale && f->bn_shift && f->bn_part && f->bn_cap > 0 && groups >= 1) {
         g_fuse.bn_y = f->bn_y, g_fuse.bn_scale = f->bn_scale, g_fuse.bn_shift = f->bn_shift, g_fuse.bn_slope = f->bn_slope;
         g_fuse.bn_part = f->bn_part, g_fuse.bn_cap = f->bn_cap, g_fuse.bn_groups = groups;
@@ -1217,7 +1228,7 @@ inline void fuse_bn_install(movae_fuse_t* f, int groups) {
 inline void fuse_bn_collect(movae_fuse_t* f) {
     if (f) f->bn_ppg = g_fuse.bn_ppg, f->ep_act_done = g_fuse.am_done ? 1 : 0;
     g_fuse.bn_y = nullptr, g_fuse.bn_part = nullptr, g_fuse.bn_ppg = 0, g_fuse.bn_groups = 1;
-    g_fuse.am.y = nullptr, g_fuse.am_groups = 1, g_fuse.am_done = false;
+    g_fuse.am.y = nullptr, g_fuse.am.res = nullptr, g_fuse.am_groups = 1, g_fuse.am_done = false;
 }
 #define MOVAE_CHECK_FUSE(f, c)                                                                                                   \
     MOVAE_CHECK_ARG(!(f) || !(f)->in_scale ||                                                                                    \

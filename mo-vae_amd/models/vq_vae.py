@@ -54,7 +54,9 @@ class ResidualLayer(torch.nn.Module):
                                   mnn.Conv2d(out_channels, out_channels, 1, bias=False))
 
     def forward(self, x):
-        return ops.add(x, self.resblock(x))
+        # the identity branch's cotangent is added by the input-gradient kernel of the branch's first conv (ops.ResCarrier)
+        carrier = ops.ResCarrier() if (torch.is_grad_enabled() and isinstance(x, torch.Tensor)) else None
+        return ops.residual_add(self.resblock(x, None, carrier), x, carrier)
 
 
 def _conv_lrelu(cin, cout, k, stride, padding):

@@ -18,7 +18,9 @@ class ResBlock(torch.nn.Module):
                               mnn.Conv2d(channel, in_channel, 1))
 
     def forward(self, x):
-        return ops.add(self.conv(x), x)
+        # the identity branch's cotangent is added by the input-gradient kernel of the branch's 3x3 conv (ops.ResCarrier)
+        carrier = ops.ResCarrier() if (torch.is_grad_enabled() and isinstance(x, torch.Tensor)) else None
+        return ops.residual_add(self.conv(x, None, carrier), x, carrier)
 
 
 class Encoder(torch.nn.Module):

@@ -138,7 +138,20 @@ class Stack(tnn.Sequential):
     """nn.Sequential (same child names, hence same state_dict keys) whose forward fuses
     conv -> [batchnorm] -> activation runs into the conv / batch-norm kernels' epilogues."""
 
-    def forward(self, x, act_in=None):
+    def accepts_res_in(self):
+        """Can this Stack's first op take the identity cotangent of a residual block (ops.ResCarrier)?  A conv can, and so can a
+        stand-alone ReLU / LeakyReLU that the next conv is linked to."""
+        mods = list(self)
+        if not mods:
+            return False
+        if isinstance(mods[0], Stack):
+            return mods[0].accepts_res_in()
+        if isinstance(mods[0], (Conv2d, ConvTranspose2d)):
+            return True
+        return (isinstance(mods[0], _Act) and mods[0].kind in ("lrelu", "relu") and len(mods) > 1 and
+                isinstance(mods[1], (Conv2d, ConvTranspose2d)))
+
+    def forward(self, x, act_in=None, res_in=None):
         """x: an NHWC tensor or an ops.LazyBN (the unmaterialised output of a fused BatchNorm); may return either -- a LazyBN
         leaves a Stack only when its last module is a fused BatchNorm (+ activation), and is handed on to Stacks and convs
         as it is; every other module receives the materialised tensor.
@@ -150,10 +163,13 @@ class Stack(tnn.Sequential):
         i, n = 0, len(mods)
         link = act_in  # the link whose activation output `x` currently is (None: x is something else)
         self._out_link = None
+        if res_in is not None and (isinstance(x, ops.LazyBN) or not self.accepts_res_in()):
+            raise ValueError("res_in: the first op of this Stack cannot take a residual block's identity cotangent")
         while i < n:
             m = mods[i]
+            rin = res_in if i == 0 else None  # (only the op applied to the block's input)
             if isinstance(m, Stack):
-                x = m(x, link)
+                x = m(x, link, rin)
                 link = m._out_link
                 m._out_link = None
                 i += 1
@@ -163,29 +179,30 @@ class Stack(tnn.Sequential):
                     act = mods[i + 2] if i + 2 < n and isinstance(mods[i + 2], _Act) else None
                     kind = act.kind if act is not None else None
                     if FUSE_BN and nxt.training and kind in (None, "lrelu", "relu") and m.out_channels % 4 == 0:
-                        fusion = ops.ConvFusion(want_stats=True, act_in=link)
+                        fusion = ops.ConvFusion(want_stats=True, act_in=link, res_in=rin)
                         if isinstance(x, ops.LazyBN):
                             fusion.in_scale, fusion.in_shift, fusion.in_slope, fusion.link = x.scale, x.shift, x.slope, x.link
                             x = x.y
                         x = nxt.forward_lazy(m(x, None, True, fusion), kind, fusion)
                     else:
-                        x = nxt(m(x, None, nxt.training, ops.ConvFusion(act_in=link) if link is not None else None), kind)
+                        x = nxt(m(x, None, nxt.training, ops.ConvFusion(act_in=link, res_in=rin) if (link is not None or rin is not None) else None), kind)
                     link = None
                     i += 3 if act is not None else 2
                 elif isinstance(nxt, _Act):
                     out = ops.ActLink() if (nxt.kind in ("lrelu", "relu") and not isinstance(x, ops.LazyBN)) else None
-                    x = m(x, nxt.kind, False, ops.ConvFusion(act_in=link, act_out=out) if (link is not None or out is not None) else None)
+                    x = m(x, nxt.kind, False, ops.ConvFusion(act_in=link, act_out=out, res_in=rin)
+                          if (link is not None or out is not None or rin is not None) else None)
                     link = out
                     i += 2
                 else:
-                    x = m(x, None, False, ops.ConvFusion(act_in=link) if link is not None else None)
+                    x = m(x, None, False, ops.ConvFusion(act_in=link, res_in=rin) if (link is not None or rin is not None) else None)
                     link = None
                     i += 1
             elif (isinstance(m, _Act) and m.kind in ("lrelu", "relu") and i + 1 < n and isinstance(mods[i + 1], (Conv2d, ConvTranspose2d))
                   and not isinstance(x, ops.LazyBN)):
                 # a stand-alone activation whose output only the next conv reads: that conv's input gradient applies its derivative
                 link = ops.ActLink()
-                x = ops.activation(x, m.kind, LRELU_SLOPE, link)
+                x = ops.activation(x, m.kind, LRELU_SLOPE, link, rin)
                 i += 1
             else:
                 x = m(ops.materialize(x))

@@ -269,10 +269,33 @@ class ActLink:
     hands it to the next module only, so the output has no other reader): the consumer's input-gradient pass multiplies its
     result by act'(y) in the epilogue / split-K reduce (movae_fuse_t::ep_act_*) and records the tensor it produced in `applied`;
     the producer's backward, handed that very tensor, starts from the pre-activation gradient -- no activation-backward pass."""
-    __slots__ = ("y", "act", "slope", "applied")
+    __slots__ = ("y", "act", "slope", "applied", "res_in", "res_done")
 
     def __init__(self):
         self.y, self.act, self.slope, self.applied = None, None, 0.0, None
+        #: ResCarrier of the residual block whose branch starts with this (stand-alone) activation: the consumer's epilogue adds
+        #: the identity cotangent too (res_done: it did, for the tensor in `applied`)
+        self.res_in, self.res_done = None, False
+
+
+class ResCarrier:
+    """out = branch(x) + x (ops.residual_add): in the backward, the gradient w.r.t. `out` reaches x twice -- through the branch and
+    straight.  Instead of letting the autograd engine add the two, residual_add's backward leaves its cotangent HERE and returns
+    nothing for x; the FIRST op of the branch (the one applied to x: a conv, or a stand-alone activation linked to a conv) adds it
+    to the input gradient it produces -- in the input-gradient kernel's epilogue where that kernel can (movae_fuse_t::ep_res),
+    with one explicit add otherwise.  The first op is told at forward time (nn.Stack: res_in)."""
+    __slots__ = ("res", "armed")
+
+    def __init__(self):
+        self.res, self.armed = None, False
+
+
+def _res_take(carrier):
+    """The identity branch's cotangent waiting in `carrier` (and disarm it), or None."""
+    if carrier is None or carrier.res is None:
+        return None
+    r, carrier.res = carrier.res, None
+    return r
 
 
 #: MOVAE_FUSE_ACT=0: every conv runs its own activation-backward pass (A/B knob)
@@ -284,13 +307,15 @@ class ConvFusion:
     in_*: the input is the RAW output y of a producer conv whose BatchNorm + activation this conv applies while loading,
     x = leaky_relu(in_scale[c] * y + in_shift[c], in_slope).  want_stats: the epilogue (or split-K reduce) also emits the
     per-channel partial sums of this conv's own output for the BatchNorm that follows it: `stats` / `parts` on return."""
-    __slots__ = ("in_scale", "in_shift", "in_slope", "want_stats", "stats", "parts", "link", "act_in", "act_out")
+    __slots__ = ("in_scale", "in_shift", "in_slope", "want_stats", "stats", "parts", "link", "act_in", "act_out", "res_in")
 
-    def __init__(self, in_scale=None, in_shift=None, in_slope=1.0, want_stats=False, link=None, act_in=None, act_out=None):
+    def __init__(self, in_scale=None, in_shift=None, in_slope=1.0, want_stats=False, link=None, act_in=None, act_out=None, res_in=None):
         self.in_scale, self.in_shift, self.in_slope, self.want_stats = in_scale, in_shift, float(in_slope), want_stats
         self.stats, self.parts = None, 0
         #: ActLink of the producer whose activation output is this conv's input / ActLink this conv fills for its consumer
         self.act_in, self.act_out = act_in, act_out
+        #: ResCarrier of the residual block whose branch starts with THIS conv (its input is the block's input)
+        self.res_in = res_in
         #: dict shared with the BatchNormLazy node whose output this conv consumes: the conv's backward leaves that
         #: BatchNorm's backward sums here (emitted by the input-gradient epilogue), the BatchNorm's backward picks them up
         self.link = link
@@ -308,7 +333,11 @@ def _fuse_struct(in_norm, stats=None, bn=None, ep=None):
     ep = ActLink: its epilogue multiplies by the producer's activation derivative."""
     f = L.MovaeFuse()
     if ep is not None:
-        f.ep_act_y, f.ep_act, f.ep_slope = ep.y.data_ptr(), L.ACT[ep.act], float(ep.slope)
+        link, res = ep[0], ep[1]
+        if link is not None:
+            f.ep_act_y, f.ep_act, f.ep_slope = link.y.data_ptr(), L.ACT[link.act], float(link.slope)
+        if res is not None:
+            f.ep_res = res.data_ptr()
     if in_norm is not None:
         f.in_scale, f.in_shift, f.in_slope = in_norm[0].data_ptr(), in_norm[1].data_ptr(), float(in_norm[2])
     if stats is not None:
@@ -335,18 +364,42 @@ def _bn_request(ctx, x, in_norm, G):
     return (x, in_norm[0], in_norm[1], in_norm[2], part)
 
 
-def _act_request(ctx, x, bn):
-    """The ActLink whose activation derivative this conv's input-gradient pass should apply, or None."""
-    link = getattr(ctx, "act_in", None)
-    if (not FUSE_ACT or link is None or link.y is None or bn is not None or not ctx.needs_input_grad[0] or
-            link.y.shape != x.shape or link.y.data_ptr() != x.data_ptr()):
+def _act_request(ctx, x, bn, dx_shape=None):
+    """What this conv's input-gradient epilogue is asked to do besides the plain dx: (link, res, carrier) or None.
+    link: the ActLink whose activation derivative to apply; res: the identity cotangent of the residual block whose branch starts
+    at this conv (carrier = ctx.res_in) or at the linked stand-alone activation (carrier = link.res_in)."""
+    if bn is not None or not ctx.needs_input_grad[0]:
         return None
-    return link
+    link = getattr(ctx, "act_in", None)
+    if (not FUSE_ACT or link is None or link.y is None or link.y.shape != x.shape or link.y.data_ptr() != x.data_ptr()):
+        link = None
+    carrier = link.res_in if link is not None else getattr(ctx, "res_in", None)
+    res = carrier.res if (carrier is not None and carrier.res is not None) else None
+    if res is not None and (not FUSE_ACT or res.data_ptr() % 16 != 0 or (dx_shape is not None and tuple(res.shape) != tuple(dx_shape))):
+        res = None  # (left in the carrier: added explicitly by whoever owns it)
+    if link is None and res is None:
+        return None
+    return (link, res, carrier)
 
 
-def _act_publish(link, f, dx):
-    if link is not None and f is not None and int(f.ep_act_done):
-        link.applied = dx.data_ptr()
+def _act_publish(req, f, dx):
+    if req is None or f is None or not int(f.ep_act_done):
+        return
+    link, res, carrier = req
+    if res is not None:
+        carrier.res = None  # consumed by the epilogue
+    if link is not None:
+        link.applied, link.res_done = dx.data_ptr(), res is not None
+
+
+def _res_finish(ctx, dx):
+    """A conv that is the first op of a residual branch: whatever is still waiting in its carrier is added to dx explicitly."""
+    r = _res_take(getattr(ctx, "res_in", None))
+    if r is None or dx is None:
+        return dx
+    r = _c(r).view_as(dx)
+    _call("movae_add", dx.data_ptr(), r.data_ptr(), dx.data_ptr(), dx.numel(), _st(dx))
+    return dx
 
 
 def _act_take(ctx, dy):
@@ -432,6 +485,7 @@ class Conv(Function):
         ctx.in_slope = in_norm[2] if in_norm is not None else None
         ctx.bn_link = fusion.link if (fusion is not None and in_norm is not None) else None
         ctx.act_in = fusion.act_in if (fusion is not None and in_norm is None) else None
+        ctx.res_in = fusion.res_in if fusion is not None else None
         ctx.act_out = None
         if fusion is not None and fusion.act_out is not None and L.ACT[act]:
             ctx.act_out = fusion.act_out
@@ -507,7 +561,7 @@ class Conv(Function):
             side.wait_stream(main)
         pair = need_w and ctx.needs_input_grad[0] and not fork  # both gradients, one stream: one call, one main launch
         bn = _bn_request(ctx, x, in_norm, 1)
-        ep = _act_request(ctx, x, bn)
+        ep = _act_request(ctx, x, bn, x.shape)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             wm = weight_mem(w)
@@ -556,6 +610,7 @@ class Conv(Function):
             defer.used = True
         elif fork:
             main.wait_stream(side)
+        dx = _res_finish(ctx, dx)
         return dx, dw, db, None, None, None, None, None, None, None, None
 
     @staticmethod
@@ -592,7 +647,7 @@ class Conv(Function):
         defer = L.DEFER if need_w else None
         pair = need_w and ctx.needs_input_grad[0] and defer is None
         bn = _bn_request(ctx, x, in_norm, G)
-        ep = _act_request(ctx, x, bn)
+        ep = _act_request(ctx, x, bn, (G,) + tuple(x.shape))
         if ctx.needs_input_grad[0]:
             dx = torch.empty((G,) + tuple(x.shape), dtype=x.dtype, device=x.device)
             wm = weight_mem(w)
@@ -634,6 +689,7 @@ class Conv(Function):
             if defer is not None:
                 defer.keep.append((dy, x, dwm, db))
                 defer.used = True
+        dx = _res_finish(ctx, dx)
         return dx, dw, db, None, None, None, None, None, None, None, None
 
 
@@ -884,37 +940,47 @@ class Activation(Function):
     may apply this activation's derivative itself (nn.Stack arranges that); the backward then passes the gradient through."""
 
     @staticmethod
-    def forward(ctx, x, act, slope, act_out=None):
+    def forward(ctx, x, act, slope, act_out=None, res_in=None):
         ctx.set_materialize_grads(False)  # an absent cotangent arrives as None: no zero-fill, no kernels on zeros
         L.require_gpu(x)
         x = _c(x)
         y = torch.empty_like(x)
         _call("movae_act_fwd", x.data_ptr(), y.data_ptr(), x.numel(), L.ACT[act], float(slope), _st(x))
         ctx.act, ctx.slope = act, slope
-        ctx.act_out = act_out
+        ctx.act_out, ctx.res_in = act_out, res_in  # res_in: this activation is the first op of a residual branch (ResCarrier)
         if act_out is not None:
             act_out.y, act_out.act, act_out.slope, act_out.applied = y.detach(), act, slope, None
+            act_out.res_in, act_out.res_done = res_in, False
         ctx.save_for_backward(y)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         if dy is None:
-            return (None,) * 4
+            return (None,) * 5
         (y,) = ctx.saved_tensors
         dy = _c(dy)
         if _act_take(ctx, dy):
-            return dy, None, None, None
+            return Activation._add_res(ctx, dy, ctx.act_out.res_done), None, None, None, None
         dx = torch.empty_like(dy)
         _call("movae_act_bwd", dy.data_ptr(), y.data_ptr(), dx.data_ptr(), dy.numel(), L.ACT[ctx.act], float(ctx.slope), _st(dy))
-        return dx, None, None, None
+        return Activation._add_res(ctx, dx, False), None, None, None, None
+
+    @staticmethod
+    def _add_res(ctx, dx, already):
+        """dx (+)= the identity cotangent of the residual block this activation opens, unless the consumer's epilogue added it."""
+        r = _res_take(ctx.res_in)
+        if r is not None and not already:
+            r = _c(r).view_as(dx)
+            _call("movae_add", dx.data_ptr(), r.data_ptr(), dx.data_ptr(), dx.numel(), _st(dx))
+        return dx
 
     @staticmethod
     def backward_batched(ctx, G, dy):
         (y,) = ctx.saved_tensors
         dy = _stacked(dy, G)
         if _act_take(ctx, dy):
-            return dy, None, None, None
+            return Activation._add_res(ctx, dy, ctx.act_out.res_done), None, None, None, None
         dx = torch.empty_like(dy)
         c = y.shape[-1]
         if c % 4 == 0 and dy.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0:  # all groups in one launch
@@ -925,13 +991,13 @@ class Activation(Function):
             for g in range(G):
                 _call("movae_act_bwd", dy[g].data_ptr(), y.data_ptr(), dx[g].data_ptr(), y.numel(), L.ACT[ctx.act], float(ctx.slope),
                       _st(dy))
-        return dx, None, None, None
+        return Activation._add_res(ctx, dx, False), None, None, None, None
 
 
-def activation(x, act, slope=0.01, act_out=None):
+def activation(x, act, slope=0.01, act_out=None, res_in=None):
     if not L.ACT[act]:
         return x
-    return Activation.apply(x, act, slope, act_out)
+    return Activation.apply(x, act, slope, act_out, res_in)
 
 
 class Add(Function):
@@ -953,6 +1019,42 @@ class Add(Function):
     @staticmethod
     def backward_batched(ctx, G, dy):
         return dy, dy
+
+
+class ResidualAdd(Function):
+    """out = branch + x with the identity cotangent handed to the branch's first op (ResCarrier) instead of to the engine."""
+
+    @staticmethod
+    def forward(ctx, branch, x, carrier):
+        ctx.set_materialize_grads(False)
+        L.require_gpu(x)
+        branch, x = _c(branch), _c(x)
+        y = torch.empty_like(x)
+        _call("movae_add", branch.data_ptr(), x.data_ptr(), y.data_ptr(), x.numel(), _st(x))
+        ctx.carrier = carrier
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if dy is None:
+            return (None,) * 3
+        if ctx.carrier is None or not ctx.needs_input_grad[1]:
+            return dy, dy, None
+        ctx.carrier.res = _c(dy)
+        return dy, None, None
+
+    @staticmethod
+    def backward_batched(ctx, G, dy):
+        if ctx.carrier is None or not ctx.needs_input_grad[1]:
+            return dy, dy, None
+        ctx.carrier.res = _stacked(dy, G)
+        return dy, None, None
+
+
+def residual_add(branch, x, carrier):
+    """branch(x) + x; carrier: the ResCarrier the branch's first op was given (None: a plain add)."""
+    assert branch.shape == x.shape
+    return ResidualAdd.apply(branch, x, carrier)
 
 
 def add(a, b):

@@ -139,3 +139,47 @@ def test_vqvae2_resblock_standalone_relu(fused, gpu_device, monkeypatch):
     n_bwd = sum(1 for nm in calls if nm.startswith("movae_act_bwd"))
     # unfused: 2 blocks x (stand-alone ReLU + epilogue ReLU) + the trailing ReLU; fused: only the trailing one (no conv reads it)
     assert n_bwd == (1 if fused else 5), calls
+    # the identity branch's cotangent: added by the 3x3 conv's input-gradient epilogue (no launch), else one explicit add per block
+    assert calls.count("movae_add") == (0 if fused else 2), calls
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_vqvae_residual_layer(fused, gpu_device, monkeypatch):
+    """models/vq_vae.py ResidualLayer: x + Conv1x1(ReLU(Conv3x3(x))), bias-free -- the branch starts with a conv, whose input-gradient
+    epilogue adds the identity cotangent (no activation in front).  (The grouped forms of the batched pull-back run through the
+    same blocks in tests/test_hip_parity_full.py: C3 Aligned-MTL and C4 MGDA at the config shapes.)"""
+    groups = 1
+    import movae_amd  # noqa: F401
+    from movae_amd import _lib as L, nn as mnn, ops
+    from movae_amd.models.vq_vae import ResidualLayer
+
+    monkeypatch.setattr(ops, "FUSE_ACT", fused)
+    calls = []
+    monkeypatch.setattr(L, "TRACE", lambda nm, a: calls.append(nm))
+    torch.manual_seed(9)
+    head = mnn.Conv2d(8, 64, 3, 1, 1).to(gpu_device)
+    layers = mnn.Stack(ResidualLayer(64, 64), ResidualLayer(64, 64), mnn.LeakyReLU()).to(gpu_device)
+    x = torch.randn(4, 8, 8, 8)
+    xr = x.clone().requires_grad_(True)
+    hw = [t.detach().cpu().contiguous().clone().requires_grad_(True) for t in (head.weight, head.bias)]
+    h = F.conv2d(xr, hw[0], hw[1], padding=1)
+    ws = []
+    for rl in list(layers)[:2]:
+        w3 = rl.resblock[0].weight.detach().cpu().contiguous().clone().requires_grad_(True)
+        w1 = rl.resblock[2].weight.detach().cpu().contiguous().clone().requires_grad_(True)
+        ws.append((w3, w1))
+        h = h + F.conv2d(F.relu(F.conv2d(h, w3, padding=1)), w1)
+    h = F.leaky_relu(h, 0.01)
+    gen = torch.Generator().manual_seed(4)
+    cots = [torch.randn(h.shape, generator=gen) for _ in range(groups)]
+    ref = [torch.autograd.grad((h * c).sum(), [xr, hw[0]] + [t for pair in ws for t in pair], retain_graph=True) for c in cots]
+    xh = x.to(gpu_device).requires_grad_(True)
+    out = layers(head(ops.to_nhwc(xh))).permute(0, 3, 1, 2)
+    _close(out, h, "output", rtol=5e-4, atol=5e-5)
+    params = [xh, head.weight] + [t for rl in list(layers)[:2] for t in (rl.resblock[0].weight, rl.resblock[2].weight)]
+    calls.clear()
+    got = [torch.autograd.grad((out * cots[0].to(gpu_device)).sum(), params)]
+    for g in range(groups):
+        for a, b, nm in zip(got[g], ref[g], ["dx", "dW_head", "dW3_0", "dW1_0", "dW3_1", "dW1_1"]):
+            _close(a, b, f"group {g} {nm}")
+    assert calls.count("movae_add") == (0 if fused else 2), calls
