@@ -711,7 +711,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_cls(const float* __restrict
         for (int z = 1; z < S; ++z) v += *reinterpret_cast<const f32x4*>(slab + (long)z * total + i);
         if (actmul_on(am)) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = actmul_apply(am, v[j], i + j);
+            for (int j = 0; j < 4; ++j) v[j] = actmul_apply(am, v[j] + (bias ? bias[n + j] : 0.f), i + j);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j] + (bias ? bias[n + j] : 0.f), act, slope);
@@ -1197,15 +1197,23 @@ int check_conv_shape(const char* who, int n, int hi, int wi, int ci, int ho, int
 // installs a movae_fuse_t for the dispatch made inside the scope; on exit reports the statistics partial count and clears it
 struct FuseScope {
     movae_fuse_t* f;
-    explicit FuseScope(movae_fuse_t* fuse, int nrm_side) : f(fuse) {
+    bool fwd;  // a forward pass (nrm_side 0): owns ep_res / ep_act_done (the backward entry points set them around their dgrad)
+    explicit FuseScope(movae_fuse_t* fuse, int nrm_side) : f(fuse), fwd(nrm_side == 0) {
         g_fuse = FuseCtx();
         if (!f) return;
         f->stats_parts = 0;
         if (f->in_scale && f->in_shift) g_fuse.nrm = Norm{f->in_scale, f->in_shift, f->in_slope}, g_fuse.nrm_side = nrm_side;
         if (f->stats && f->stats_cap > 0) g_fuse.stats = f->stats, g_fuse.stats_cap = f->stats_cap;
+        // forward passes: out = conv(x) (+ bias) + ep_res -- the last conv of a residual branch adds the block's input itself
+        if (fwd) {
+            f->ep_act_done = 0;
+            if (f->ep_res && (reinterpret_cast<uintptr_t>(f->ep_res) & 15) == 0)
+                g_fuse.am = ActMul{nullptr, 0, 0.f, 0, 0, f->ep_res}, g_fuse.am_groups = 1;
+        }
     }
     ~FuseScope() {
         if (f) f->stats_parts = g_fuse.stats_parts;
+        if (f && fwd) f->ep_act_done = g_fuse.am_done ? 1 : 0;
         g_fuse = FuseCtx();
     }
 };

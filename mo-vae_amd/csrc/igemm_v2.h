@@ -354,6 +354,7 @@ __device__ __forceinline__ void igemm2_fwd_body(const FwdArgs& a, float* __restr
             const int row = q / QPR, n = n0 + (q - row * QPR) * 4, m = m0 + row;
             if (m >= M || n >= N) continue;
             f32x4 v = *reinterpret_cast<const f32x4*>(Ts + row * LDT + (n - n0));
+            if (ep.bias) v += *reinterpret_cast<const f32x4*>(ep.bias + n);
             if (yp) {
                 const f32x4 y4 = *reinterpret_cast<const f32x4*>(yp + (long)(yrow0 + row) * N + n);
 #pragma unroll
@@ -676,6 +677,7 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
             const int hc = fdiv(rem, a.fd_w[cls]), wc = rem - hc * Woc;
             const long p = (long)(img * g.Ho + (hc * s + ph)) * g.Wo + (wc * s + pw);
             f32x4 v = *reinterpret_cast<const f32x4*>(Ts + row * LDT + (n - n0));
+            if (ep.bias) v += *reinterpret_cast<const f32x4*>(ep.bias + n);
             if (yp) {
                 const f32x4 y4 = *reinterpret_cast<const f32x4*>(yp + (p - ybase) * N + n);
 #pragma unroll
@@ -1170,8 +1172,9 @@ int launch_fwd2(const float* X, const float* W, float* Y, const Geom& g, const E
     }
     // the previous layer's activation derivative on the result: in the epilogue (unsplit) or in the reduce
     ActMul ram{nullptr, 0, 0.f, 0, 0, nullptr};
-    if ((g_fuse.am.y || g_fuse.am.res) && ep.act == MOVAE_ACT_NONE && !ep.bias && !rbb.y && !a.bb.y && M % g_fuse.am_groups == 0 &&
-        g.Nn % 4 == 0 && (reinterpret_cast<uintptr_t>(Y) & 15) == 0) {
+    if ((g_fuse.am.y || g_fuse.am.res) && ep.act == MOVAE_ACT_NONE && (!ep.bias || !g_fuse.am.y) && !rbb.y && !a.bb.y &&
+        M % g_fuse.am_groups == 0 && g.Nn % 4 == 0 && ((reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(ep.bias)) & 15) == 0 &&
+        !want_stats) {
         const long rpg = M / g_fuse.am_groups;
         if (g_fuse.am_groups == 1 || rpg % BM == 0 || S > 1 || !g_fuse.am.y) {
             ActMul am = g_fuse.am;
@@ -1294,8 +1297,8 @@ int launch_bwd2(const float* X, const float* W, float* Y, const Geom& g, const E
         }
     }
     ActMul ram{nullptr, 0, 0.f, 0, 0, nullptr};  // (see launch_fwd2)
-    if ((g_fuse.am.y || g_fuse.am.res) && ep.act == MOVAE_ACT_NONE && !ep.bias && !rbb.y && !a.bb.y && g.Nn % 4 == 0 &&
-        (reinterpret_cast<uintptr_t>(Y) & 15) == 0) {
+    if ((g_fuse.am.y || g_fuse.am.res) && ep.act == MOVAE_ACT_NONE && (!ep.bias || !g_fuse.am.y) && !rbb.y && !a.bb.y && g.Nn % 4 == 0 &&
+        ((reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(ep.bias)) & 15) == 0 && !want_stats) {
         const long pix = (long)g.Nimg * g.Ho * g.Wo;
         const int G = g_fuse.am_groups;
         if (pix % G == 0) {

@@ -151,7 +151,12 @@ class Stack(tnn.Sequential):
         return (isinstance(mods[0], _Act) and mods[0].kind in ("lrelu", "relu") and len(mods) > 1 and
                 isinstance(mods[1], (Conv2d, ConvTranspose2d)))
 
-    def forward(self, x, act_in=None, res_in=None):
+    def accepts_res_out(self):
+        """Does this Stack end with a plain conv (no BatchNorm, no activation after it) that can add a residual block's input?"""
+        mods = list(self)
+        return bool(mods) and isinstance(mods[-1], (Conv2d, ConvTranspose2d))
+
+    def forward(self, x, act_in=None, res_in=None, res_out=None):
         """x: an NHWC tensor or an ops.LazyBN (the unmaterialised output of a fused BatchNorm); may return either -- a LazyBN
         leaves a Stack only when its last module is a fused BatchNorm (+ activation), and is handed on to Stacks and convs
         as it is; every other module receives the materialised tensor.
@@ -165,6 +170,8 @@ class Stack(tnn.Sequential):
         self._out_link = None
         if res_in is not None and (isinstance(x, ops.LazyBN) or not self.accepts_res_in()):
             raise ValueError("res_in: the first op of this Stack cannot take a residual block's identity cotangent")
+        if res_out is not None and not self.accepts_res_out():
+            raise ValueError("res_out: this Stack does not end with a plain conv")
         while i < n:
             m = mods[i]
             rin = res_in if i == 0 else None  # (only the op applied to the block's input)
@@ -195,7 +202,9 @@ class Stack(tnn.Sequential):
                     link = out
                     i += 2
                 else:
-                    x = m(x, None, False, ops.ConvFusion(act_in=link, res_in=rin) if (link is not None or rin is not None) else None)
+                    rout = res_out if i == n - 1 else None  # (the residual branch's last conv adds the block's input)
+                    x = m(x, None, False, ops.ConvFusion(act_in=link, res_in=rin, res_out=rout)
+                          if (link is not None or rin is not None or rout is not None) else None)
                     link = None
                     i += 1
             elif (isinstance(m, _Act) and m.kind in ("lrelu", "relu") and i + 1 < n and isinstance(mods[i + 1], (Conv2d, ConvTranspose2d))

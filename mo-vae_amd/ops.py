@@ -307,15 +307,19 @@ class ConvFusion:
     in_*: the input is the RAW output y of a producer conv whose BatchNorm + activation this conv applies while loading,
     x = leaky_relu(in_scale[c] * y + in_shift[c], in_slope).  want_stats: the epilogue (or split-K reduce) also emits the
     per-channel partial sums of this conv's own output for the BatchNorm that follows it: `stats` / `parts` on return."""
-    __slots__ = ("in_scale", "in_shift", "in_slope", "want_stats", "stats", "parts", "link", "act_in", "act_out", "res_in")
+    __slots__ = ("in_scale", "in_shift", "in_slope", "want_stats", "stats", "parts", "link", "act_in", "act_out", "res_in", "res_out")
 
-    def __init__(self, in_scale=None, in_shift=None, in_slope=1.0, want_stats=False, link=None, act_in=None, act_out=None, res_in=None):
+    def __init__(self, in_scale=None, in_shift=None, in_slope=1.0, want_stats=False, link=None, act_in=None, act_out=None, res_in=None,
+                 res_out=None):
         self.in_scale, self.in_shift, self.in_slope, self.want_stats = in_scale, in_shift, float(in_slope), want_stats
         self.stats, self.parts = None, 0
         #: ActLink of the producer whose activation output is this conv's input / ActLink this conv fills for its consumer
         self.act_in, self.act_out = act_in, act_out
         #: ResCarrier of the residual block whose branch starts with THIS conv (its input is the block's input)
         self.res_in = res_in
+        #: (x, ResCarrier): this conv ENDS a residual branch -- its epilogue adds the block's input x, its backward hands the
+        #: cotangent of the sum to the carrier (what ops.residual_add would do, without the launches)
+        self.res_out = res_out
         #: dict shared with the BatchNormLazy node whose output this conv consumes: the conv's backward leaves that
         #: BatchNorm's backward sums here (emitted by the input-gradient epilogue), the BatchNorm's backward picks them up
         self.link = link
@@ -462,10 +466,14 @@ class Conv(Function):
             stats = torch.empty((n * ho * wo // 8 + 64) * 2 * co, dtype=torch.float32, device=x.device)
         if in_norm is not None and ((fn, geom) in _NO_FUSE or not FUSE_NORM):
             x, in_norm = scale_shift_act(x, *in_norm), None
-        if in_norm is None and stats is None:
+        res_out = fusion.res_out if (fusion is not None and fusion.res_out is not None and not L.ACT[act]) else None
+        if res_out is not None:
+            assert tuple(res_out[0].shape) == tuple(y.shape), "residual input and branch output differ in shape"
+        ep_fwd = (None, _c(res_out[0])) if res_out is not None else None
+        if in_norm is None and stats is None and ep_fwd is None:
             _call(fn, x.data_ptr(), wm.data_ptr(), L.ptr(b), y.data_ptr(), *geom, L.ACT[act], float(slope), wsp, wsb, _st(x))
         else:
-            f = _fuse_struct(in_norm, stats)
+            f = _fuse_struct(in_norm, stats, None, ep_fwd)
             try:
                 _call(fn + "_f", x.data_ptr(), wm.data_ptr(), L.ptr(b), y.data_ptr(), *geom, L.ACT[act], float(slope), wsp, wsb, _st(x),
                       C.byref(f))
@@ -474,11 +482,13 @@ class Conv(Function):
                     raise
                 _NO_FUSE.add((fn, geom))
                 x, in_norm = scale_shift_act(x, *in_norm), None
-                f = _fuse_struct(None, stats)
+                f = _fuse_struct(None, stats, None, ep_fwd)
                 _call(fn + "_f", x.data_ptr(), wm.data_ptr(), L.ptr(b), y.data_ptr(), *geom, L.ACT[act], float(slope), wsp, wsb, _st(x),
                       C.byref(f))
             if fusion is not None:
                 fusion.stats, fusion.parts = stats, int(f.stats_parts)
+            if ep_fwd is not None and not int(f.ep_act_done):  # this kernel has no such epilogue: one explicit add
+                _call("movae_add", y.data_ptr(), ep_fwd[1].data_ptr(), y.data_ptr(), y.numel(), _st(x))
         ctx.geom = geom
         ctx.transposed, ctx.act, ctx.slope, ctx.has_bias = transposed, act, slope, b is not None
         ctx.bias_grad_is_zero = bias_grad_is_zero
@@ -486,6 +496,7 @@ class Conv(Function):
         ctx.bn_link = fusion.link if (fusion is not None and in_norm is not None) else None
         ctx.act_in = fusion.act_in if (fusion is not None and in_norm is None) else None
         ctx.res_in = fusion.res_in if fusion is not None else None
+        ctx.res_out = res_out[1] if res_out is not None else None
         ctx.act_out = None
         if fusion is not None and fusion.act_out is not None and L.ACT[act]:
             ctx.act_out = fusion.act_out
@@ -534,6 +545,8 @@ class Conv(Function):
             return (None,) * 11
         x, w, y, b, in_norm = Conv._saved(ctx)
         dy = _c(dy)
+        if ctx.res_out is not None:  # this conv's output is branch + block input: dy is the identity branch's cotangent too
+            ctx.res_out.res = dy
         n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad = ctx.geom
         st = _st(dy)
         wsp, wsb = _ws(dy)
@@ -621,6 +634,8 @@ class Conv(Function):
         group reduces over its own pixels, x is shared) writing straight into the groups' Jacobian rows."""
         x, w, y, b, in_norm = Conv._saved(ctx)
         dy = _stacked(dy, G)
+        if ctx.res_out is not None:
+            ctx.res_out.res = dy
         n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad = ctx.geom
         st = _st(dy)
         wsp, wsb = _ws(dy)
