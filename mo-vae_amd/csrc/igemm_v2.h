@@ -331,11 +331,14 @@ __device__ __forceinline__ void igemm2_fwd_body(const FwdArgs& a, float* __restr
     const long pidx = (long)bx * T::WM + wm;
     // the block's first row inside its cotangent group (bb / am: the auxiliary tensor is shared by the groups)
     const int yrow0 = bb_on ? m0 % a.bb.rows_per_group : ((am_on && a.am.y) ? (int)(m0 % (a.am.per_group / N)) : 0);
-    if (am_on) {
-        // ActMul epilogue (result * act'(y) + res): the tile goes through LDS once (free after the loop's last barrier) so that
-        // y, res and the result move as 16-byte pieces along n -- in accumulator layout a lane holds one column, i.e. 64 4-byte
-        // loads per operand and lane, issued in batches as registers allow: measured +6 % on a 320 us kernel, more than the
-        // element-wise pass it replaces.  (Host: N % 4 == 0, 16-byte aligned operands.)
+    // Every epilogue that emits no BatchNorm side product moves its tile through LDS once (free after the loop's last barrier)
+    // and then works in 16-byte pieces along n: in accumulator layout a lane holds one COLUMN -- 64 four-byte stores per lane
+    // (and as many loads per auxiliary operand of the ActMul form, issued in batches as registers allow).  Measured: plain
+    // stores / slab writes -3 % (C3 layers) to -6 % (C2 layers) per call; the ActMul form was 6 % SLOWER than the element-wise
+    // pass it replaces before this.  (ActMul: the host guarantees N % 4 == 0 and 16-byte aligned operands.)
+    const bool lds_ep = am_on || (!st_on && !bb_on && (N & 3) == 0 &&
+                                  ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(ep.bias)) & 15) == 0);
+    if (lds_ep) {
         constexpr int LDT = BN + 4, QPR = BN / 4;
         static_assert(BM * LDT <= FwdSmem<BM, BN>::FLOATS, "tile fits the stage buffers");
         float* Ts = smem;
@@ -354,14 +357,21 @@ __device__ __forceinline__ void igemm2_fwd_body(const FwdArgs& a, float* __restr
             const int row = q / QPR, n = n0 + (q - row * QPR) * 4, m = m0 + row;
             if (m >= M || n >= N) continue;
             f32x4 v = *reinterpret_cast<const f32x4*>(Ts + row * LDT + (n - n0));
-            if (ep.bias) v += *reinterpret_cast<const f32x4*>(ep.bias + n);
-            if (yp) {
-                const f32x4 y4 = *reinterpret_cast<const f32x4*>(yp + (long)(yrow0 + row) * N + n);
+            if (!to_slab) {
+                if (ep.bias) v += *reinterpret_cast<const f32x4*>(ep.bias + n);
+                if (am_on) {
+                    if (yp) {
+                        const f32x4 y4 = *reinterpret_cast<const f32x4*>(yp + (long)(yrow0 + row) * N + n);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] *= act_grad_from_out(y4[j], a.am.act, a.am.slope);
+                        for (int j = 0; j < 4; ++j) v[j] *= act_grad_from_out(y4[j], a.am.act, a.am.slope);
+                    }
+                    if (rp) v += *reinterpret_cast<const f32x4*>(rp + (long)m * N + n);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], ep.act, ep.slope);
+                }
             }
-            if (rp) v += *reinterpret_cast<const f32x4*>(rp + (long)m * N + n);
-            *reinterpret_cast<f32x4*>(Y + (long)m * N + n) = v;
+            *reinterpret_cast<f32x4*>(out + (long)m * N + n) = v;
         }
         return;
     }
@@ -654,7 +664,9 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
         pidx = (long)gi * a.bb.ppg + ((long)cls * bpg + (bx - gi * bpg)) * T::WM + wm;
         ybase = (long)gi * a.bb.rows_per_group;
     }
-    if (am_on) {  // ActMul epilogue through LDS: see igemm2_fwd_body (rows are the class's pixels here)
+    const bool lds_ep = am_on || (!st_on && !bb_on && (N & 3) == 0 &&
+                                  ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(ep.bias)) & 15) == 0);
+    if (lds_ep) {  // epilogue through LDS in 16-byte pieces: see igemm2_fwd_body (rows are the class's pixels here)
         constexpr int LDT = BN + 4, QPR = BN / 4;
         static_assert(BM * LDT <= BwdSmem<BM, BN>::FLOATS, "tile fits the stage buffers");
         float* Ts = smem;
@@ -677,14 +689,21 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
             const int hc = fdiv(rem, a.fd_w[cls]), wc = rem - hc * Woc;
             const long p = (long)(img * g.Ho + (hc * s + ph)) * g.Wo + (wc * s + pw);
             f32x4 v = *reinterpret_cast<const f32x4*>(Ts + row * LDT + (n - n0));
-            if (ep.bias) v += *reinterpret_cast<const f32x4*>(ep.bias + n);
-            if (yp) {
-                const f32x4 y4 = *reinterpret_cast<const f32x4*>(yp + (p - ybase) * N + n);
+            if (!to_slab) {
+                if (ep.bias) v += *reinterpret_cast<const f32x4*>(ep.bias + n);
+                if (am_on) {
+                    if (yp) {
+                        const f32x4 y4 = *reinterpret_cast<const f32x4*>(yp + (p - ybase) * N + n);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] *= act_grad_from_out(y4[j], a.am.act, a.am.slope);
+                        for (int j = 0; j < 4; ++j) v[j] *= act_grad_from_out(y4[j], a.am.act, a.am.slope);
+                    }
+                    if (rp) v += *reinterpret_cast<const f32x4*>(rp + p * N + n);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], ep.act, ep.slope);
+                }
             }
-            if (rp) v += *reinterpret_cast<const f32x4*>(rp + p * N + n);
-            *reinterpret_cast<f32x4*>(Y + p * N + n) = v;
+            *reinterpret_cast<f32x4*>(out + p * N + n) = v;
         }
         return;
     }
@@ -1008,6 +1027,26 @@ __device__ __forceinline__ void igemm2_wgrad_body(const WgArgs& a, float* __rest
 
     const int lane = t & 63, half = lane >> 5, l31 = lane & 31;
     float* dst = to_slab ? out + (long)bz * a.slab_stride : a.tab.p[grp];
+    if ((N & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {  // through LDS in 16-byte pieces (see igemm2_fwd_body)
+        constexpr int LDT = BN + 4, QPR = BN / 4;
+        static_assert(BM * LDT <= WgSmem<BM, BN>::FLOATS, "tile fits the stage buffers");
+        __syncthreads();  // (the column-sum fold above may still be reading LDS)
+        float* Ts = smem;
+#pragma unroll
+        for (int tn = 0; tn < T::TN; ++tn)
+#pragma unroll
+            for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Ts[(wm * T::TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDT + wn * T::TN * 32 + tn * 32 + l31] =
+                        acc[tm * T::TN + tn][r];
+        __syncthreads();
+        for (int q = t; q < BM * QPR; q += 256) {
+            const int row = q / QPR, n = n0 + (q - row * QPR) * 4, m = m0 + row;
+            if (m < M && n < N) *reinterpret_cast<f32x4*>(dst + (long)m * N + n) = *reinterpret_cast<const f32x4*>(Ts + row * LDT + (n - n0));
+        }
+        return;
+    }
 #pragma unroll
     for (int tn = 0; tn < T::TN; ++tn) {
         const int n = n0 + wn * T::TN * 32 + tn * 32 + l31;
