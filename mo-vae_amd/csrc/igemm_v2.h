@@ -375,6 +375,74 @@ __device__ __forceinline__ void igemm2_fwd_body(const FwdArgs& a, float* __restr
         }
         return;
     }
+    if ((st_on || bb_on) && (N & 3) == 0 &&
+        ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(ep.bias) | reinterpret_cast<uintptr_t>(a.bb.y)) & 15) == 0) {
+        // the same through-LDS epilogue with a BatchNorm side product: a thread owns one column quad and every (256 / QPR)-th row
+        // of the tile, adds up its part of the column sums, the row lanes fold through LDS in fixed order.  ONE partial pair per
+        // block: it goes to the block's first wave-row slot, the other WM - 1 slots of the layout read zero.
+        constexpr int LDT = BN + 4, QPR = BN / 4, RSTEP = 256 / QPR;
+        float* Ts = smem;
+#pragma unroll
+        for (int tn = 0; tn < T::TN; ++tn)
+#pragma unroll
+            for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Ts[(wm * T::TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDT + wn * T::TN * 32 + tn * 32 + l31] =
+                        acc[tm * T::TN + tn][r];
+        __syncthreads();
+        const int cq = t % QPR, rowi = t / QPR, n = n0 + cq * 4;
+        f32x4 s1 = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = s1;
+        if (n < N) {
+            const f32x4 b4 = ep.bias ? *reinterpret_cast<const f32x4*>(ep.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 sc4 = bb_on ? *reinterpret_cast<const f32x4*>(a.bb.scale + n) : b4;
+            const f32x4 sh4 = bb_on ? *reinterpret_cast<const f32x4*>(a.bb.shift + n) : b4;
+            const float* __restrict__ yp = a.bb.y;
+            for (int rb = rowi; rb < BM; rb += 4 * RSTEP) {
+                f32x4 y4[4];  // (the y loads of four rows ahead of their stores: see the note on aliasing below)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int row = rb + u * RSTEP;
+                    y4[u] = (bb_on && row < BM && m0 + row < M) ? *reinterpret_cast<const f32x4*>(yp + (long)(yrow0 + row) * N + n)
+                                                                : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int row = rb + u * RSTEP, m = m0 + row;
+                    if (row >= BM || m >= M) continue;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(Ts + row * LDT + cq * 4);
+                    if (st_on) {
+                        v += b4;
+                        s1 += v;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) s2[j] = fmaf(v[j], v[j], s2[j]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float d = v[j] * (fmaf(y4[u][j], sc4[j], sh4[j]) > 0.f ? 1.f : a.bb.slope);
+                            s1[j] += d;
+                            s2[j] = fmaf(d, y4[u][j], s2[j]);
+                        }
+                    }
+                    *reinterpret_cast<f32x4*>(out + (long)m * N + n) = v;
+                }
+            }
+        }
+        __syncthreads();
+        *reinterpret_cast<f32x4*>(Ts + rowi * BN + cq * 4) = s1;
+        *reinterpret_cast<f32x4*>(Ts + (RSTEP + rowi) * BN + cq * 4) = s2;
+        __syncthreads();
+        if (t < BN && n0 + t < N) {
+            float c1 = 0.f, c2 = 0.f;
+            for (int i = 0; i < RSTEP; ++i) c1 += Ts[i * BN + t], c2 += Ts[(RSTEP + i) * BN + t];
+            float* P = st_on ? a.stats : a.bb.part;
+            const long p0 = (long)bx * T::WM;
+            P[(p0 * 2 + 0) * N + n0 + t] = c1;
+            P[(p0 * 2 + 1) * N + n0 + t] = c2;
+            for (int w = 1; w < T::WM; ++w) P[((p0 + w) * 2 + 0) * N + n0 + t] = 0.f, P[((p0 + w) * 2 + 1) * N + n0 + t] = 0.f;
+        }
+        return;
+    }
 #pragma unroll
     for (int tn = 0; tn < T::TN; ++tn) {
         const int n = n0 + wn * T::TN * 32 + tn * 32 + l31;
@@ -704,6 +772,79 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
                 }
             }
             *reinterpret_cast<f32x4*>(out + p * N + n) = v;
+        }
+        return;
+    }
+    if ((st_on || bb_on) && (N & 3) == 0 &&
+        ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(ep.bias) | reinterpret_cast<uintptr_t>(a.bb.y)) & 15) == 0) {
+        // through-LDS epilogue with a BatchNorm side product: see igemm2_fwd_body (one partial pair per block, in its first slot)
+        constexpr int LDT = BN + 4, QPR = BN / 4, RSTEP = 256 / QPR;
+        float* Ts = smem;
+#pragma unroll
+        for (int tn = 0; tn < T::TN; ++tn)
+#pragma unroll
+            for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Ts[(wm * T::TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDT + wn * T::TN * 32 + tn * 32 + l31] =
+                        acc[tm * T::TN + tn][r];
+        __syncthreads();
+        const int cq = t % QPR, rowi = t / QPR, n = n0 + cq * 4;
+        const int hwc = Hoc * Woc;
+        f32x4 s1 = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = s1;
+        if (n < N) {
+            const f32x4 b4 = ep.bias ? *reinterpret_cast<const f32x4*>(ep.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 sc4 = bb_on ? *reinterpret_cast<const f32x4*>(a.bb.scale + n) : b4;
+            const f32x4 sh4 = bb_on ? *reinterpret_cast<const f32x4*>(a.bb.shift + n) : b4;
+            const float* __restrict__ yp = a.bb.y;
+            for (int rb = rowi; rb < BM; rb += 4 * RSTEP) {
+                f32x4 y4[4];
+                long px[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int row = rb + u * RSTEP, m = m0 + row;
+                    px[u] = -1;
+                    y4[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (row < BM && m < M) {
+                        const int img = fdiv(m, a.fd_hw[cls]), rem = m - img * hwc;
+                        const int hc = fdiv(rem, a.fd_w[cls]), wc = rem - hc * Woc;
+                        px[u] = (long)(img * g.Ho + (hc * s + ph)) * g.Wo + (wc * s + pw);
+                        if (bb_on) y4[u] = *reinterpret_cast<const f32x4*>(yp + (px[u] - ybase) * N + n);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (px[u] < 0) continue;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(Ts + (rb + u * RSTEP) * LDT + cq * 4);
+                    if (st_on) {
+                        v += b4;
+                        s1 += v;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) s2[j] = fmaf(v[j], v[j], s2[j]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float d = v[j] * (fmaf(y4[u][j], sc4[j], sh4[j]) > 0.f ? 1.f : a.bb.slope);
+                            s1[j] += d;
+                            s2[j] = fmaf(d, y4[u][j], s2[j]);
+                        }
+                    }
+                    *reinterpret_cast<f32x4*>(out + px[u] * N + n) = v;
+                }
+            }
+        }
+        __syncthreads();
+        *reinterpret_cast<f32x4*>(Ts + rowi * BN + cq * 4) = s1;
+        *reinterpret_cast<f32x4*>(Ts + (RSTEP + rowi) * BN + cq * 4) = s2;
+        __syncthreads();
+        if (t < BN && n0 + t < N) {
+            float c1 = 0.f, c2 = 0.f;
+            for (int i = 0; i < RSTEP; ++i) c1 += Ts[i * BN + t], c2 += Ts[(RSTEP + i) * BN + t];
+            float* P = st_on ? a.stats : a.bb.part;
+            const long p0 = pidx - wm;  // the block's first wave-row slot
+            P[(p0 * 2 + 0) * N + n0 + t] = c1;
+            P[(p0 * 2 + 1) * N + n0 + t] = c2;
+            for (int w = 1; w < T::WM; ++w) P[((p0 + w) * 2 + 0) * N + n0 + t] = 0.f, P[((p0 + w) * 2 + 1) * N + n0 + t] = 0.f;
         }
         return;
     }
