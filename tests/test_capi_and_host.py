@@ -225,3 +225,29 @@ def test_reference_yaml_argv_parses(pkg, capsys):
         --prior_lmdb_map_size_gb""".split()
     known = {s for act in train.build_parser()._actions for s in act.option_strings}
     assert len(ref_flags) == 96 and not [f for f in ref_flags if f not in known]
+
+
+def test_fuse_struct_layout_matches_the_header(pkg, tmp_path):
+    """movae_fuse_t crosses the C ABI by address: the ctypes mirror (_lib.MovaeFuse) must have the header's field offsets and size.
+    include/movae.h is plain C: compile a probe with the host compiler and compare."""
+    import ctypes as C
+    import shutil
+    import subprocess
+
+    import movae_amd._lib as L
+
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no host C compiler")
+    names = [n for n, _ in L.MovaeFuse._fields_]
+    src = tmp_path / "probe.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "movae.h"\nint main(void) {\n'
+                   '  printf("%zu\\n", sizeof(movae_fuse_t));\n' +
+                   "".join(f'  printf("{n} %zu\\n", offsetof(movae_fuse_t, {n}));\n' for n in names) + "  return 0;\n}\n")
+    exe = tmp_path / "probe"
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.run([cc, "-I", inc, str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    assert int(out[0]) == C.sizeof(L.MovaeFuse)
+    want = {ln.split()[0]: int(ln.split()[1]) for ln in out[1:] if ln.strip()}
+    assert want == {n: getattr(L.MovaeFuse, n).offset for n in names}
