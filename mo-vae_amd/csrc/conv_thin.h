@@ -18,7 +18,7 @@ namespace thin {
 template <int NN, bool BWD>
 __global__ __launch_bounds__(256) void thin_in_k(const float* __restrict__ X, const float* __restrict__ W,
                                                  const float* __restrict__ bias, float* __restrict__ Y, Geom g, int M, int act,
-                                                 float slope, float* __restrict__ stats, BnBwd bb) {
+                                                 float slope, float* __restrict__ stats, BnBwd bb, ActMul am) {
     extern __shared__ __attribute__((aligned(16))) float Wl[];  // [K][NN]
     const int t = threadIdx.x;
     const int taps = g.KH * g.KW, K = taps * g.Cr, N = g.Nn;
@@ -125,6 +125,32 @@ __global__ __launch_bounds__(256) void thin_in_k(const float* __restrict__ X, co
                 bb.part[(pidx * 2 + 0) * 32 + c] = s1;
                 bb.part[(pidx * 2 + 1) * 32 + c] = s2;
             }
+        }
+        if (actmul_on(am)) {
+            // the result is the cotangent of an activation output / a residual block's branch (ActMul): factor act'(y) and the
+            // identity cotangent on the way out, 16-byte pieces, all loads of a thread ahead of its stores
+            f32x4 y4[8], r4[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = i * 256 + t, px = idx >> 3, q = idx & 7;
+                const long o = ((long)blockIdx.x * 256 + px) * 32 + q * 4;
+                const bool ok = px < rows_left;
+                y4[i] = (ok && am.y) ? *reinterpret_cast<const f32x4*>(am.y + o % am.per_group) : f32x4{0.f, 0.f, 0.f, 0.f};
+                r4[i] = (ok && am.res) ? *reinterpret_cast<const f32x4*>(am.res + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = i * 256 + t, px = idx >> 3, q = idx & 7;
+                if (px < rows_left) {
+                    const float* src = Wl + px * 33 + q * 4;
+                    f32x4 o4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        o4[e] = src[e] * (am.y ? act_grad_from_out(y4[i][e], am.act, am.slope) : 1.f) + r4[i][e];
+                    *reinterpret_cast<f32x4*>(yb + px * 32 + q * 4) = o4;
+                }
+            }
+            return;
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -614,7 +640,8 @@ template <int TC, int KH, int KW, bool REV>
 __global__ __launch_bounds__(256) void thin_wgrad_mfma_k(const float* __restrict__ Wide, const float* __restrict__ Thin,
                                                          float* __restrict__ slab, int Hw, int Ww, int Cw, int Ht, int Wt,
                                                          int stride, int pad, int TH, int TW, int tiles_h, int tiles_w,
-                                                         int Cs, int Cb, long wide_gs, long thin_gs, long slab_gs, Norm nrm, int ntiles) {
+                                                         int Cs, int Cb, long wide_gs, long thin_gs, long slab_gs, Norm nrm, int ntiles,
+                                                         FastDiv fd_tw, FastDiv fd_bw) {
     constexpr int TAPS = KH * KW, NA = TAPS * TC, NT = (NA + 31) / 32;
     static_assert(NT <= 2, "at most 64 columns");
     Wide += blockIdx.z * wide_gs;
@@ -645,59 +672,91 @@ __global__ __launch_bounds__(256) void thin_wgrad_mfma_k(const float* __restrict
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
     const int step = REV ? 1 : stride;
-    // persistent: the block walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and keeps ONE accumulator set -- one fold, one slab
-    // row and one reduce input per block instead of per tile (the per-tile epilogue and the 8192-slab reduce were the cost)
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int tw_shift = __ffs(TW) - 1;
+    // Operands of a tile travel global -> registers -> LDS, and the registers of tile i+1 are loaded BEFORE the MFMA loop of tile i:
+    // a block keeps WPF 16-byte pieces of the wide tile and TPF thin pixels in flight while it computes (a load-store loop with one
+    // piece per trip had ~16 KB per CU in flight, i.e. ~1.3 TB/s of the ~5 the HBM delivers).  Host: TH * TW <= 256, BH * BW <= 1280.
+    constexpr int WPF = 8, TPF = 5;
+    f32x4 wv[WPF];
+    float tv[TPF][TC];
+    unsigned wok = 0;  // bit u: piece u of the wide tile lies inside the image (padding stays exactly zero under a fused transform)
+    const int q = t & 7;
+    auto fetch = [&](int tile) {
         int b = tile;
         const int tw = b % tiles_w;
         b /= tiles_w;
         const int th = b % tiles_h, img = b / tiles_h;
         const int y0 = th * TH, x0 = tw * TW;
-        __syncthreads();  // the previous tile's readers are done
-        {
-            const float* Wb = Wide + (long)img * Hw * Ww * Cw + c0;
-            const int q = t & 7;
-            for (int pix = t >> 3; pix < npix + 1; pix += 32) {
-                const int py = pix / TW, px = pix - py * TW;
-                const int y = y0 + py, x = x0 + px;
-                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (pix < npix && y < Hw && x < Ww) {
-                    v = *reinterpret_cast<const f32x4*>(Wb + ((long)y * Ww + x) * Cw + q * 4);
-                    if (nrm.scale)
-                        v = norm_apply(v, *reinterpret_cast<const f32x4*>(nrm.scale + c0 + q * 4),
-                                       *reinterpret_cast<const f32x4*>(nrm.shift + c0 + q * 4), nrm.slope);
-                }
-                *reinterpret_cast<f32x4*>(wideT + pix * 32 + q * 4) = v;
-            }
-            const float* Tb = Thin + (long)img * Ht * Wt * TC;
-            const int ty0 = REV ? y0 + pad - (KH - 1) : y0 * stride - pad, tx0 = REV ? x0 + pad - (KW - 1) : x0 * stride - pad;
-            for (int pix = t; pix < BH * BW; pix += 256) {
-                const int r = pix / BW, c = pix - r * BW;
-                const int y = ty0 + r, x = tx0 + c;
-                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (y >= 0 && y < Ht && x >= 0 && x < Wt) {
-                    const float* src = Tb + ((long)y * Wt + x) * TC;
+        const float* Wb = Wide + (long)img * Hw * Ww * Cw + c0 + q * 4;
+        wok = 0;
 #pragma unroll
-                    for (int j = 0; j < TC; ++j) v[j] = src[j];
-                }
-                *reinterpret_cast<f32x4*>(thinF + pix * 4) = v;
-            }
+        for (int u = 0; u < WPF; ++u) {
+            const int pix = (t >> 3) + 32 * u;
+            const int py = fdiv(pix, fd_tw), px = pix - py * TW;
+            const int y = y0 + py, x = x0 + px;
+            const bool ok = pix < npix && y < Hw && x < Ww;
+            wv[u] = ok ? *reinterpret_cast<const f32x4*>(Wb + ((long)y * Ww + x) * Cw) : f32x4{0.f, 0.f, 0.f, 0.f};
+            wok |= ok ? 1u << u : 0u;
         }
-        __syncthreads();
-        // this lane's pixel of the wave's first pair; every iteration moves on by 8 pixels (4 waves x 2)
-        int p = 2 * wave + half;
-        int py = p / TW, px = p - py * TW;
-        for (; p - half < npix; p += 8) {  // (p - half: both halves of a wave leave the loop together)
-            const int pc = p < npix ? p : npix;  // past the tile: the zero pixel
-            const float a = wideT[pc * 32 + l31];
-            const int base = p < npix ? ((py * step) * BW + px * step) * 4 : 0;
+        const float* Tb = Thin + (long)img * Ht * Wt * TC;
+        const int ty0 = REV ? y0 + pad - (KH - 1) : y0 * stride - pad, tx0 = REV ? x0 + pad - (KW - 1) : x0 * stride - pad;
 #pragma unroll
-            for (int u = 0; u < NT; ++u) {
-                const float bv = thinF[base + delta[u]] * keep[u];
-                acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[u], 0, 0, 0);
+        for (int u = 0; u < TPF; ++u) {
+            const int pix = t + 256 * u;
+            const int r = fdiv(pix, fd_bw), c = pix - r * BW;
+            const int y = ty0 + r, x = tx0 + c;
+            const bool ok = pix < BH * BW && y >= 0 && y < Ht && x >= 0 && x < Wt;
+            const float* src = Tb + ((long)y * Wt + x) * TC;
+#pragma unroll
+            for (int j = 0; j < TC; ++j) tv[u][j] = ok ? src[j] : 0.f;
+        }
+    };
+    f32x4 nsc = f32x4{1.f, 1.f, 1.f, 1.f}, nsh = f32x4{0.f, 0.f, 0.f, 0.f};  // this thread's channel quad under a fused input transform
+    if (nrm.scale) {
+        nsc = *reinterpret_cast<const f32x4*>(nrm.scale + c0 + q * 4);
+        nsh = *reinterpret_cast<const f32x4*>(nrm.shift + c0 + q * 4);
+    }
+    if (t < 8) *reinterpret_cast<f32x4*>(wideT + npix * 32 + t * 4) = f32x4{0.f, 0.f, 0.f, 0.f};  // the zero pixel behind the tile
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+    // persistent: the block walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and keeps ONE accumulator set -- one fold, one slab
+    // row and one reduce input per block instead of per tile (the per-tile epilogue and the 8192-slab reduce were the cost)
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();  // the previous tile's readers are done
+#pragma unroll
+        for (int u = 0; u < WPF; ++u) {
+            const int pix = (t >> 3) + 32 * u;
+            f32x4 v = wv[u];
+            if (nrm.scale && (wok >> u & 1)) v = norm_apply(v, nsc, nsh, nrm.slope);
+            if (pix < npix) *reinterpret_cast<f32x4*>(wideT + pix * 32 + q * 4) = v;
+        }
+#pragma unroll
+        for (int u = 0; u < TPF; ++u) {
+            const int pix = t + 256 * u;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < TC; ++j) v[j] = tv[u][j];
+            if (pix < BH * BW) *reinterpret_cast<f32x4*>(thinF + pix * 4) = v;
+        }
+        if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);  // in flight under this tile's MFMA loop
+        __syncthreads();
+        // this lane's pixel of the wave's first pair; every step moves on by 8 pixels (4 waves x 2).
+        // Host: tile width a power of two, tile a multiple of 32 pixels.  Four pairs per trip -- their 4 * (1 + NT) LDS reads go out back
+        // to back ahead of the 4 * NT MFMAs, addresses by shift / mask / 24-bit multiply-add.  (One pair per trip with a wrap loop for
+        // the row change spent ~500 cycles of issue and LDS latency per 64-cycle MFMA.)
+        for (int p = 2 * wave + half; p < npix; p += 32) {
+            float a[4], bv[4][NT];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int pk = p + 8 * k;
+                a[k] = wideT[pk * 32 + l31];
+                const int base = __mul24(__mul24(pk >> tw_shift, step), BW) + __mul24(pk & (TW - 1), step);
+#pragma unroll
+                for (int u = 0; u < NT; ++u) bv[k][u] = thinF[base * 4 + delta[u]] * keep[u];
             }
-            px += 8;
-            while (px >= TW) px -= TW, ++py;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], bv[k][u], acc[u], 0, 0, 0);
         }
     }
     // fold the four waves through LDS (the wide tile is dead), then this block's slab row
@@ -733,7 +792,7 @@ int launch_thin_in(const float* X, const float* W, float* Y, const Geom& g, cons
     if (g.Nn > 32) {
         dim3 grid(ceil_div(M, 256), ceil_div(g.Nn, 64));
         hipLaunchKernelGGL((thin_in_k<64, BWD>), grid, dim3(256), (size_t)K * 64 * sizeof(float), st, X, W, ep.bias, Y, g, M,
-                           ep.act, ep.slope, (float*)nullptr, BnBwd{});
+                           ep.act, ep.slope, (float*)nullptr, BnBwd{}, ActMul{nullptr, 0, 0.f, 0, 0, nullptr});
     } else {
         dim3 grid(ceil_div(M, 256), 1);
         size_t lds_floats = (size_t)K * 32;
@@ -747,8 +806,16 @@ int launch_thin_in(const float* X, const float* W, float* Y, const Geom& g, cons
             if (float* part = fuse_bn_claim(rpg / 256 * 4, 32))
                 bb = BnBwd{g_fuse.bn_y, g_fuse.bn_scale, g_fuse.bn_shift, g_fuse.bn_slope, part, (int)rpg, (int)(rpg / 256 * 4)};
         }
+        // the previous layer's activation derivative / a residual block's identity cotangent on the result (32-output tile only)
+        ActMul am{nullptr, 0, 0.f, 0, 0, nullptr};
+        if ((g_fuse.am.y || g_fuse.am.res) && g.Nn == 32 && ep.act == MOVAE_ACT_NONE && (!ep.bias || !g_fuse.am.y) && !bb.y && !stats &&
+            M % g_fuse.am_groups == 0 && (reinterpret_cast<uintptr_t>(Y) & 15) == 0) {
+            am = g_fuse.am;
+            am.per_group = (long)(M / g_fuse.am_groups) * 32;
+            g_fuse.am_done = true;
+        }
         hipLaunchKernelGGL((thin_in_k<32, BWD>), grid, dim3(256), lds_floats * sizeof(float), st, X, W, ep.bias, Y, g, M,
-                           ep.act, ep.slope, stats, bb);
+                           ep.act, ep.slope, stats, bb, am);
     }
     MOVAE_CHECK_LAUNCH("thin_in");
     return MOVAE_OK;
@@ -850,8 +917,10 @@ int launch_thin_wgrad_impl(const float* S, const float* Bg, float* const* dW, in
             int TH = tile_px / TW;
             if (TH < 1) TH = 1;
             if (TH > Hw) TH = Hw;
+            const int TH0 = TH;
             const int taps = g.KH * g.KW, na = taps * 3;
-            static const bool use_mfma = !getenv("MOVAE_THIN_WGRAD_SWEEP");  // (A/B knob: the VALU sweep kernel)
+            static const bool mfma_env = !getenv("MOVAE_THIN_WGRAD_SWEEP");  // (A/B knob: the VALU sweep kernel)
+            bool use_mfma = mfma_env;
             auto lds_bytes = [&](int th, int tw) {
                 const int bh = thin_small ? th + g.KH - 1 : (th - 1) * g.stride + g.KH;
                 const int bw = thin_small ? tw + g.KW - 1 : (tw - 1) * g.stride + g.KW;
@@ -860,11 +929,22 @@ int launch_thin_wgrad_impl(const float* S, const float* Bg, float* const* dW, in
                 const long wide_f = tile_f > fold_f ? tile_f : fold_f;
                 return (wide_f + (long)bh * bw * 4) * 4;
             };
-            while (lds_bytes(TH, TW) > 60 * 1024 && TH > 1) TH = (TH + 1) / 2;
+            // the MFMA kernel prefetches a tile into registers: <= 256 wide pixels (8 pieces per thread), <= 1280 thin pixels (5 per thread)
+            auto thin_px = [&](int th, int tw) {
+                return (thin_small ? th + g.KH - 1 : (th - 1) * g.stride + g.KH) * (thin_small ? tw + g.KW - 1 : (tw - 1) * g.stride + g.KW);
+            };
+            while ((lds_bytes(TH, TW) > 60 * 1024 || (use_mfma && (TH * TW > 256 || thin_px(TH, TW) > 1280))) && TH > 1) TH = (TH + 1) / 2;
+            // ... and steps through it with shifts: tile width a power of two, tile a multiple of 32 pixels; the VALU sweep kernel otherwise
+            if (use_mfma && !(TH * TW <= 256 && thin_px(TH, TW) <= 1280 && (TW & (TW - 1)) == 0 && (TH * TW) % 32 == 0)) {
+                use_mfma = false;
+                TH = TH0;
+                while (lds_bytes(TH, TW) > 60 * 1024 && TH > 1) TH = (TH + 1) / 2;
+            }
             const int tiles_h = ceil_div(Hw, TH), tiles_w = ceil_div(Ww, TW);
             const long ntiles = (long)g.Nimg * tiles_h * tiles_w;
             // MFMA kernel: persistent blocks (one slab row each), about four per CU and (wide slice, group)
-            static const int persist = getenv("MOVAE_THIN_PERSIST") ? atoi(getenv("MOVAE_THIN_PERSIST")) : 1024;
+            // (three blocks of the MFMA kernel fit a CU -- 136 VGPRs + 16 accumulators per lane: 768 persistent blocks fill the chip once)
+            static const int persist = getenv("MOVAE_THIN_PERSIST") ? atoi(getenv("MOVAE_THIN_PERSIST")) : 768;
             long nblk = ntiles;
             if (use_mfma) {
                 const long cap = persist / ((long)(wide / 32) * G) > 64 ? persist / ((long)(wide / 32) * G) : 64;
@@ -893,7 +973,8 @@ int launch_thin_wgrad_impl(const float* S, const float* Bg, float* const* dW, in
                        g.pad, TH, TW, tiles_h, tiles_w, g.Cs, g.Cb, wide_gs, thin_gs, slab_gs, wide_nrm)
 #define MOVAE_MF(K, REVV)                                                                                                      \
     hipLaunchKernelGGL((thin_wgrad_mfma_k<3, K, K, REVV>), grid, dim3(256), shb, st, Wd, Tn, slab, Hw, Ww, wide, Ht, Wt, g.stride, \
-                       g.pad, TH, TW, tiles_h, tiles_w, g.Cs, g.Cb, wide_gs, thin_gs, slab_gs, wide_nrm, (int)ntiles)
+                       g.pad, TH, TW, tiles_h, tiles_w, g.Cs, g.Cb, wide_gs, thin_gs, slab_gs, wide_nrm, (int)ntiles, fastdiv_make(TW),    \
+                       fastdiv_make(thin_small ? TW + g.KW - 1 : (TW - 1) * g.stride + g.KW))
                 if (use_mfma) {
                     if (thin_small) {
                         if (k33) MOVAE_MF(3, true); else MOVAE_MF(4, true);

@@ -52,7 +52,7 @@ class BetaTCVAE(HotPathModel):
 
     def decode(self, z):
         h = ops.unflatten_nchw(self.decoder_input(z), self.hidden_dims[-1], self._sp, self._sp)
-        return nchw_view(self.final_layer(self.decoder(h)))
+        return nchw_view(mnn.chain(h, self.decoder, self.final_layer))
 
     graph_safe = True
     _iter_dev = None

@@ -221,6 +221,17 @@ class Stack(tnn.Sequential):
         return x
 
 
+def chain(x, *stacks):
+    """stacks[-1](... stacks[0](x)) for Stacks that a model keeps as separate attributes (decoder -> final_layer): the activation
+    link of each Stack's output is handed to the next one, as an enclosing Stack would.  Each intermediate result must have no other
+    reader (ops.ActLink)."""
+    link = None
+    for s in stacks:
+        x = s(x, link)
+        link, s._out_link = s._out_link, None
+    return x
+
+
 class Codebook(tnn.Module):
     """nn.Embedding(K, D) drawn like models/vq_vae.py:24-25 (normal_ first, then uniform(-1/K, 1/K))."""
 

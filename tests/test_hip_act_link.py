@@ -26,6 +26,10 @@ CHAINS = [
     ("wide", 16, 16, [("conv", 64, 128, 3, 1, 1, 0, "relu"), ("conv", 128, 128, 3, 1, 1, 0, "lrelu"), ("convT", 128, 64, 4, 2, 1, 0, None)], False),
     # consumer without the epilogue (3-channel thin kernel): the producer runs its own activation backward
     ("thin_consumer", 4, 16, [("conv", 16, 16, 3, 1, 1, 0, "lrelu"), ("conv", 16, 3, 3, 1, 1, 0, None)], False),
+    # ... except the 32-channel form of that kernel (last layers of the VAE / BetaTC-VAE decoders), whose output tile passes through LDS
+    ("thin_consumer32", 4, 16, [("convT", 16, 32, 3, 2, 1, 1, "lrelu"), ("conv", 32, 3, 3, 1, 1, 0, None)], False),
+    # Stacks held as separate attributes, run through nn.chain (BetaTC-VAE: decoder -> final_layer)
+    ("chained", 4, 8, [("convT", 32, 32, 3, 2, 1, 1, "lrelu"), ("convT", 32, 32, 3, 2, 1, 1, "lrelu"), ("conv", 32, 3, 3, 1, 1, 0, None)], "chain"),
 ]
 
 
@@ -38,6 +42,18 @@ def _build(spec, nested):
         layer = [conv] + ([mnn.LeakyReLU() if act == "lrelu" else mnn.ReLU()] if act else [])
         groups.append(layer)
         mods.extend(layer)
+    if nested == "chain":  # first layer | the rest, joined by nn.chain
+        a, b = mnn.Stack(mnn.Stack(*groups[0])), mnn.Stack(*[m for g in groups[1:] for m in g])
+
+        class Chained(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.a, self.b = a, b
+
+            def forward(self, x):
+                return mnn.chain(x, self.a, self.b)
+
+        return Chained(), [g[0] for g in groups]
     return (mnn.Stack(*[mnn.Stack(*g) for g in groups]) if nested else mnn.Stack(*mods)), [g[0] for g in groups]
 
 
