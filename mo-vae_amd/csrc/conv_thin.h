@@ -14,6 +14,92 @@
 
 namespace thin {
 
+// Output side of the 32-output thin-input kernels: the block's 256 pixels x 32 outputs sit in LDS as Wl[pixel * 33 + n] (activation
+// applied) and are one contiguous 32 KiB run of Y.  BatchNorm statistics / backward sums of the tile, the ActMul factor, then stores of
+// 1 KiB per wave instead of 64 scattered 16-byte pieces.
+__device__ __forceinline__ void thin_in_tile_out(float* __restrict__ Wl, float* __restrict__ Y, int M, int t, float* __restrict__ stats,
+                                                 const BnBwd& bb, const ActMul& am) {
+    float* yb = Y + (long)blockIdx.x * 256 * 32;
+    const long rows_left = (long)M - (long)blockIdx.x * 256;
+    if (stats) {
+        // column statistics of the block's 256 x 32 tile for the BatchNorm that follows (the tile sits in LDS anyway):
+        // thread t sums channel t & 31 over rows 32 * (t >> 5) ..+31 (stride 33: conflict-free), the two row groups of a
+        // wave fold with one shuffle; one partial pair per wave: stats[((4 * block + wave) * 2 + {0,1}) * 32 + c]
+        const int c = t & 31, r0 = (t >> 5) * 32;
+        float sm = 0.f, sq = 0.f;
+        for (int r = 0; r < 32; ++r)
+            if (r0 + r < rows_left) {
+                const float v = Wl[(r0 + r) * 33 + c];
+                sm += v;
+                sq = fmaf(v, v, sq);
+            }
+        sm += __shfl_xor(sm, 32, 64);
+        sq += __shfl_xor(sq, 32, 64);
+        if ((t & 63) < 32) {
+            const long pidx = (long)blockIdx.x * 4 + (t >> 6);
+            stats[(pidx * 2 + 0) * 32 + c] = sm;
+            stats[(pidx * 2 + 1) * 32 + c] = sq;
+        }
+    }
+    if (bb.y) {
+        // the tile is `dout` of a fused BatchNorm over y (same shape as Y): its backward sums, same thread mapping; a
+        // block's 256 rows never straddle two cotangent groups (host).  Each load instruction covers two whole 128-byte rows.
+        const int c = t & 31, r0 = (t >> 5) * 32;
+        const float sc = bb.scale[c], sh_ = bb.shift[c];
+        const float* yb_ = bb.y + ((long)blockIdx.x * 256 % bb.rows_per_group) * 32;
+        float s1 = 0.f, s2 = 0.f;
+        for (int r = 0; r < 32; ++r)
+            if (r0 + r < rows_left) {
+                const float yv = yb_[(r0 + r) * 32 + c];
+                const float z = fmaf(yv, sc, sh_);
+                const float d = Wl[(r0 + r) * 33 + c] * (z > 0.f ? 1.f : bb.slope);
+                s1 += d;
+                s2 = fmaf(d, yv, s2);
+            }
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if ((t & 63) < 32) {
+            const long pidx = (long)blockIdx.x * 4 + (t >> 6);
+            bb.part[(pidx * 2 + 0) * 32 + c] = s1;
+            bb.part[(pidx * 2 + 1) * 32 + c] = s2;
+        }
+    }
+    if (actmul_on(am)) {
+        // the result is the cotangent of an activation output / a residual block's branch (ActMul): factor act'(y) and the
+        // identity cotangent on the way out, 16-byte pieces, all loads of a thread ahead of its stores
+        f32x4 y4[8], r4[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = i * 256 + t, px = idx >> 3, q = idx & 7;
+            const long o = ((long)blockIdx.x * 256 + px) * 32 + q * 4;
+            const bool ok = px < rows_left;
+            y4[i] = (ok && am.y) ? *reinterpret_cast<const f32x4*>(am.y + o % am.per_group) : f32x4{0.f, 0.f, 0.f, 0.f};
+            r4[i] = (ok && am.res) ? *reinterpret_cast<const f32x4*>(am.res + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = i * 256 + t, px = idx >> 3, q = idx & 7;
+            if (px < rows_left) {
+                const float* src = Wl + px * 33 + q * 4;
+                f32x4 o4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    o4[e] = src[e] * (am.y ? act_grad_from_out(y4[i][e], am.act, am.slope) : 1.f) + r4[i][e];
+                *reinterpret_cast<f32x4*>(yb + px * 32 + q * 4) = o4;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = i * 256 + t, px = idx >> 3, q = idx & 7;
+        if (px < rows_left) {
+            const float* src = Wl + px * 33 + q * 4;
+            *reinterpret_cast<f32x4*>(yb + px * 32 + q * 4) = f32x4{src[0], src[1], src[2], src[3]};
+        }
+    }
+}
+
 // ---- thin reduction side ---------------------------------------------------------------------------
 template <int NN, bool BWD>
 __global__ __launch_bounds__(256) void thin_in_k(const float* __restrict__ X, const float* __restrict__ W,
@@ -81,85 +167,7 @@ __global__ __launch_bounds__(256) void thin_in_k(const float* __restrict__ X, co
 #pragma unroll
         for (int n = 0; n < NN; ++n) Wl[t * 33 + n] = apply_act(acc[n], act, slope);
         __syncthreads();
-        float* yb = Y + (long)blockIdx.x * 256 * 32;
-        const long rows_left = (long)M - (long)blockIdx.x * 256;
-        if (stats) {
-            // column statistics of the block's 256 x 32 tile for the BatchNorm that follows (the tile sits in LDS anyway):
-            // thread t sums channel t & 31 over rows 32 * (t >> 5) ..+31 (stride 33: conflict-free), the two row groups of a
-            // wave fold with one shuffle; one partial pair per wave: stats[((4 * block + wave) * 2 + {0,1}) * 32 + c]
-            const int c = t & 31, r0 = (t >> 5) * 32;
-            float sm = 0.f, sq = 0.f;
-            for (int r = 0; r < 32; ++r)
-                if (r0 + r < rows_left) {
-                    const float v = Wl[(r0 + r) * 33 + c];
-                    sm += v;
-                    sq = fmaf(v, v, sq);
-                }
-            sm += __shfl_xor(sm, 32, 64);
-            sq += __shfl_xor(sq, 32, 64);
-            if ((t & 63) < 32) {
-                const long pidx = (long)blockIdx.x * 4 + (t >> 6);
-                stats[(pidx * 2 + 0) * 32 + c] = sm;
-                stats[(pidx * 2 + 1) * 32 + c] = sq;
-            }
-        }
-        if (bb.y) {
-            // the tile is `dout` of a fused BatchNorm over y (same shape as Y): its backward sums, same thread mapping; a
-            // block's 256 rows never straddle two cotangent groups (host).  Each load instruction covers two whole 128-byte rows.
-            const int c = t & 31, r0 = (t >> 5) * 32;
-            const float sc = bb.scale[c], sh_ = bb.shift[c];
-            const float* yb_ = bb.y + ((long)blockIdx.x * 256 % bb.rows_per_group) * 32;
-            float s1 = 0.f, s2 = 0.f;
-            for (int r = 0; r < 32; ++r)
-                if (r0 + r < rows_left) {
-                    const float yv = yb_[(r0 + r) * 32 + c];
-                    const float z = fmaf(yv, sc, sh_);
-                    const float d = Wl[(r0 + r) * 33 + c] * (z > 0.f ? 1.f : bb.slope);
-                    s1 += d;
-                    s2 = fmaf(d, yv, s2);
-                }
-            s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 32, 64);
-            if ((t & 63) < 32) {
-                const long pidx = (long)blockIdx.x * 4 + (t >> 6);
-                bb.part[(pidx * 2 + 0) * 32 + c] = s1;
-                bb.part[(pidx * 2 + 1) * 32 + c] = s2;
-            }
-        }
-        if (actmul_on(am)) {
-            // the result is the cotangent of an activation output / a residual block's branch (ActMul): factor act'(y) and the
-            // identity cotangent on the way out, 16-byte pieces, all loads of a thread ahead of its stores
-            f32x4 y4[8], r4[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int idx = i * 256 + t, px = idx >> 3, q = idx & 7;
-                const long o = ((long)blockIdx.x * 256 + px) * 32 + q * 4;
-                const bool ok = px < rows_left;
-                y4[i] = (ok && am.y) ? *reinterpret_cast<const f32x4*>(am.y + o % am.per_group) : f32x4{0.f, 0.f, 0.f, 0.f};
-                r4[i] = (ok && am.res) ? *reinterpret_cast<const f32x4*>(am.res + o) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int idx = i * 256 + t, px = idx >> 3, q = idx & 7;
-                if (px < rows_left) {
-                    const float* src = Wl + px * 33 + q * 4;
-                    f32x4 o4;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        o4[e] = src[e] * (am.y ? act_grad_from_out(y4[i][e], am.act, am.slope) : 1.f) + r4[i][e];
-                    *reinterpret_cast<f32x4*>(yb + px * 32 + q * 4) = o4;
-                }
-            }
-            return;
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int idx = i * 256 + t, px = idx >> 3, q = idx & 7;
-            if (px < rows_left) {
-                const float* src = Wl + px * 33 + q * 4;
-                *reinterpret_cast<f32x4*>(yb + px * 32 + q * 4) = f32x4{src[0], src[1], src[2], src[3]};
-            }
-        }
+        thin_in_tile_out(Wl, Y, M, t, stats, bb, am);
         return;
     }
     if (!live) return;
@@ -177,6 +185,105 @@ __global__ __launch_bounds__(256) void thin_in_k(const float* __restrict__ X, co
         for (int n = 0; n < NN; ++n)
             if (n0 + n < N) yo[n] = apply_act(acc[n], act, slope);
     }
+}
+
+// ---- thin reduction side on the MFMA pipe (3 reduction channels, 32 outputs) ------------------------------------
+// thin_in_k is bound by the LDS return bandwidth of its broadcast weight reads (one ds_read_b128 per four FMAs: 47 us of LDS time
+// for the first layer of C5, measured 50).  As a GEMM the layer is out[pixel][n] = sum_k patch[pixel][k] * W[k][n] with K = taps * 3
+// = 27 / 48: a v_mfma_f32_32x32x2_f32 step takes two k for 32 pixels, with B = W[2j + half][n = lane & 31] held in registers for the
+// whole block and A = one ds_read_b32 per lane from the block's input region, staged in LDS as a plain copy of the image rows
+// (3 floats per pixel: lanes are consecutive pixels, stride 3 or 6 floats): address = pixel corner + a lane-half constant per step.
+// ~30x less LDS traffic than the VALU form; K / 2 MFMAs per 32 pixels.  A block owns 256 consecutive output pixels of one image --
+// whole rows or a row segment (host) -- and leaves through thin_in_tile_out like thin_in_k.  BWD: stride 1 only.
+template <int KH, int KW, bool BWD>
+__global__ __launch_bounds__(256) void thin_in_mfma_k(const float* __restrict__ X, const float* __restrict__ W,
+                                                      const float* __restrict__ bias, float* __restrict__ Y, Geom g, int M, int act,
+                                                      float slope, float* __restrict__ stats, BnBwd bb, ActMul am, int ncols, int RH,
+                                                      int RW, FastDiv fd_row, FastDiv fd3, FastDiv fd_ncols, FastDiv fd_hw, FastDiv fd_wo) {
+    constexpr int TC = 3, TAPS = KH * KW, K = TAPS * TC, KS = (K + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) float Wl[];  // input region [RH][RW * 3], then the output tile [256][33]
+    const int t = threadIdx.x, lane = t & 63, half = lane >> 5, l31 = lane & 31, wave = t >> 6;
+    const int p0 = blockIdx.x * 256, hw = g.Ho * g.Wo;
+    const int img = fdiv(p0, fd_hw), rem = p0 - img * hw;
+    const int ho0 = fdiv(rem, fd_wo), wo0 = rem - ho0 * g.Wo;
+    const int s = g.stride;
+    const int ih0 = BWD ? ho0 + g.pad - (KH - 1) : ho0 * s - g.pad, iw0 = BWD ? wo0 + g.pad - (KW - 1) : wo0 * s - g.pad;
+    constexpr int KP = K | 1;  // odd LDS row pitch of the staged weights: lanes are outputs, conflict-free
+    float bw[KS];  // B operand: W[k = 2j + half][n = lane & 31]
+    if (BWD) {     // W[c][tap][n]: the lanes of a load are neighbours in memory
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            const int k = 2 * j + half, kk = k < K ? k : K - 1;
+            const int tap = kk / TC, c = kk - tap * TC;
+            const float w = W[((long)c * TAPS + tap) * 32 + l31];
+            bw[j] = k < K ? w : 0.f;
+        }
+    }
+    float* Ww = Wl + RH * RW * 3;  // FWD: [32][KP] copy of W[n][tap][c] (the lanes' own rows lie 4 * K bytes apart in memory)
+    {   // the region: rows ih0 .. ih0 + RH - 1, columns iw0 .. iw0 + RW - 1 of image img, zero outside; nine loads in flight per thread
+        const float* Xb = X + (long)img * g.Hi * g.Wi * TC;
+        const int row_f = RW * 3, total = RH * row_f;
+        float wv[BWD ? 1 : (32 * K + 255) / 256];
+        if (!BWD) {
+#pragma unroll
+            for (int u = 0; u < (32 * K + 255) / 256; ++u) wv[u] = t + u * 256 < 32 * K ? W[t + u * 256] : 0.f;
+        }
+        for (int base = t; base < total; base += 9 * 256) {
+            float v[9];
+#pragma unroll
+            for (int u = 0; u < 9; ++u) {
+                const int f = base + u * 256;
+                const int r = fdiv(f, fd_row), o = f - r * row_f;
+                const int ih = ih0 + r, iw = iw0 + fdiv(o, fd3);
+                const bool ok = f < total && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi;
+                v[u] = ok ? Xb[((long)ih * g.Wi + iw0) * TC + o] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 9; ++u)
+                if (base + u * 256 < total) Wl[base + u * 256] = v[u];
+        }
+        if (!BWD) {
+#pragma unroll
+            for (int u = 0; u < (32 * K + 255) / 256; ++u) {
+                const int f = t + u * 256, n = f / K;
+                if (f < 32 * K) Ww[n * KP + f - n * K] = wv[u];
+            }
+        }
+    }
+    __syncthreads();
+    int dl[KS];
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+        const int k = 2 * j + half, kk = k < K ? k : K - 1;
+        const int tap = kk / TC, c = kk - tap * TC, kh = tap / KW, kw = tap - kh * KW;
+        if (!BWD) bw[j] = k < K ? Ww[l31 * KP + kk] : 0.f;
+        dl[j] = (BWD ? -(kh * RW + kw) : kh * RW + kw) * 3 + c;
+    }
+    f32x16 acc[2];
+    int cb[2];  // float offset of this lane's pixel corner in the region, per 32-pixel tile of the wave
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+        const int pix = wave * 64 + u * 32 + l31;
+        const int py = fdiv(pix, fd_ncols), px = pix - py * ncols;
+        cb[u] = BWD ? ((py + KH - 1) * RW + px + KW - 1) * 3 : (py * s * RW + px * s) * 3;
+    }
+#pragma unroll
+    for (int j = 0; j < KS; ++j)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(Wl[cb[u] + dl[j]], bw[j], acc[u], 0, 0, 0);
+    __syncthreads();  // the region is dead: the output tile takes its place
+    const float bv = bias ? bias[l31] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+            Wl[(wave * 64 + u * 32 + m) * 33 + l31] = apply_act(acc[u][r] + bv, act, slope);
+        }
+    __syncthreads();
+    thin_in_tile_out(Wl, Y, M, t, stats, bb, am);
 }
 
 // ---- thin output side (FWD gather) -----------------------------------------------------------------
@@ -813,6 +920,28 @@ int launch_thin_in(const float* X, const float* W, float* Y, const Geom& g, cons
             am = g_fuse.am;
             am.per_group = (long)(M / g_fuse.am_groups) * 32;
             g_fuse.am_done = true;
+        }
+        // MFMA form: 3 reduction channels, 32 outputs, 3x3 / 4x4 taps, blocks of whole rows or of a row segment of one image
+        static const bool valu_only = getenv("MOVAE_THIN_IN_VALU") != nullptr;  // (A/B knob)
+        const int hw = g.Ho * g.Wo;
+        const bool k33 = g.KH == 3 && g.KW == 3, k44 = g.KH == 4 && g.KW == 4;
+        if (!valu_only && g.Nn == 32 && g.Cr == 3 && (k33 || k44) && (!BWD || g.stride == 1) && hw % 256 == 0 &&
+            (256 % g.Wo == 0 || g.Wo % 256 == 0) && g.wrow == 0) {
+            const int ncols = g.Wo < 256 ? g.Wo : 256, nrows = 256 / ncols;
+            const int RH = BWD ? nrows + g.KH - 1 : (nrows - 1) * g.stride + g.KH;
+            const int RW = BWD ? ncols + g.KW - 1 : (ncols - 1) * g.stride + g.KW;
+            size_t lf = (size_t)RH * RW * 3 + (BWD ? 0 : 32 * (g.KH * g.KW * 3 | 1));
+            if (lf < 256 * 33) lf = 256 * 33;
+            if (lf * sizeof(float) <= 60 * 1024) {
+#define MOVAE_TI(K)                                                                                                                \
+    hipLaunchKernelGGL((thin_in_mfma_k<K, K, BWD>), grid, dim3(256), lf * sizeof(float), st, X, W, ep.bias, Y, g, M, ep.act, ep.slope,  \
+                       stats, bb, am, ncols, RH, RW, fastdiv_make(RW * 3), fastdiv_make(3), fastdiv_make(ncols), fastdiv_make(hw),  \
+                       fastdiv_make(g.Wo))
+                if (k33) MOVAE_TI(3); else MOVAE_TI(4);
+#undef MOVAE_TI
+                MOVAE_CHECK_LAUNCH("thin_in_mfma");
+                return MOVAE_OK;
+            }
         }
         hipLaunchKernelGGL((thin_in_k<32, BWD>), grid, dim3(256), lds_floats * sizeof(float), st, X, W, ep.bias, Y, g, M,
                            ep.act, ep.slope, stats, bb, am);
