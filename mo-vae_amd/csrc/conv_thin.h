@@ -17,8 +17,18 @@ namespace thin {
 // Output side of the 32-output thin-input kernels: the block's 256 pixels x 32 outputs sit in LDS as Wl[pixel * 33 + n] (activation
 // applied) and are one contiguous 32 KiB run of Y.  BatchNorm statistics / backward sums of the tile, the ActMul factor, then stores of
 // 1 KiB per wave instead of 64 scattered 16-byte pieces.
+// pre_y: the ActMul factor's source (am.y pieces of this thread, thin_in_am_y) loaded by the caller ahead of its compute phase.
+__device__ __forceinline__ void thin_in_am_y(const ActMul& am, int M, int t, f32x4 (&y4)[8]) {
+    const long rows_left = (long)M - (long)blockIdx.x * 256;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = i * 256 + t, px = idx >> 3, q = idx & 7;
+        const long o = ((long)blockIdx.x * 256 + px) * 32 + q * 4;
+        y4[i] = (px < rows_left && am.y) ? *reinterpret_cast<const f32x4*>(am.y + o % am.per_group) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
 __device__ __forceinline__ void thin_in_tile_out(float* __restrict__ Wl, float* __restrict__ Y, int M, int t, float* __restrict__ stats,
-                                                 const BnBwd& bb, const ActMul& am) {
+                                                 const BnBwd& bb, const ActMul& am, const f32x4 (*pre_y)[8] = nullptr) {
     float* yb = Y + (long)blockIdx.x * 256 * 32;
     const long rows_left = (long)M - (long)blockIdx.x * 256;
     if (stats) {
@@ -68,13 +78,17 @@ __device__ __forceinline__ void thin_in_tile_out(float* __restrict__ Wl, float* 
         // the result is the cotangent of an activation output / a residual block's branch (ActMul): factor act'(y) and the
         // identity cotangent on the way out, 16-byte pieces, all loads of a thread ahead of its stores
         f32x4 y4[8], r4[8];
+        if (pre_y) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) y4[i] = (*pre_y)[i];
+        } else {
+            thin_in_am_y(am, M, t, y4);
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int idx = i * 256 + t, px = idx >> 3, q = idx & 7;
             const long o = ((long)blockIdx.x * 256 + px) * 32 + q * 4;
-            const bool ok = px < rows_left;
-            y4[i] = (ok && am.y) ? *reinterpret_cast<const f32x4*>(am.y + o % am.per_group) : f32x4{0.f, 0.f, 0.f, 0.f};
-            r4[i] = (ok && am.res) ? *reinterpret_cast<const f32x4*>(am.res + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+            r4[i] = (px < rows_left && am.res) ? *reinterpret_cast<const f32x4*>(am.res + o) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -209,6 +223,8 @@ __global__ __launch_bounds__(256) void thin_in_mfma_k(const float* __restrict__ 
     const int s = g.stride;
     const int ih0 = BWD ? ho0 + g.pad - (KH - 1) : ho0 * s - g.pad, iw0 = BWD ? wo0 + g.pad - (KW - 1) : wo0 * s - g.pad;
     constexpr int KP = K | 1;  // odd LDS row pitch of the staged weights: lanes are outputs, conflict-free
+    f32x4 y4[8];   // ActMul: the activation output this block's result is multiplied by act'(.) of -- in flight under staging and MFMAs
+    if (am.y) thin_in_am_y(am, M, t, y4);
     float bw[KS];  // B operand: W[k = 2j + half][n = lane & 31]
     if (BWD) {     // W[c][tap][n]: the lanes of a load are neighbours in memory
 #pragma unroll
@@ -283,7 +299,7 @@ __global__ __launch_bounds__(256) void thin_in_mfma_k(const float* __restrict__ 
             Wl[(wave * 64 + u * 32 + m) * 33 + l31] = apply_act(acc[u][r] + bv, act, slope);
         }
     __syncthreads();
-    thin_in_tile_out(Wl, Y, M, t, stats, bb, am);
+    thin_in_tile_out(Wl, Y, M, t, stats, bb, am, am.y ? &y4 : nullptr);
 }
 
 // ---- thin output side (FWD gather) -----------------------------------------------------------------
@@ -490,6 +506,130 @@ __global__ __launch_bounds__(256) void thin_out_tile_k(const float* __restrict__
             for (int n = 0; n < 4; ++n)
                 if (n < N) yo[n] = apply_act(acc[u][n] + (bias ? bias[n] : 0.f), act, slope);
         }
+    }
+}
+
+// ---- thin output side on the MFMA pipe (3 outputs, stride-1 KH x KW conv, reduction channels a multiple of 32) ----------------
+// thin_out_tile_k is bound by the LDS return bandwidth of its operand reads (weights as broadcast ds_read_b128, 5 reads per 24 FMAs:
+// ~88 us of LDS time for the last conv of C5, measured 153).  The same arithmetic as a GEMM over INPUT pixels,
+//   P[q][tap * 3 + co] = sum_c X[q][c] * W[co][tap][c]                       (M = input pixels, K = Cr, N = taps * 3 = 27 <= 32)
+// followed by out[y][x][co] = sum_tap P[(y - pad + kh, x - pad + kw)][tap * 3 + co]: the big operand goes from global memory straight
+// into the A registers of v_mfma_f32_32x32x2_f32 (lane = input pixel, its half of the 32-channel chunk as four 16-byte loads; step j
+// pairs channel j of the lower half with channel 16 + j of the upper one, B = the weights under the same pairing), P passes through
+// LDS once (27 floats per input pixel) and every output pixel gathers its 27 terms: ~10x less LDS traffic.  A block owns an 8 x 32
+// output tile and computes P for the tile's (8 + KH - 1) x (32 + KW - 1) input pixels in 32-pixel groups dealt to its four waves.
+template <int KH, int KW, bool ONE>  // ONE: 32 reduction channels (a single chunk)
+__global__ __launch_bounds__(256) void thin_out_mfma_k(const float* __restrict__ X, const float* __restrict__ W,
+                                                       const float* __restrict__ bias, float* __restrict__ Y, Geom g, int tiles_h,
+                                                       int tiles_w, int act, float slope, Norm nrm) {
+    constexpr int TH = 8, TW = 32, RH = TH + KH - 1, RW = TW + KW - 1, NPX = RH * RW, NG = (NPX + 31) / 32;
+    constexpr int TAPS = KH * KW, NC = TAPS * 3, PS = NC | 1;  // odd pitch: the gather's lanes are consecutive input pixels
+    static_assert(NC <= 32, "taps * 3 columns in one MFMA tile");
+    extern __shared__ __attribute__((aligned(16))) float Pl[];  // [NG * 32][PS]
+    const int t = threadIdx.x, lane = t & 63, half = lane >> 5, l31 = lane & 31, wave = t >> 6;
+    int b = blockIdx.x;
+    const int tw = b % tiles_w;
+    b /= tiles_w;
+    const int th = b % tiles_h, img = b / tiles_h;
+    const int y0 = th * TH, x0 = tw * TW;
+    const float* Xb = X + (long)img * g.Hi * g.Wi * g.Cr + 16 * half;
+    // this lane's weight row: column n = l31 -> (tap, co); W[co][tap][c]
+    const int ntap = l31 / 3, nco = l31 - ntap * 3;
+    const float* Wn = W + ((long)nco * TAPS + ntap) * g.Cr + 16 * half;
+    const bool ncol = l31 < NC;
+    if (ONE) {
+        // one chunk: the wave's (up to) three groups are loaded back to back before the first MFMA -- one memory latency per block
+        // instead of one per group -- and share the weight registers
+        constexpr int GW = (NG + 3) / 4;
+        f32x4 a[GW][4], bw[4];
+        bool ok[GW];
+#pragma unroll
+        for (int u = 0; u < GW; ++u) {
+            const int ri = (wave + 4 * u) * 32 + l31;
+            const int ry = ri / RW, rx = ri - ry * RW;
+            const int iy = y0 - g.pad + ry, ix = x0 - g.pad + rx;
+            ok[u] = wave + 4 * u < NG && ri < NPX && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi;
+            const float* xp = Xb + ((long)iy * g.Wi + ix) * g.Cr;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[u][i] = ok[u] ? *reinterpret_cast<const f32x4*>(xp + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bw[i] = ncol ? *reinterpret_cast<const f32x4*>(Wn + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < GW; ++u) {
+            const int grp = wave + 4 * u;
+            if (grp >= NG) break;
+            if (nrm.scale) {  // virtual input (fused BatchNorm + activation of the producer); padding stays exactly zero
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    a[u][i] = norm_apply_if(ok[u], a[u][i], *reinterpret_cast<const f32x4*>(nrm.scale + 16 * half + 4 * i),
+                                            *reinterpret_cast<const f32x4*>(nrm.shift + 16 * half + 4 * i), nrm.slope);
+            }
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i][e], bw[i][e], acc, 0, 0, 0);
+            if (ncol) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Pl[(grp * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * PS + l31] = acc[r];
+            }
+        }
+    }
+    // (Several chunks: loading the operands of the next item ahead of an item's MFMAs in a rolling two-deep pipeline was measured
+    // slower -- 152 VGPRs, three waves per SIMD: 126 vs 110 us on the C5 layer.)
+    for (int grp = wave; !ONE && grp < NG; grp += 4) {
+        const int ri = grp * 32 + l31;
+        const int ry = ri / RW, rx = ri - ry * RW;
+        const int iy = y0 - g.pad + ry, ix = x0 - g.pad + rx;
+        const bool ok = ri < NPX && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi;
+        const float* xp = Xb + ((long)iy * g.Wi + ix) * g.Cr;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int c0 = 0; c0 < g.Cr; c0 += 32) {
+            f32x4 a[4], bw[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = ok ? *reinterpret_cast<const f32x4*>(xp + c0 + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+                bw[i] = ncol ? *reinterpret_cast<const f32x4*>(Wn + c0 + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (nrm.scale) {  // virtual input (fused BatchNorm + activation of the producer); padding stays exactly zero
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    a[i] = norm_apply_if(ok, a[i], *reinterpret_cast<const f32x4*>(nrm.scale + c0 + 16 * half + 4 * i),
+                                         *reinterpret_cast<const f32x4*>(nrm.shift + c0 + 16 * half + 4 * i), nrm.slope);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], bw[i][e], acc, 0, 0, 0);
+        }
+        if (ncol) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Pl[(grp * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * PS + l31] = acc[r];
+        }
+    }
+    __syncthreads();
+    const int py = t >> 5, px = t & 31;
+    const int oy = y0 + py, ox = x0 + px;
+    if (oy < g.Ho && ox < g.Wo) {
+        float v[3];
+#pragma unroll
+        for (int co = 0; co < 3; ++co) v[co] = bias ? bias[co] : 0.f;
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < KW; ++kw) {
+                const float* pp = Pl + ((py + kh) * RW + px + kw) * PS + (kh * KW + kw) * 3;
+#pragma unroll
+                for (int co = 0; co < 3; ++co) v[co] += pp[co];
+            }
+        float* yo = Y + (((long)img * g.Ho + oy) * g.Wo + ox) * 3;
+#pragma unroll
+        for (int co = 0; co < 3; ++co) yo[co] = apply_act(v[co], act, slope);
     }
 }
 
@@ -995,6 +1135,26 @@ inline bool thin_out_tile_plan(const Geom& g, const float* X, int& TH, int& TW, 
 
 template <bool BWD>
 int launch_thin_out_tile(const float* X, const float* W, float* Y, const Geom& g, const Epilogue& ep, hipStream_t st, bool* handled) {
+    static const bool valu_only = getenv("MOVAE_THIN_OUT_VALU") != nullptr;  // (A/B knob)
+    if (!BWD && !valu_only && g.Nn == 3 && g.Cr % 32 == 0 && g.stride == 1 && g.KH == 3 && g.KW == 3 && g.wrow == 0 &&
+        g.Ho == g.Hi + 2 * g.pad - 2 && g.Wo == g.Wi + 2 * g.pad - 2 &&
+        ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(g_fuse.nrm.scale) |
+          reinterpret_cast<uintptr_t>(g_fuse.nrm.shift)) & 15) == 0) {
+        const int tiles_h = ceil_div(g.Ho, 8), tiles_w = ceil_div(g.Wo, 32);
+        const long nblk = (long)g.Nimg * tiles_h * tiles_w;
+        if (nblk <= 0x7fffffffL) {
+            constexpr int NG = (10 * 34 + 31) / 32;
+            if (g.Cr == 32)
+                hipLaunchKernelGGL((thin_out_mfma_k<3, 3, true>), dim3((unsigned)nblk), dim3(256), (size_t)NG * 32 * 27 * sizeof(float), st,
+                                   X, W, ep.bias, Y, g, tiles_h, tiles_w, ep.act, ep.slope, g_fuse.nrm);
+            else
+                hipLaunchKernelGGL((thin_out_mfma_k<3, 3, false>), dim3((unsigned)nblk), dim3(256), (size_t)NG * 32 * 27 * sizeof(float), st,
+                                   X, W, ep.bias, Y, g, tiles_h, tiles_w, ep.act, ep.slope, g_fuse.nrm);
+            MOVAE_CHECK_LAUNCH("thin_out_mfma");
+            *handled = true;
+            return MOVAE_OK;
+        }
+    }
     int TH, TW, IH, IW, CC, PPT;
     *handled = thin_out_tile_plan<BWD>(g, X, TH, TW, IH, IW, CC, PPT);
     if (!*handled) return MOVAE_OK;
