@@ -367,6 +367,12 @@ int movae_bn_bwd_finalize(const float* bn_part, size_t bn_cap, int ppg, int grou
                           int accumulate, movae_stream_t stream);
 int movae_bn_bwd_apply(const float* dout, const float* y, const float* scale, const float* shift, float slope, const float* coef,
                        float* dy, int groups, size_t rows, int c, movae_stream_t stream);
+/* The two calls above as one: with few partials per group (the deep layers) a single launch folds them per 32-channel slice and forms
+ * dy; otherwise the two launches.  coef is scratch of [groups][3][c] floats either way. */
+int movae_bn_bwd_finalize_apply(const float* bn_part, size_t bn_cap, int ppg, int groups, size_t rows, int c, const float* gamma,
+                                const float* save_mean, const float* save_rstd, float* const* dgamma, float* const* dbeta, float* coef,
+                                int accumulate, const float* dout, const float* y, const float* scale, const float* shift, float slope,
+                                float* dy, movae_stream_t stream);
 /* partial sums -> mean / rstd (saved for movae_bn_act_bwd), scale / shift (for the consumers), running statistics with
  * nn.BatchNorm2d's momentum rule and unbiased variance, num_batches_tracked += 1 (each may be NULL).  rows = n * h * w.
  * stats_cap / bn_cap: floats available at the partials buffer -- with more than 256 partials and room behind them, a first

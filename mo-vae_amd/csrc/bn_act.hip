@@ -698,6 +698,85 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_coef_k(const float* __restri
     }
 }
 
+// Both steps in one launch for the layers whose sums arrive in few partials (the deep, latency-bound ones: <= 256 per group).  A block
+// owns 32 channels x a chunk of rows: it first folds the partials of its 32 channels itself (<= 64 KiB out of L2, eight pairs in flight per lane, doubles, the
+// arithmetic of bn_bwd_finalize_k), keeps the three coefficients in LDS and then forms dy for its rows -- eight lanes cover the 128
+// bytes of a row's channel slice.  The blocks of the first row chunk also write dgamma / dbeta.
+__global__ __launch_bounds__(256) void bn_bwd_fused_k(const float* __restrict__ part, int ppg, int rows, int C,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, BnOut out, int accumulate,
+                                                     const float* __restrict__ dout, const float* __restrict__ y,
+                                                     const float* __restrict__ scale, const float* __restrict__ shift, float slope,
+                                                     float* __restrict__ dy, int rows_per_chunk) {
+    const int g = blockIdx.z, c0 = blockIdx.y * 32, t = threadIdx.x;
+    __shared__ double red[2][8][32];
+    __shared__ __attribute__((aligned(16))) float cf[3][32];
+    {
+        const int cl = t & 31, c = c0 + cl, pl = t >> 5;
+        double s1 = 0.0, s2 = 0.0;
+        if (c < C)
+            for (int p0 = pl; p0 < ppg; p0 += 64) {  // eight partial pairs in flight per lane
+                float v1[8], v2[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int p = p0 + 8 * u;
+                    const long q = (long)g * ppg + (p < ppg ? p : pl);
+                    v1[u] = part[(q * 2 + 0) * C + c], v2[u] = part[(q * 2 + 1) * C + c];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (p0 + 8 * u < ppg) s1 += (double)v1[u], s2 += (double)v2[u];
+            }
+        red[0][pl][cl] = s1;
+        red[1][pl][cl] = s2;
+        __syncthreads();
+        if (t < 32 && c < C) {
+            s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s1 += red[0][i][cl], s2 += red[1][i][cl];
+            const double m = mean[c], r = rstd[c], ga = gamma[c];
+            const double dgam = r * (s2 - m * s1);
+            if (blockIdx.x == 0) {
+                if (out.dbeta[g]) out.dbeta[g][c] = (float)(accumulate ? out.dbeta[g][c] + s1 : s1);
+                if (out.dgamma[g]) out.dgamma[g][c] = (float)(accumulate ? out.dgamma[g][c] + dgam : dgam);
+            }
+            const double k1 = ga * r, c2 = -k1 * r * dgam / rows, c3 = -k1 * s1 / rows - c2 * m;
+            cf[0][cl] = (float)k1, cf[1][cl] = (float)c2, cf[2][cl] = (float)c3;
+        }
+        __syncthreads();
+    }
+    const int q = t & 7, c = c0 + 4 * q;
+    if (c >= C) return;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(scale + c), b = *reinterpret_cast<const f32x4*>(shift + c);
+    const f32x4 k1 = *reinterpret_cast<const f32x4*>(&cf[0][4 * q]), c2 = *reinterpret_cast<const f32x4*>(&cf[1][4 * q]),
+                c3 = *reinterpret_cast<const f32x4*>(&cf[2][4 * q]);
+    const long goff = (long)g * rows * C;
+    const int row0 = blockIdx.x * rows_per_chunk, row1 = min(rows, row0 + rows_per_chunk);
+    for (int row = row0 + (t >> 3); row < row1; row += 4 * 32) {
+        f32x4 d4[4], y4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = row + 32 * u;
+            const bool ok = rr < row1;
+            d4[u] = ok ? *reinterpret_cast<const f32x4*>(dout + goff + (long)rr * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            y4[u] = ok ? *reinterpret_cast<const f32x4*>(y + (long)rr * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = row + 32 * u;
+            if (rr >= row1) break;
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float z = fmaf(y4[u][j], a[j], b[j]);
+                const float d = d4[u][j] * (z > 0.f ? 1.f : slope);
+                o[j] = fmaf(k1[j], d, fmaf(c2[j], y4[u][j], c3[j]));
+            }
+            *reinterpret_cast<f32x4*>(dy + goff + (long)rr * C + c) = o;
+        }
+    }
+}
+
 inline int small_rows() {  // MOVAE_BN_SMALL_ROWS: largest row count served by the one-launch kernels (0 disables them)
     static const int v = getenv("MOVAE_BN_SMALL_ROWS") ? atoi(getenv("MOVAE_BN_SMALL_ROWS")) : 1024;
     return v < 1024 ? v : 1024;  // the kernels hold the whole column in registers: 4 rows per thread
@@ -900,6 +979,40 @@ int movae_bn_bwd_apply(const float* dout, const float* y, const float* scale, co
     hipLaunchKernelGGL(bn_bwd_apply_coef_k, dim3(grid_for(nv / 4 + 1), groups), dim3(256), 0, (hipStream_t)stream, dout, y, scale, shift, slope,
                        coef, dy, nv, c);
     MOVAE_CHECK_LAUNCH("bn_bwd_apply");
+    return MOVAE_OK;
+}
+
+int movae_bn_bwd_finalize_apply(const float* bn_part, size_t bn_cap, int ppg, int groups, size_t rows, int c, const float* gamma,
+                                const float* save_mean, const float* save_rstd, float* const* dgamma, float* const* dbeta, float* coef,
+                                int accumulate, const float* dout, const float* y, const float* scale, const float* shift, float slope,
+                                float* dy, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(bn_part && gamma && save_mean && save_rstd && coef && dout && y && scale && shift && dy,
+                    "movae_bn_bwd_finalize_apply: null pointer");
+    MOVAE_CHECK_ARG(ppg > 0 && rows > 0 && rows <= 0x7fffffffUL && c > 0 && groups >= 1 && groups <= MAX_GROUPS,
+                    "movae_bn_bwd_finalize_apply: bad shape");
+    MOVAE_CHECK_ARG(c % 4 == 0 && al16(dout, y, dy) && al16(scale, shift, coef), "movae_bn_bwd_finalize_apply: needs c %% 4 == 0 and aligned operands");
+    static const int fuse_below = getenv("MOVAE_BN_BWD_FUSE_PARTS") ? atoi(getenv("MOVAE_BN_BWD_FUSE_PARTS")) : 256;
+    if (ppg > fuse_below) {  // many partials: every block folding them again costs more than the finalize launch
+        if (int rc = movae_bn_bwd_finalize(bn_part, bn_cap, ppg, groups, (int)rows, c, gamma, save_mean, save_rstd, dgamma, dbeta, coef,
+                                           accumulate, stream))
+            return rc;
+        return movae_bn_bwd_apply(dout, y, scale, shift, slope, coef, dy, groups, rows, c, stream);
+    }
+    BnOut tab;
+    for (int g = 0; g < MAX_GROUPS; ++g) {
+        tab.dgamma[g] = (g < groups && dgamma) ? dgamma[g] : nullptr;
+        tab.dbeta[g] = (g < groups && dbeta) ? dbeta[g] : nullptr;
+    }
+    const int slices = (c + 31) / 32;
+    // about 2048 blocks over (row chunks, channel slices, groups), chunks of at least 128 rows (four per lane group)
+    long chunks = 2048 / ((long)slices * groups);
+    if (chunks < 1) chunks = 1;
+    long rpc = ((long)rows + chunks - 1) / chunks;
+    if (rpc < 128) rpc = 128;
+    chunks = ((long)rows + rpc - 1) / rpc;
+    hipLaunchKernelGGL(bn_bwd_fused_k, dim3((unsigned)chunks, slices, groups), dim3(256), 0, (hipStream_t)stream, bn_part, ppg, (int)rows, c,
+                       gamma, save_mean, save_rstd, tab, accumulate, dout, y, scale, shift, slope, dy, (int)rpc);
+    MOVAE_CHECK_LAUNCH("bn_bwd_finalize_apply");
     return MOVAE_OK;
 }
 

@@ -883,11 +883,10 @@ class BatchNormLazy(Function):
         coef = torch.empty((G, 3, c), dtype=y.dtype, device=y.device)
         arr = C.c_void_p * G
         st = _st(y)
-        _call("movae_bn_bwd_finalize", part.data_ptr(), part.numel(), ppg, G, rows, c, gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-              arr(*[t.data_ptr() for t in dgs]), arr(*[t.data_ptr() for t in dbs]), coef.data_ptr(), 0, st)
         dy = torch.empty_like(dout)
-        _call("movae_bn_bwd_apply", dout.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr(), float(ctx.slope), coef.data_ptr(),
-              dy.data_ptr(), G, rows, c, st)
+        _call("movae_bn_bwd_finalize_apply", part.data_ptr(), part.numel(), ppg, G, rows, c, gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+              arr(*[t.data_ptr() for t in dgs]), arr(*[t.data_ptr() for t in dbs]), coef.data_ptr(), 0, dout.data_ptr(), y.data_ptr(),
+              scale.data_ptr(), shift.data_ptr(), float(ctx.slope), dy.data_ptr(), st)
         return dy
 
     @staticmethod
