@@ -1158,6 +1158,12 @@ int launch_wgrad(const float* S, const float* Bg, float* const* dW, int G, long 
         if (g.Cs <= 32 && N >= 128) return (g_last_kernel = "igemm2_wgrad<32,128>", v2::launch_wgrad2<32, 128>(S, Bg, dW, G, s_gs, b_gs, g, (int)Kl, accumulate, ws, ws_bytes, st, cs));
         if (g.Cs >= 128 && (long)(g.Cs / 128) * (N / 128) * (Kl / 512) * G >= big_tile_min())
             return (g_last_kernel = "igemm2_wgrad<128,128>", v2::launch_wgrad2<128, 128>(S, Bg, dW, G, s_gs, b_gs, g, (int)Kl, accumulate, ws, ws_bytes, st, cs));
+        // 64 rows of dW with a long reduction (C5: 32 -> 64 channels on 64 x 64 images, four cotangent groups): a 64-wide tile moves
+        // 16 KiB of operands per 64 x 64 x 32 MACs -- 16 flop per byte from L2, bandwidth-bound near 0.6 of the MFMA peak; twice the
+        // width reads the S operand half as often.  Unpaired (work of this size fills the chip on its own).
+        static const bool wide64 = !getenv("MOVAE_NO_WGRAD_64x128");
+        if (wide64 && g.Cs > 32 && g.Cs <= 64 && N >= 256 && (long)(N / 128) * (Kl / 512) * G >= big_tile_min())
+            return (g_last_kernel = "igemm2_wgrad<64,128>", v2::launch_wgrad2<64, 128>(S, Bg, dW, G, s_gs, b_gs, g, (int)Kl, accumulate, ws, ws_bytes, st, cs));
         return (g_last_kernel = "igemm2_wgrad<64,64>", v2::launch_wgrad2<64, 64>(S, Bg, dW, G, s_gs, b_gs, g, (int)Kl, accumulate, ws, ws_bytes, st, cs));
     }
     if (thin::thin_wgrad_ok(g) && ws)
