@@ -17,18 +17,8 @@ namespace thin {
 // Output side of the 32-output thin-input kernels: the block's 256 pixels x 32 outputs sit in LDS as Wl[pixel * 33 + n] (activation
 // applied) and are one contiguous 32 KiB run of Y.  BatchNorm statistics / backward sums of the tile, the ActMul factor, then stores of
 // 1 KiB per wave instead of 64 scattered 16-byte pieces.
-// pre_y: the ActMul factor's source (am.y pieces of this thread, thin_in_am_y) loaded by the caller ahead of its compute phase.
-__device__ __forceinline__ void thin_in_am_y(const ActMul& am, int M, int t, f32x4 (&y4)[8]) {
-    const long rows_left = (long)M - (long)blockIdx.x * 256;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int idx = i * 256 + t, px = idx >> 3, q = idx & 7;
-        const long o = ((long)blockIdx.x * 256 + px) * 32 + q * 4;
-        y4[i] = (px < rows_left && am.y) ? *reinterpret_cast<const f32x4*>(am.y + o % am.per_group) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-}
 __device__ __forceinline__ void thin_in_tile_out(float* __restrict__ Wl, float* __restrict__ Y, int M, int t, float* __restrict__ stats,
-                                                 const BnBwd& bb, const ActMul& am, const f32x4 (*pre_y)[8] = nullptr) {
+                                                 const BnBwd& bb, const ActMul& am) {
     float* yb = Y + (long)blockIdx.x * 256 * 32;
     const long rows_left = (long)M - (long)blockIdx.x * 256;
     if (stats) {
@@ -77,29 +67,30 @@ __device__ __forceinline__ void thin_in_tile_out(float* __restrict__ Wl, float* 
     if (actmul_on(am)) {
         // the result is the cotangent of an activation output / a residual block's branch (ActMul): factor act'(y) and the
         // identity cotangent on the way out, 16-byte pieces, all loads of a thread ahead of its stores
-        f32x4 y4[8], r4[8];
-        if (pre_y) {
+        // (two halves of four pieces: sixteen 16-byte registers for y and res at once would cost the kernels a wave of occupancy)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) y4[i] = (*pre_y)[i];
-        } else {
-            thin_in_am_y(am, M, t, y4);
-        }
+        for (int h = 0; h < 2; ++h) {
+            f32x4 y4[4], r4[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int idx = i * 256 + t, px = idx >> 3, q = idx & 7;
-            const long o = ((long)blockIdx.x * 256 + px) * 32 + q * 4;
-            r4[i] = (px < rows_left && am.res) ? *reinterpret_cast<const f32x4*>(am.res + o) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+            for (int j = 0; j < 4; ++j) {
+                const int i = h * 4 + j;
+                const int idx = i * 256 + t, px = idx >> 3, q = idx & 7;
+                const long o = ((long)blockIdx.x * 256 + px) * 32 + q * 4;
+                const bool ok = px < rows_left;
+                y4[j] = (ok && am.y) ? *reinterpret_cast<const f32x4*>(am.y + o % am.per_group) : f32x4{0.f, 0.f, 0.f, 0.f};
+                r4[j] = (ok && am.res) ? *reinterpret_cast<const f32x4*>(am.res + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int idx = i * 256 + t, px = idx >> 3, q = idx & 7;
-            if (px < rows_left) {
-                const float* src = Wl + px * 33 + q * 4;
-                f32x4 o4;
+            for (int j = 0; j < 4; ++j) {
+                const int idx = (h * 4 + j) * 256 + t, px = idx >> 3, q = idx & 7;
+                if (px < rows_left) {
+                    const float* src = Wl + px * 33 + q * 4;
+                    f32x4 o4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    o4[e] = src[e] * (am.y ? act_grad_from_out(y4[i][e], am.act, am.slope) : 1.f) + r4[i][e];
-                *reinterpret_cast<f32x4*>(yb + px * 32 + q * 4) = o4;
+                    for (int e = 0; e < 4; ++e)
+                        o4[e] = src[e] * (am.y ? act_grad_from_out(y4[j][e], am.act, am.slope) : 1.f) + r4[j][e];
+                    *reinterpret_cast<f32x4*>(yb + px * 32 + q * 4) = o4;
+                }
             }
         }
         return;
@@ -223,8 +214,6 @@ __global__ __launch_bounds__(256) void thin_in_mfma_k(const float* __restrict__ 
     const int s = g.stride;
     const int ih0 = BWD ? ho0 + g.pad - (KH - 1) : ho0 * s - g.pad, iw0 = BWD ? wo0 + g.pad - (KW - 1) : wo0 * s - g.pad;
     constexpr int KP = K | 1;  // odd LDS row pitch of the staged weights: lanes are outputs, conflict-free
-    f32x4 y4[8];   // ActMul: the activation output this block's result is multiplied by act'(.) of -- in flight under staging and MFMAs
-    if (am.y) thin_in_am_y(am, M, t, y4);
     float bw[KS];  // B operand: W[k = 2j + half][n = lane & 31]
     if (BWD) {     // W[c][tap][n]: the lanes of a load are neighbours in memory
 #pragma unroll
@@ -299,7 +288,9 @@ __global__ __launch_bounds__(256) void thin_in_mfma_k(const float* __restrict__ 
             Wl[(wave * 64 + u * 32 + m) * 33 + l31] = apply_act(acc[u][r] + bv, act, slope);
         }
     __syncthreads();
-    thin_in_tile_out(Wl, Y, M, t, stats, bb, am, am.y ? &y4 : nullptr);
+    // (Loading the ActMul factor's source ahead of the staging / MFMA phase was measured slower: 32 more registers, three waves per SIMD,
+    // 211 vs 176 us on the C5 layer.)
+    thin_in_tile_out(Wl, Y, M, t, stats, bb, am);
 }
 
 // ---- thin output side (FWD gather) -----------------------------------------------------------------
