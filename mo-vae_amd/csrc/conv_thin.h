@@ -18,8 +18,9 @@ namespace thin {
 // applied) and are one contiguous 32 KiB run of Y.  BatchNorm statistics / backward sums of the tile, the ActMul factor, then stores of
 // 1 KiB per wave instead of 64 scattered 16-byte pieces.
 __device__ __forceinline__ void thin_in_tile_out(float* __restrict__ Wl, float* __restrict__ Y, int M, int t, float* __restrict__ stats,
-                                                 const BnBwd& bb, const ActMul& am) {
-    float* yb = Y + (long)blockIdx.x * 256 * 32;
+                                                 const BnBwd& bb, const ActMul& am, int N = 32, int n0 = 0) {
+    // N > 32: the tile is columns n0 .. n0 + 31 of 256 rows of N floats (128-byte row segments; statistics / backward sums: N == 32 only)
+    float* yb = Y + (long)blockIdx.x * 256 * N + n0;
     const long rows_left = (long)M - (long)blockIdx.x * 256;
     if (stats) {
         // column statistics of the block's 256 x 32 tile for the BatchNorm that follows (the tile sits in LDS anyway):
@@ -81,7 +82,7 @@ __device__ __forceinline__ void thin_in_tile_out(float* __restrict__ Wl, float* 
             for (int j = 0; j < 4; ++j) {
                 const int i = h * 4 + j;
                 const int idx = i * 256 + t, px = idx >> 3, q = idx & 7;
-                const long o = ((long)blockIdx.x * 256 + px) * 32 + q * 4;
+                const long o = ((long)blockIdx.x * 256 + px) * N + n0 + q * 4;
                 const bool ok = px < rows_left;
                 y4[j] = (ok && am.y) ? *reinterpret_cast<const f32x4*>(am.y + o % am.per_group) : f32x4{0.f, 0.f, 0.f, 0.f};
                 r4[j] = (ok && am.res) ? *reinterpret_cast<const f32x4*>(am.res + o) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -95,7 +96,7 @@ __device__ __forceinline__ void thin_in_tile_out(float* __restrict__ Wl, float* 
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         o4[e] = src[e] * (am.y ? act_grad_from_out(y4[j][e], am.act, am.slope) : 1.f) + r4[j][e];
-                    *reinterpret_cast<f32x4*>(yb + px * 32 + q * 4) = o4;
+                    *reinterpret_cast<f32x4*>(yb + (long)px * N + q * 4) = o4;
                 }
             }
         }
@@ -106,7 +107,7 @@ __device__ __forceinline__ void thin_in_tile_out(float* __restrict__ Wl, float* 
         const int idx = i * 256 + t, px = idx >> 3, q = idx & 7;
         if (px < rows_left) {
             const float* src = Wl + px * 33 + q * 4;
-            *reinterpret_cast<f32x4*>(yb + px * 32 + q * 4) = f32x4{src[0], src[1], src[2], src[3]};
+            *reinterpret_cast<f32x4*>(yb + (long)px * N + q * 4) = f32x4{src[0], src[1], src[2], src[3]};
         }
     }
 }
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(256) void thin_in_mfma_k(const float* __restrict__ 
     constexpr int TC = 3, TAPS = KH * KW, K = TAPS * TC, KS = (K + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) float Wl[];  // input region [RH][RW * 3], then the output tile [256][33]
     const int t = threadIdx.x, lane = t & 63, half = lane >> 5, l31 = lane & 31, wave = t >> 6;
+    const int N = g.Nn, n0 = blockIdx.y * 32;  // N % 32 == 0 (host): a block computes 32 of the N outputs of its 256 pixels
     const int p0 = blockIdx.x * 256, hw = g.Ho * g.Wo;
     const int img = fdiv(p0, fd_hw), rem = p0 - img * hw;
     const int ho0 = fdiv(rem, fd_wo), wo0 = rem - ho0 * g.Wo;
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(256) void thin_in_mfma_k(const float* __restrict__ 
         for (int j = 0; j < KS; ++j) {
             const int k = 2 * j + half, kk = k < K ? k : K - 1;
             const int tap = kk / TC, c = kk - tap * TC;
-            const float w = W[((long)c * TAPS + tap) * 32 + l31];
+            const float w = W[((long)c * TAPS + tap) * N + n0 + l31];
             bw[j] = k < K ? w : 0.f;
         }
     }
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(256) void thin_in_mfma_k(const float* __restrict__ 
         float wv[BWD ? 1 : (32 * K + 255) / 256];
         if (!BWD) {
 #pragma unroll
-            for (int u = 0; u < (32 * K + 255) / 256; ++u) wv[u] = t + u * 256 < 32 * K ? W[t + u * 256] : 0.f;
+            for (int u = 0; u < (32 * K + 255) / 256; ++u) wv[u] = t + u * 256 < 32 * K ? W[(long)n0 * K + t + u * 256] : 0.f;
         }
         for (int base = t; base < total; base += 9 * 256) {
             float v[9];
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(256) void thin_in_mfma_k(const float* __restrict__ 
 #pragma unroll
         for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(Wl[cb[u] + dl[j]], bw[j], acc[u], 0, 0, 0);
     __syncthreads();  // the region is dead: the output tile takes its place
-    const float bv = bias ? bias[l31] : 0.f;
+    const float bv = bias ? bias[n0 + l31] : 0.f;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(256) void thin_in_mfma_k(const float* __restrict__ 
     __syncthreads();
     // (Loading the ActMul factor's source ahead of the staging / MFMA phase was measured slower: 32 more registers, three waves per SIMD,
     // 211 vs 176 us on the C5 layer.)
-    thin_in_tile_out(Wl, Y, M, t, stats, bb, am);
+    thin_in_tile_out(Wl, Y, M, t, stats, bb, am, N, n0);
 }
 
 // ---- thin output side (FWD gather) -----------------------------------------------------------------
@@ -1033,53 +1035,55 @@ template <bool BWD>
 int launch_thin_in(const float* X, const float* W, float* Y, const Geom& g, const Epilogue& ep, hipStream_t st) {
     const long Ml = (long)g.Nimg * g.Ho * g.Wo;
     const int M = (int)Ml, K = g.KH * g.KW * g.Cr;
-    if (g.Nn > 32) {
-        dim3 grid(ceil_div(M, 256), ceil_div(g.Nn, 64));
-        hipLaunchKernelGGL((thin_in_k<64, BWD>), grid, dim3(256), (size_t)K * 64 * sizeof(float), st, X, W, ep.bias, Y, g, M,
-                           ep.act, ep.slope, (float*)nullptr, BnBwd{}, ActMul{nullptr, 0, 0.f, 0, 0, nullptr});
-    } else {
-        dim3 grid(ceil_div(M, 256), 1);
-        size_t lds_floats = (size_t)K * 32;
-        if (g.Nn == 32 && lds_floats < 256 * 33) lds_floats = 256 * 33;  // room for the coalescing transpose of the outputs
-        float* stats = nullptr;  // the 32-output kernel holds its tile in LDS: statistics for a following BatchNorm come for free
-        if (!BWD && g.Nn == 32 && ep.act == MOVAE_ACT_NONE) stats = fuse_stats_claim((long)grid.x * 4, 32);
-        BnBwd bb{};  // input gradient of the last conv = output gradient of the fused BatchNorm in front of it
-        if (BWD && g.Nn == 32 && g_fuse.bn_y && ep.act == MOVAE_ACT_NONE && !ep.bias && M % g_fuse.bn_groups == 0 &&
-            (M / g_fuse.bn_groups) % 256 == 0) {
-            const long rpg = M / g_fuse.bn_groups;
-            if (float* part = fuse_bn_claim(rpg / 256 * 4, 32))
-                bb = BnBwd{g_fuse.bn_y, g_fuse.bn_scale, g_fuse.bn_shift, g_fuse.bn_slope, part, (int)rpg, (int)(rpg / 256 * 4)};
-        }
-        // the previous layer's activation derivative / a residual block's identity cotangent on the result (32-output tile only)
-        ActMul am{nullptr, 0, 0.f, 0, 0, nullptr};
-        if ((g_fuse.am.y || g_fuse.am.res) && g.Nn == 32 && ep.act == MOVAE_ACT_NONE && (!ep.bias || !g_fuse.am.y) && !bb.y && !stats &&
-            M % g_fuse.am_groups == 0 && (reinterpret_cast<uintptr_t>(Y) & 15) == 0) {
-            am = g_fuse.am;
-            am.per_group = (long)(M / g_fuse.am_groups) * 32;
-            g_fuse.am_done = true;
-        }
-        // MFMA form: 3 reduction channels, 32 outputs, 3x3 / 4x4 taps, blocks of whole rows or of a row segment of one image
-        static const bool valu_only = getenv("MOVAE_THIN_IN_VALU") != nullptr;  // (A/B knob)
-        const int hw = g.Ho * g.Wo;
-        const bool k33 = g.KH == 3 && g.KW == 3, k44 = g.KH == 4 && g.KW == 4;
-        if (!valu_only && g.Nn == 32 && g.Cr == 3 && (k33 || k44) && (!BWD || g.stride == 1) && hw % 256 == 0 &&
-            (256 % g.Wo == 0 || g.Wo % 256 == 0) && g.wrow == 0) {
-            const int ncols = g.Wo < 256 ? g.Wo : 256, nrows = 256 / ncols;
-            const int RH = BWD ? nrows + g.KH - 1 : (nrows - 1) * g.stride + g.KH;
-            const int RW = BWD ? ncols + g.KW - 1 : (ncols - 1) * g.stride + g.KW;
-            size_t lf = (size_t)RH * RW * 3 + (BWD ? 0 : 32 * (g.KH * g.KW * 3 | 1));
-            if (lf < 256 * 33) lf = 256 * 33;
-            if (lf * sizeof(float) <= 60 * 1024) {
+    const bool n32 = g.Nn == 32;
+    dim3 grid(ceil_div(M, 256), 1);
+    float* stats = nullptr;  // the 32-output kernels hold their tile in LDS: statistics for a following BatchNorm come for free
+    if (!BWD && n32 && ep.act == MOVAE_ACT_NONE) stats = fuse_stats_claim((long)grid.x * 4, 32);
+    BnBwd bb{};  // input gradient of the last conv = output gradient of the fused BatchNorm in front of it
+    if (BWD && n32 && g_fuse.bn_y && ep.act == MOVAE_ACT_NONE && !ep.bias && M % g_fuse.bn_groups == 0 && (M / g_fuse.bn_groups) % 256 == 0) {
+        const long rpg = M / g_fuse.bn_groups;
+        if (float* part = fuse_bn_claim(rpg / 256 * 4, 32))
+            bb = BnBwd{g_fuse.bn_y, g_fuse.bn_scale, g_fuse.bn_shift, g_fuse.bn_slope, part, (int)rpg, (int)(rpg / 256 * 4)};
+    }
+    // MFMA form: 3 reduction channels, a multiple of 32 outputs (32 per block: grid.y column tiles), 3x3 / 4x4 taps, blocks of whole
+    // rows or of a row segment of one image
+    static const bool valu_only = getenv("MOVAE_THIN_IN_VALU") != nullptr;  // (A/B knob)
+    const int hw = g.Ho * g.Wo;
+    const bool k33 = g.KH == 3 && g.KW == 3, k44 = g.KH == 4 && g.KW == 4;
+    bool mfma = !valu_only && g.Nn % 32 == 0 && g.Cr == 3 && (k33 || k44) && (!BWD || g.stride == 1) && hw % 256 == 0 &&
+                (256 % g.Wo == 0 || g.Wo % 256 == 0) && g.wrow == 0 && (reinterpret_cast<uintptr_t>(Y) & 15) == 0;
+    const int ncols = g.Wo < 256 ? g.Wo : 256, nrows = 256 / ncols;
+    const int RH = BWD ? nrows + g.KH - 1 : (nrows - 1) * g.stride + g.KH;
+    const int RW = BWD ? ncols + g.KW - 1 : (ncols - 1) * g.stride + g.KW;
+    size_t lf = (size_t)RH * RW * 3 + (BWD ? 0 : 32 * (g.KH * g.KW * 3 | 1));
+    if (lf < 256 * 33) lf = 256 * 33;
+    mfma = mfma && lf * sizeof(float) <= 60 * 1024;
+    // the previous layer's activation derivative / a residual block's identity cotangent on the result (kernels with the LDS output tile)
+    ActMul am{nullptr, 0, 0.f, 0, 0, nullptr};
+    if ((g_fuse.am.y || g_fuse.am.res) && (n32 || mfma) && ep.act == MOVAE_ACT_NONE && (!ep.bias || !g_fuse.am.y) && !bb.y && !stats &&
+        M % g_fuse.am_groups == 0 && (reinterpret_cast<uintptr_t>(Y) & 15) == 0) {
+        am = g_fuse.am;
+        am.per_group = (long)(M / g_fuse.am_groups) * g.Nn;
+        g_fuse.am_done = true;
+    }
+    if (mfma) {
+        grid.y = g.Nn / 32;
 #define MOVAE_TI(K)                                                                                                                \
     hipLaunchKernelGGL((thin_in_mfma_k<K, K, BWD>), grid, dim3(256), lf * sizeof(float), st, X, W, ep.bias, Y, g, M, ep.act, ep.slope,  \
                        stats, bb, am, ncols, RH, RW, fastdiv_make(RW * 3), fastdiv_make(3), fastdiv_make(ncols), fastdiv_make(hw),  \
                        fastdiv_make(g.Wo))
-                if (k33) MOVAE_TI(3); else MOVAE_TI(4);
+        if (k33) MOVAE_TI(3); else MOVAE_TI(4);
 #undef MOVAE_TI
-                MOVAE_CHECK_LAUNCH("thin_in_mfma");
-                return MOVAE_OK;
-            }
-        }
+        MOVAE_CHECK_LAUNCH("thin_in_mfma");
+        return MOVAE_OK;
+    }
+    if (g.Nn > 32) {
+        grid.y = ceil_div(g.Nn, 64);
+        hipLaunchKernelGGL((thin_in_k<64, BWD>), grid, dim3(256), (size_t)K * 64 * sizeof(float), st, X, W, ep.bias, Y, g, M,
+                           ep.act, ep.slope, (float*)nullptr, BnBwd{}, ActMul{nullptr, 0, 0.f, 0, 0, nullptr});
+    } else {
+        size_t lds_floats = (size_t)K * 32;
+        if (n32 && lds_floats < 256 * 33) lds_floats = 256 * 33;  // room for the coalescing transpose of the outputs
         hipLaunchKernelGGL((thin_in_k<32, BWD>), grid, dim3(256), lds_floats * sizeof(float), st, X, W, ep.bias, Y, g, M,
                            ep.act, ep.slope, stats, bb, am);
     }
