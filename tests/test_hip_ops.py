@@ -64,6 +64,12 @@ CONV_CASES = [
     (4, 32, 1, 1, 48, 3, 1, 1),      # 1x1 input, 3x3 taps: the tap window is the centre tap alone (and it is NOT a linear layer)
     (3, 16, 2, 2, 24, 4, 2, 1),      # 2x2 -> 1x1 with 4x4 taps: window rows/cols 1..2 of the stored kernel
     (2, 256, 2, 2, 512, 3, 2, 1),    # the C2 layer itself: K 2304 -> 1024
+    # thin-channel MFMA kernels (blocks of 256 output pixels of one image):
+    (2, 3, 32, 32, 32, 3, 2, 1),     # thin_in_mfma_k fwd, 3x3 stride 2, a block = the whole 16x16 output image (CIFAR first conv)
+    (1, 3, 64, 64, 64, 4, 2, 1),     # ... 4x4 taps, 64 outputs = two column tiles, 8 rows of 32 per block (VQ / BetaTC first conv)
+    (1, 3, 4, 512, 32, 3, 1, 1),     # ... blocks are row SEGMENTS (Wo a multiple of 256), stride 1
+    (2, 32, 16, 16, 3, 3, 1, 1),     # thin_out_mfma_k fwd; its input gradient is thin_in_mfma_k BWD (32 outputs)
+    (1, 64, 8, 32, 3, 3, 1, 1),      # ... two channel chunks fwd, two column tiles in the input gradient
 ]
 
 
@@ -100,6 +106,7 @@ CONVT_CASES = [
     (2, 64, 16, 16, 3, 4, 2, 1, 0),   # thin-output kernel, exact tiles
     (3, 32, 8, 8, 3, 3, 2, 1, 1),     # thin-output kernel, 3x3 taps with output padding
     (2, 24, 16, 16, 2, 4, 2, 1, 0),   # thin-output kernel, 2 outputs, channels not a multiple of the chunk
+    (2, 128, 16, 16, 3, 4, 2, 1, 0),  # VQ last layer: the input gradient is thin_in_mfma_k in FWD form with 128 outputs (four column tiles)
 ]
 
 
