@@ -632,6 +632,120 @@ __global__ __launch_bounds__(256) void thin_out_mfma_k(const float* __restrict__
     }
 }
 
+// The transposed form (last layer of the VQ decoders: ConvTranspose2d C -> 3, 4x4 taps, stride 2, pad 1): the same two steps,
+//   P[q][tap * 3 + co] = sum_c X[q][c] * W[c][tap][co]                      (48 columns: two MFMA column tiles, the second half used)
+//   out[y][x][co] = sum over the 2 x 2 taps of y's / x's parity of P[((y + 1 - kh) / 2, (x + 1 - kw) / 2)][tap * 3 + co].
+// A block owns 16 x 64 output pixels = 8 x 32 input pixels plus a one-pixel halo (10 x 34, eleven groups of 32, <= 3 per wave).  The
+// weights pass through LDS once, transposed to [column][channel] (the lanes of B are columns: their channels lie 192 bytes apart in
+// memory); every 32-channel chunk loads its B registers for both column tiles from there and the A registers of the wave's groups from
+// global memory, then runs 2 x 16 MFMAs per group into accumulators that stay in registers over all chunks; P takes the place of the
+// weights in LDS after the last chunk and each thread gathers four output pixels.
+__global__ __launch_bounds__(256, 2) void thin_outT_mfma_k(const float* __restrict__ X, const float* __restrict__ W,
+                                                        const float* __restrict__ bias, float* __restrict__ Y, Geom g, int tiles_h,
+                                                        int tiles_w, int act, float slope, Norm nrm) {
+    constexpr int ITH = 8, ITW = 32, RH = ITH + 2, RW = ITW + 2, NPX = RH * RW, NG = (NPX + 31) / 32, GW = (NG + 3) / 4;
+    constexpr int TAPS = 16, NC = TAPS * 3, PS = NC + 1;  // 48 columns, odd pitch
+    extern __shared__ __attribute__((aligned(16))) float Pl[];  // W^T [NC][Cr + 4] during the MFMA phase, then P [NG * 32][PS]
+    const int t = threadIdx.x, lane = t & 63, half = lane >> 5, l31 = lane & 31, wave = t >> 6;
+    int b = blockIdx.x;
+    const int tw = b % tiles_w;
+    b /= tiles_w;
+    const int th = b % tiles_h, img = b / tiles_h;
+    const int a0 = th * ITH, b0 = tw * ITW;  // input tile origin; output tile origin (2 * a0, 2 * b0)
+    const int Cr = g.Cr, WP = Cr + 4;
+    for (int f = t; f < Cr * NC; f += 256) {  // W[c][n] -> W^T[n][c]
+        const int c = f / NC, n = f - c * NC;
+        Pl[n * WP + c] = W[f];
+    }
+    // this lane's pixels: group u of the wave -> region pixel -> image pixel
+    const float* xp[GW];
+    bool ok[GW];
+#pragma unroll
+    for (int u = 0; u < GW; ++u) {
+        const int ri = (wave + 4 * u) * 32 + l31;
+        const int ry = ri / RW, rx = ri - ry * RW;
+        const int iy = a0 - 1 + ry, ix = b0 - 1 + rx;
+        ok[u] = wave + 4 * u < NG && ri < NPX && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi;
+        xp[u] = X + (((long)img * g.Hi + iy) * g.Wi + ix) * Cr + 16 * half;
+    }
+    f32x16 acc[GW][2];
+#pragma unroll
+    for (int u = 0; u < GW; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[u][v][r] = 0.f;
+    __syncthreads();
+    const bool col1 = l31 < NC - 32;  // second column tile: 16 of its 32 columns exist
+    for (int c0 = 0; c0 < Cr; c0 += 32) {
+        f32x4 bw[2][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bw[0][i] = *reinterpret_cast<const f32x4*>(Pl + l31 * WP + c0 + 16 * half + 4 * i);
+            bw[1][i] = col1 ? *reinterpret_cast<const f32x4*>(Pl + (32 + l31) * WP + c0 + 16 * half + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        f32x4 a[2][4];  // this group's operand and the next one's, loaded one group ahead
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[0][i] = ok[0] ? *reinterpret_cast<const f32x4*>(xp[0] + c0 + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < GW; ++u) {
+            if (wave + 4 * u >= NG) break;
+            if (u + 1 < GW) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    a[(u + 1) & 1][i] = ok[u + 1] ? *reinterpret_cast<const f32x4*>(xp[u + 1] + c0 + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (nrm.scale) {  // virtual input (fused BatchNorm + activation of the producer); padding stays exactly zero
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    a[u & 1][i] = norm_apply_if(ok[u], a[u & 1][i], *reinterpret_cast<const f32x4*>(nrm.scale + c0 + 16 * half + 4 * i),
+                                                *reinterpret_cast<const f32x4*>(nrm.shift + c0 + 16 * half + 4 * i), nrm.slope);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[u][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u & 1][i][e], bw[0][i][e], acc[u][0], 0, 0, 0);
+                    acc[u][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u & 1][i][e], bw[1][i][e], acc[u][1], 0, 0, 0);
+                }
+        }
+    }
+    __syncthreads();  // every wave is done with the weights: P takes their place
+#pragma unroll
+    for (int u = 0; u < GW; ++u) {
+        const int grp = wave + 4 * u;
+        if (grp >= NG) break;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float* row = Pl + (grp * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * PS;
+            row[l31] = acc[u][0][r];
+            if (col1) row[32 + l31] = acc[u][1][r];
+        }
+    }
+    __syncthreads();
+    const float b0v = bias ? bias[0] : 0.f, b1v = bias ? bias[1] : 0.f, b2v = bias ? bias[2] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int op = t + 256 * u, oy = op >> 6, ox = op & 63;
+        const int y = 2 * a0 + oy, x = 2 * b0 + ox;
+        if (y >= g.Ho || x >= g.Wo) continue;
+        float v0 = b0v, v1 = b1v, v2 = b2v;
+        const int ph = (oy + 1) & 1, pw = (ox + 1) & 1;  // (2 * a0, 2 * b0 are even; pad = 1)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int kh = ph + 2 * i, rr = ((oy + 1 - kh) >> 1) + 1;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int kw = pw + 2 * j, rc = ((ox + 1 - kw) >> 1) + 1;
+                const float* pp = Pl + (rr * RW + rc) * PS + (kh * 4 + kw) * 3;
+                v0 += pp[0], v1 += pp[1], v2 += pp[2];
+            }
+        }
+        float* yo = Y + (((long)img * g.Ho + y) * g.Wo + x) * 3;
+        yo[0] = apply_act(v0, act, slope), yo[1] = apply_act(v1, act, slope), yo[2] = apply_act(v2, act, slope);
+    }
+}
+
 // ---- thin weight gradient ----------------------------------------------------------------------------
 // dW[a][tap][b] = sum_p S[p][a] * Bg[p*s - pad + tap][b].  THIN_SMALL: Cs <= 4 (accumulators over a, lanes
 // over b); else Cb <= 4 (accumulators over b, lanes over a).  grid = (pixel chunks, taps); block = WL wide
@@ -1152,6 +1266,21 @@ int launch_thin_out_tile(const float* X, const float* W, float* Y, const Geom& g
                 hipLaunchKernelGGL((thin_out_mfma_k<3, 3, false>), dim3((unsigned)nblk), dim3(256), (size_t)NG * 32 * 27 * sizeof(float), st,
                                    X, W, ep.bias, Y, g, tiles_h, tiles_w, ep.act, ep.slope, g_fuse.nrm);
             MOVAE_CHECK_LAUNCH("thin_out_mfma");
+            *handled = true;
+            return MOVAE_OK;
+        }
+    }
+    if (BWD && !valu_only && g.Nn == 3 && g.Cr % 32 == 0 && g.stride == 2 && g.KH == 4 && g.KW == 4 && g.pad == 1 && g.Ho == 2 * g.Hi &&
+        g.Wo == 2 * g.Wi && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(g_fuse.nrm.scale) |
+                              reinterpret_cast<uintptr_t>(g_fuse.nrm.shift)) & 15) == 0) {
+        const int tiles_h = ceil_div(g.Hi, 8), tiles_w = ceil_div(g.Wi, 32);
+        const long nblk = (long)g.Nimg * tiles_h * tiles_w;
+        const size_t wt = (size_t)48 * (g.Cr + 4), pt = (size_t)11 * 32 * 49;
+        const size_t shb = (wt > pt ? wt : pt) * sizeof(float);
+        if (nblk <= 0x7fffffffL && shb <= 80 * 1024) {
+            hipLaunchKernelGGL(thin_outT_mfma_k, dim3((unsigned)nblk), dim3(256), shb, st, X, W, ep.bias, Y, g, tiles_h, tiles_w, ep.act,
+                               ep.slope, g_fuse.nrm);
+            MOVAE_CHECK_LAUNCH("thin_outT_mfma");
             *handled = true;
             return MOVAE_OK;
         }
