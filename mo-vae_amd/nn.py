@@ -134,6 +134,13 @@ class Identity(_Act):
 ACTIVATIONS = {"tanh": Tanh, "sigmoid": Sigmoid, "none": Identity}
 
 
+def _starts_with_conv(m):
+    """Is the first op of `m` a conv (m itself, or the first module of a Stack, recursively)?  Such a module takes an ActLink."""
+    while isinstance(m, Stack) and len(m) > 0:
+        m = m[0]
+    return isinstance(m, (Conv2d, ConvTranspose2d))
+
+
 class Stack(tnn.Sequential):
     """nn.Sequential (same child names, hence same state_dict keys) whose forward fuses
     conv -> [batchnorm] -> activation runs into the conv / batch-norm kernels' epilogues."""
@@ -207,7 +214,7 @@ class Stack(tnn.Sequential):
                           if (link is not None or rin is not None or rout is not None) else None)
                     link = None
                     i += 1
-            elif (isinstance(m, _Act) and m.kind in ("lrelu", "relu") and i + 1 < n and isinstance(mods[i + 1], (Conv2d, ConvTranspose2d))
+            elif (isinstance(m, _Act) and m.kind in ("lrelu", "relu") and i + 1 < n and _starts_with_conv(mods[i + 1])
                   and not isinstance(x, ops.LazyBN)):
                 # a stand-alone activation whose output only the next conv reads: that conv's input gradient applies its derivative
                 link = ops.ActLink()

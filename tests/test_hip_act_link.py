@@ -199,3 +199,37 @@ def test_vqvae_residual_layer(fused, gpu_device, monkeypatch):
         for a, b, nm in zip(got[g], ref[g], ["dx", "dW_head", "dW3_0", "dW1_0", "dW3_1", "dW1_1"]):
             _close(a, b, f"group {g} {nm}")
     assert calls.count("movae_add") == (0 if fused else 2), calls
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_standalone_activation_before_a_nested_stack(fused, gpu_device, monkeypatch):
+    """models/vq_vae.py:218-236: residual layers -> LeakyReLU -> Sequential(Conv / ConvTranspose, LeakyReLU).  The stand-alone
+    activation's only reader is the first conv of the NEXT Stack: that conv's input gradient applies its derivative."""
+    import movae_amd  # noqa: F401
+    from movae_amd import _lib as L, nn as mnn, ops
+
+    monkeypatch.setattr(ops, "FUSE_ACT", fused)
+    calls = []
+    monkeypatch.setattr(L, "TRACE", lambda nm, a: calls.append(nm))
+    torch.manual_seed(11)
+    c0, c1, c2 = mnn.Conv2d(8, 32, 3, 1, 1), mnn.ConvTranspose2d(32, 16, 4, 2, 1), mnn.Conv2d(16, 8, 1, 1, 0)
+    stack = mnn.Stack(mnn.Stack(c0), mnn.LeakyReLU(), mnn.Stack(c1, mnn.LeakyReLU()), mnn.Stack(c2, mnn.LeakyReLU())).to(gpu_device)
+    x = torch.randn(4, 8, 8, 8)
+    xr = x.clone().requires_grad_(True)
+    ws = [(c.weight.detach().cpu().contiguous().clone().requires_grad_(True), c.bias.detach().cpu().clone().requires_grad_(True)) for c in (c0, c1, c2)]
+    h = F.leaky_relu(F.conv2d(xr, ws[0][0], ws[0][1], padding=1), 0.01)
+    h = F.leaky_relu(F.conv_transpose2d(h, ws[1][0], ws[1][1], stride=2, padding=1), 0.01)
+    h = F.leaky_relu(F.conv2d(h, ws[2][0], ws[2][1]), 0.01)
+    cot = torch.randn(h.shape, generator=torch.Generator().manual_seed(5))
+    (h * cot).sum().backward()
+    xh = x.to(gpu_device).requires_grad_(True)
+    out = stack(ops.to_nhwc(xh)).permute(0, 3, 1, 2)
+    _close(out, h, "output", rtol=5e-4, atol=5e-5)
+    calls.clear()
+    (out * cot.to(gpu_device)).sum().backward()
+    _close(xh.grad, xr.grad, "dx")
+    for i, (c, (w, b)) in enumerate(zip((c0, c1, c2), ws)):
+        _close(c.weight.grad, w.grad, f"dW{i}")
+        _close(c.bias.grad, b.grad, f"db{i}")
+    n_bwd = sum(1 for nm in calls if nm.startswith("movae_act_bwd"))
+    assert n_bwd == (1 if fused else 3), calls  # fused: only the last activation (no consumer) runs a backward pass of its own
