@@ -39,6 +39,7 @@ CONFIGS = {
 CONV_CALLS = {"movae_conv2d_fwd", "movae_conv2d_dgrad", "movae_conv2d_wgrad", "movae_convT2d_fwd", "movae_convT2d_dgrad",
               "movae_convT2d_wgrad", "movae_conv2d_wgrad_grouped", "movae_convT2d_wgrad_grouped",
               "movae_conv2d_dgrad_wgrad_grouped", "movae_convT2d_dgrad_wgrad_grouped"}
+PAIR_CALLS = {"movae_linear_pair_fwd", "movae_linear_pair_bwd"}  # fc_mu || fc_var (conv family: 1x1 convs on a 1x1 image)
 POOL_BATCHES = 24               # distinct synthetic batches cycled by the timed loop (>= 20)
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 HBM_PEAK_GBS = 8000.0
@@ -101,6 +102,16 @@ def conv_call_bytes(name, a):
     if "dgrad_wgrad" in name:  # dy[G], x, w read; dx[G], dW[G] written
         return 4.0 * (n * hi * wi * ci * (1 + groups) + groups * n * ho * wo * co + (1 + groups) * kh * kw * ci * co)
     return 4.0 * (n * hi * wi * ci + groups * (n * ho * wo * co + kh * kw * ci * co))
+
+
+def pair_call_info(name, a):
+    """(flops, algorithmic bytes, shape) of a movae_linear_pair_* call (include/movae.h)."""
+    if name.endswith("_fwd"):   # (x, w1, b1, w2, b2, y1, y2, m, n, k, stream)
+        m, n, k = a[7:10]
+        return 2 * 2.0 * m * n * k, 4.0 * (m * k + 2 * n * k + 2 * m * n), [m, 1, 1, k, 1, 1, 2 * n, 1, 1, 1, 0]
+    g, (m, n, k) = int(a[0]), a[11:14]  # (groups, dy1, dy2, w1, w2, x, dx, dw1, dw2, db1, db2, m, n, k, stream)
+    passes = (1 if a[6] else 0) + (1 if a[7] else 0)
+    return g * 2 * passes * 2.0 * m * n * k, 4.0 * (m * k * (1 + g) + 2 * g * m * n + 2 * (1 + g) * n * k), [m, 1, 1, k, 1, 1, 2 * n, 1, 1, 1, 0, g]
 
 
 def conv_call_key(name, a):
@@ -183,7 +194,7 @@ def cpu_baseline(cfg, seconds, device=None, check_steps=20):
     return out
 
 
-FAMILY = [("conv", "movae_conv"), ("batchnorm", "movae_bn_"), ("batchnorm", "movae_scale_shift"), ("loss", "movae_recon"), ("loss", "movae_kl"), ("loss", "movae_tc"),
+FAMILY = [("conv", "movae_conv"), ("conv", "movae_linear_pair"), ("batchnorm", "movae_bn_"), ("batchnorm", "movae_scale_shift"), ("loss", "movae_recon"), ("loss", "movae_kl"), ("loss", "movae_tc"),
           ("vq", "movae_vq"), ("aggregation", "movae_gram"), ("aggregation", "movae_weights"), ("aggregation", "movae_combine"),
           ("aggregation", "movae_gd_"), ("optimizer", "movae_adam"), ("optimizer", "movae_sumsq"), ("optimizer", "movae_scale_by"),
           ("elementwise", "movae_")]
@@ -269,6 +280,12 @@ def measure_dominant_kernel(recorded, device, reps=20, live=False):
     other = {}
     for name, rec in recorded:
         fn = getattr(lib, name)
+        if name in PAIR_CALLS and live:
+            us = timed(fn, tuple(rec))
+            fl, by, shape = pair_call_info(name, rec)
+            rows.append(dict(call=name, kernel=lib.movae_bench_last_kernel().decode(), shape=shape, us=us, us_main=us, gflop=fl / 1e9,
+                             gflop_executed=fl / 1e9, alg_bytes=by))
+            continue
         if _base(name) not in CONV_CALLS:
             if live:
                 fam = family_of(name)
@@ -420,7 +437,7 @@ def main():
             L.TRACE = None
         torch.cuda.synchronize()
         all_rows, other = measure_dominant_kernel(recorded, device, live=live)
-        rows = [r for r in all_rows if _base(r["call"]) in CONV_CALLS]
+        rows = [r for r in all_rows if _base(r["call"]) in CONV_CALLS or r["call"] in PAIR_CALLS]
         tot_us = sum(r["us"] for r in rows)
         tot_gf = sum(r["gflop"] for r in rows)
         # group the main-kernel timings by kernel symbol (the way rocprofv3 --stats does) and report the one with

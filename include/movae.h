@@ -89,6 +89,18 @@ int movae_convT2d_dgrad_wgrad_grouped(int groups, const float* dy, const float* 
 int movae_convT2d_wgrad_grouped(int groups, const float* dy, const float* x, float* const* dw, float* const* dbias,
                                 int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad,
                                 int accumulate, void* ws, size_t ws_bytes, movae_stream_t stream);
+/* Two nn.Linear layers applied to the same input -- fc_mu || fc_var (models/vae.py:128-129,187-192, betatc_vae.py:100-101,181-182):
+ *   y1 = x w1^T + b1, y2 = x w2^T + b2      x [m][k], w [n][k], y [m][n]                          (one launch)
+ *   dx[g] = dy1[g] w1 + dy2[g] w2;  dw_i[g] = dy_i[g]^T x;  db_i[g] = column sums of dy_i[g]       (two launches, all groups)
+ * dy_i stacked [groups][m][n], dx [groups][m][k] (NULL: not wanted), dw_i / db_i HOST arrays of device pointers (db_i or its entries
+ * may be NULL; dw1 == dw2 == NULL: no weight gradients).  Results equal the four ordinary calls up to the summation order of dx.
+ * Returns MOVAE_EUNSUPPORTED, with nothing launched, outside the one-launch GEMM kernels' range (groups <= 4, n, k multiples of 4, m * n,
+ * m * k, n * k <= 2^20, reductions <= 2048, 16-byte aligned operands): make the ordinary calls then. */
+int movae_linear_pair_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y1, float* y2,
+                          int m, int n, int k, movae_stream_t stream);
+int movae_linear_pair_bwd(int groups, const float* dy1, const float* dy2, const float* w1, const float* w2, const float* x, float* dx,
+                          float* const* dw1, float* const* dw2, float* const* db1, float* const* db2, int m, int n, int k,
+                          movae_stream_t stream);
 
 /* ---- BatchNorm2d (training statistics) + activation ------------------------------------------
  * nn.BatchNorm2d + nn.LeakyReLU   models/vae.py:123-125,157-158,169-170   (eps 1e-5, momentum 0.1)

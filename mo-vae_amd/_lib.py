@@ -107,6 +107,8 @@ SIGNATURES = {
     "movae_convT2d_dgrad_f": (_conv_dgrad + [_p, _i], _i),
     "movae_bn_bwd_finalize": ([_p, _z, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p], _i),
     "movae_bn_bwd_apply": ([_p, _p, _p, _p, _f, _p, _p, _i, _z, _i, _p], _i),
+    "movae_linear_pair_fwd": ([_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
+    "movae_linear_pair_bwd": ([_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p], _i),
     "movae_bn_bwd_finalize_apply": ([_p, _z, _i, _i, _z, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _f, _p, _p], _i),
     "movae_bn_finalize": ([_p, _z, _i, _i, _i, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p], _i),
     "movae_bn_stats": ([_p, _i, _i, _p, _z, _p, _p], _i),

@@ -1489,6 +1489,50 @@ int movae_convT2d_dgrad_wgrad_grouped(int groups, const float* dy, const float* 
                                                ws, ws_bytes, stream, nullptr);
 }
 
+// Two fully connected layers on one input (fc_mu || fc_var) -- see lin::LinPair.  MOVAE_EUNSUPPORTED (nothing launched) for shapes
+// outside the one-launch GEMM kernels: the caller then makes the two ordinary calls.
+static bool linear_pair_ok(int groups, int m, int n, int k, const void* a, const void* b, const void* c, const void* d) {
+    return groups >= 1 && groups <= 4 && m > 0 && n > 0 && k > 0 && n % 4 == 0 && k % 4 == 0 && lin::linear_small_ok(m, n, k) &&
+           lin::linear_small_ok(m, k, n) && lin::linear_small_ok(n, k, (m + 3) / 4 * 4) &&
+           ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) | reinterpret_cast<uintptr_t>(d)) & 15) == 0;
+}
+
+int movae_linear_pair_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y1, float* y2,
+                          int m, int n, int k, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(x && w1 && w2 && y1 && y2, "movae_linear_pair_fwd: null pointer");
+    if (!linear_pair_ok(1, m, n, k, x, w1, w2, nullptr)) return MOVAE_EUNSUPPORTED;
+    float* ys[2] = {y1, y2};
+    g_last_kernel = "linear_small_k<NT pair>";
+    return lin::launch_linear_pair<0>(x, nullptr, w1, w2, ys, nullptr, 1, 0, b1, b2, m, n, k, (hipStream_t)stream);
+}
+
+int movae_linear_pair_bwd(int groups, const float* dy1, const float* dy2, const float* w1, const float* w2, const float* x, float* dx,
+                          float* const* dw1, float* const* dw2, float* const* db1, float* const* db2, int m, int n, int k,
+                          movae_stream_t stream) {
+    MOVAE_CHECK_ARG(dy1 && dy2 && w1 && w2 && x, "movae_linear_pair_bwd: null pointer");
+    if (!linear_pair_ok(groups, m, n, k, dy1, dy2, w1, w2) || (reinterpret_cast<uintptr_t>(x) & 15) != 0) return MOVAE_EUNSUPPORTED;
+    const long gs = (long)m * n;  // one cotangent group of dy
+    if (dx) {  // dx[g] = dy1[g] W1 + dy2[g] W2: [m][n] x [n][k]
+        float* ys[8];
+        for (int g = 0; g < groups; ++g) ys[g] = dx + (long)g * m * k;
+        if (int rc = lin::launch_linear_pair<1>(dy1, dy2, w1, w2, ys, nullptr, groups, gs, nullptr, nullptr, m, k, n, (hipStream_t)stream))
+            return rc;
+    }
+    if (dw1 && dw2) {  // dW[g] = dy[g]^T x: [n][k], reduction over the m rows; the bias gradients are the column sums of dy
+        float* ys[8];
+        float* cs[8];
+        for (int g = 0; g < groups; ++g) {
+            ys[g] = dw1[g], ys[groups + g] = dw2[g];
+            cs[g] = db1 ? db1[g] : nullptr, cs[groups + g] = db2 ? db2[g] : nullptr;
+            MOVAE_CHECK_ARG(ys[g] && ys[groups + g], "movae_linear_pair_bwd: null weight-gradient destination");
+        }
+        if (int rc = lin::launch_linear_pair<2>(dy1, dy2, x, nullptr, ys, cs, groups, gs, nullptr, nullptr, n, k, m, (hipStream_t)stream))
+            return rc;
+    }
+    g_last_kernel = "linear_small_k<NN pair> + linear_small_k<TN pair>";
+    return MOVAE_OK;
+}
+
 // Stand-alone statistics pass in the partial-sum format of the fused epilogues, for producers that cannot emit them
 // (a thin-channel or generic kernel): one read of y.
 int movae_bn_stats(const float* y, int rows, int c, float* stats, size_t stats_cap, int* parts_out, movae_stream_t stream) {

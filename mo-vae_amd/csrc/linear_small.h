@@ -23,18 +23,45 @@ struct LinOut {
     float* colsum[8];  // TN only: bias gradient per group (may be null)
 };
 
-template <int FORM>  // 0 = NT, 1 = NN, 2 = TN
+// PAIR: two layers that read the same input in one launch (fc_mu || fc_var, models/vae.py:128-129,187-192: each is ~6 us of latency
+// for ~0.2 us of arithmetic).  Second problem's operands in LinPair; the first one's in the ordinary arguments.
+//   NT (forward):  blockIdx.z = layer;  A = x shared, B / bias / Y per layer
+//   TN (wgrad):    blockIdx.z = layer * G + group;  A = dy of the layer and group, B = x shared
+//   NN (dgrad):    blockIdx.z = group;  dx = dy1 W1 + dy2 W2 -- waves 0-1 reduce over layer 1, waves 2-3 over layer 2, the fold adds them
+struct LinPair {
+    const float* A2;
+    const float* B2;
+    const float* bias2;
+    int G;  // TN: cotangent groups per layer
+};
+
+template <int FORM, bool PAIR = false>  // 0 = NT, 1 = NN, 2 = TN
 __global__ __launch_bounds__(256) void linear_small_k(const float* __restrict__ A, const float* __restrict__ B, LinOut out,
                                                       const float* __restrict__ bias, int M, int N, int K, int act, float slope,
-                                                      long a_gs, int accumulate) {
+                                                      long a_gs, int accumulate, LinPair pr = LinPair{nullptr, nullptr, nullptr, 1}) {
     __shared__ float red[4][16][64];
     __shared__ float csum[4][32];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
-    A += blockIdx.z * a_gs;  // cotangent group: only the A operand (dy) is per group
+    int slot = wave, nslots = 4;  // this wave's share of the reduction
+    if (PAIR) {
+        if (FORM == 0) {
+            if (blockIdx.z) B = pr.B2, bias = pr.bias2;
+        } else if (FORM == 2) {
+            const int layer = blockIdx.z / pr.G;
+            A = (layer ? pr.A2 : A) + (blockIdx.z - layer * pr.G) * a_gs;
+        } else {
+            const int layer = wave >> 1;
+            A = (layer ? pr.A2 : A) + blockIdx.z * a_gs;
+            if (layer) B = pr.B2;
+            slot = wave & 1, nslots = 2;
+        }
+    } else {
+        A += blockIdx.z * a_gs;  // cotangent group: only the A operand (dy) is per group
+    }
     // reduction slice of this wave, in groups of 8
-    const int groups = (K + 7) / 8, gper = (groups + 3) / 4;
-    const int g_begin = wave * gper, g_end = min(groups, g_begin + gper);
+    const int groups = (K + 7) / 8, gper = (groups + nslots - 1) / nslots;
+    const int g_begin = slot * gper, g_end = min(groups, g_begin + gper);
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -122,8 +149,24 @@ int launch_linear_small(const float* A, const float* B, float* const* Y, float* 
         out.colsum[i] = (i < G && colsum) ? colsum[i] : nullptr;
     }
     hipLaunchKernelGGL((linear_small_k<FORM>), dim3(ceil_div(M, 32), ceil_div(N, 32), G), dim3(256), 0, st, A, B, out, bias, M, N, K, act,
-                       slope, a_gs, accumulate);
+                       slope, a_gs, accumulate, LinPair{nullptr, nullptr, nullptr, 1});
     MOVAE_CHECK_LAUNCH("linear_small");
+    return MOVAE_OK;
+}
+
+// the pair forms (see LinPair).  Y / colsum: NT two entries (layer), TN 2 * G entries (layer-major), NN G entries (group)
+template <int FORM>
+int launch_linear_pair(const float* A, const float* A2, const float* B, const float* B2, float* const* Y, float* const* colsum, int G,
+                       long a_gs, const float* bias, const float* bias2, int M, int N, int K, hipStream_t st) {
+    const int nz = FORM == 0 ? 2 : (FORM == 2 ? 2 * G : G);
+    LinOut out;
+    for (int i = 0; i < 8; ++i) {
+        out.y[i] = i < nz ? Y[i] : nullptr;
+        out.colsum[i] = (i < nz && colsum) ? colsum[i] : nullptr;
+    }
+    hipLaunchKernelGGL((linear_small_k<FORM, true>), dim3(ceil_div(M, 32), ceil_div(N, 32), nz), dim3(256), 0, st, A, B, out, bias, M, N, K,
+                       0, 0.f, a_gs, 0, LinPair{A2, B2, bias2, G});
+    MOVAE_CHECK_LAUNCH("linear_pair");
     return MOVAE_OK;
 }
 

@@ -48,7 +48,7 @@ class BetaTCVAE(HotPathModel):
     def encode(self, x):
         h = ops.flatten_nchw(self.encoder(ops.to_nhwc(x)))
         h = self.fc(h)  # no activation after fc (models/betatc_vae.py:180)
-        return [self.fc_mu(h), self.fc_var(h)]
+        return list(mnn.linear_pair(h, self.fc_mu, self.fc_var))
 
     def decode(self, z):
         h = ops.unflatten_nchw(self.decoder_input(z), self.hidden_dims[-1], self._sp, self._sp)

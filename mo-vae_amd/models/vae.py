@@ -74,7 +74,7 @@ class VAE(HotPathModel):
     # -- reference API ------------------------------------------------------------------------
     def encode(self, x):
         h = self.encoder(ops.to_nhwc(x))
-        return self.mu(h), self.log_var(h)
+        return mnn.linear_pair(h, self.mu, self.log_var)  # (fc_mu || fc_var in one launch where the shapes allow)
 
     def reparameterize(self, mu, log_var):
         return ops.reparameterize(mu, log_var, self._noise_like(mu))

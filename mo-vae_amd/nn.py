@@ -78,6 +78,11 @@ class Linear(tnn.Module):
         return f"{self.in_features}, {self.out_features}"
 
 
+def linear_pair(x, lin1, lin2):
+    """(lin1(x), lin2(x)) for two Linear modules that read the same input (fc_mu, fc_var): one launch forward, two backward."""
+    return ops.linear_pair(x, lin1.weight, lin1.bias, lin2.weight, lin2.bias)
+
+
 class BatchNorm2d(tnn.Module):
     """nn.BatchNorm2d(affine, track_running_stats) semantics: eps 1e-5, momentum 0.1."""
 

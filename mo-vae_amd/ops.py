@@ -734,6 +734,88 @@ def linear(x, w, b=None, act=None, slope=0.01):
     return y.reshape(n, w.shape[0])
 
 
+#: MOVAE_LINEAR_PAIR=0: fc_mu / fc_var as two ordinary linear calls
+LINEAR_PAIR = __import__("os").environ.get("MOVAE_LINEAR_PAIR", "1") != "0"
+
+
+def linear_pair_ok(x, w1, b1, w2, b2, groups=1):
+    """The range of movae_linear_pair_* (include/movae.h): two equally shaped nn.Linear layers on one [m, k] input."""
+    if not (LINEAR_PAIR and x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and w1.shape == w2.shape and b1 is not None and b2 is not None):
+        return False
+    m, k = x.shape
+    n = w1.shape[0]
+    if w1.shape[1] != k or n % 4 or k % 4 or max(m * n, m * k, n * k) > (1 << 20) or max(m, n, k) > 2048 or groups > 4:
+        return False
+    return all(t.is_contiguous() and t.data_ptr() % 16 == 0 for t in (x, w1, w2))
+
+
+class LinearPair(Function):
+    """(x w1^T + b1, x w2^T + b2) in one launch, and the two layers' backward in two (movae_linear_pair_*): fc_mu || fc_var of the
+    VAE / BetaTC-VAE encoders (models/vae.py:187-192).  The caller checks linear_pair_ok."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        ctx.set_materialize_grads(False)
+        L.require_gpu(x)
+        x = _c(x)
+        m, k = x.shape
+        n = w1.shape[0]
+        y1 = torch.empty((m, n), dtype=x.dtype, device=x.device)
+        y2 = torch.empty_like(y1)
+        _call("movae_linear_pair_fwd", x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), y1.data_ptr(), y2.data_ptr(),
+              m, n, k, _st(x))
+        ctx.save_for_backward(x, w1, b1, w2, b2)
+        return y1, y2
+
+    @staticmethod
+    def _run(ctx, G, dy1, dy2, sink):
+        """dy_i: [G, m, n] stacked (or None: that output had no cotangent).  sink(g, param, shape) -> gradient destination."""
+        x, w1, b1, w2, b2 = ctx.saved_tensors
+        m, k = x.shape
+        n = w1.shape[0]
+        ref = dy1 if dy1 is not None else dy2
+        if dy1 is None:
+            dy1 = torch.zeros_like(ref)
+        if dy2 is None:
+            dy2 = torch.zeros_like(ref)
+        need_x = ctx.needs_input_grad[0]
+        need_w = any(ctx.needs_input_grad[1:])
+        dx = torch.empty((G, m, k), dtype=x.dtype, device=x.device) if need_x else None
+        dw1 = dw2 = db1 = db2 = None
+        if need_w:
+            dw1, dw2 = [sink(g, w1, (n, k)) for g in range(G)], [sink(g, w2, (n, k)) for g in range(G)]
+            db1, db2 = [sink(g, b1, (n,)) for g in range(G)], [sink(g, b2, (n,)) for g in range(G)]
+        for g0 in range(0, G, 4):  # (the entry point takes up to four cotangent groups)
+            g1 = min(G, g0 + 4)
+            ptrs = lambda ts: (C.c_void_p * (g1 - g0))(*[t.data_ptr() for t in ts[g0:g1]]) if ts is not None else None  # noqa: E731
+            _call("movae_linear_pair_bwd", g1 - g0, dy1[g0].data_ptr(), dy2[g0].data_ptr(), w1.data_ptr(), w2.data_ptr(), x.data_ptr(),
+                  dx[g0].data_ptr() if dx is not None else 0, ptrs(dw1), ptrs(dw2), ptrs(db1), ptrs(db2), m, n, k, _st(x))
+        return dx, dw1, db1, dw2, db2
+
+    @staticmethod
+    def backward(ctx, dy1, dy2):
+        if dy1 is None and dy2 is None:
+            return None, None, None, None, None
+        one = lambda t: _c(t).unsqueeze(0) if t is not None else None  # noqa: E731
+        dx, dw1, db1, dw2, db2 = LinearPair._run(ctx, 1, one(dy1), one(dy2), lambda g, p, shape: _sink(p, shape))
+        first = lambda ts: ts[0] if ts is not None else None  # noqa: E731
+        return (dx[0] if dx is not None else None), first(dw1), first(db1), first(dw2), first(db2)
+
+    @staticmethod
+    def backward_batched(ctx, G, dy1, dy2):
+        if dy1 is None and dy2 is None:
+            return None, None, None, None, None
+        st = lambda t: _stacked(t, G) if t is not None else None  # noqa: E731
+        return LinearPair._run(ctx, G, st(dy1), st(dy2), _sink_row)
+
+
+def linear_pair(x, w1, b1, w2, b2):
+    """(linear(x, w1, b1), linear(x, w2, b2)); one launch where the shapes allow (linear_pair_ok)."""
+    if linear_pair_ok(x, w1, b1, w2, b2):
+        return LinearPair.apply(x, w1, b1, w2, b2)
+    return linear(x, w1, b1), linear(x, w2, b2)
+
+
 # ---------------------------------------------------------------------------------------------
 class BatchNormAct(Function):
     @staticmethod

@@ -787,3 +787,41 @@ def test_invalid_arguments_raise(M):
         ops.conv2d(torch.zeros(1, 4, 4, 3), torch.zeros(8, 3, 3, 3))  # CPU tensors: no CPU path
     with pytest.raises(ValueError):
         agg.compute_gramian(torch.zeros(9, 10).cuda())  # K > MOVAE_MAX_K
+
+
+@pytest.mark.parametrize("m,k,n", [(256, 512, 128), (32, 256, 128), (7, 64, 20)])
+def test_linear_pair_matches_two_linears(M, m, k, n):
+    """ops.linear_pair (fc_mu || fc_var in one launch, movae_linear_pair_*): forward, plain backward and the batched pull-back with
+    2 and 5 cotangent groups (the entry point takes four at a time) against two torch linears on the CPU."""
+    ops, _ = M
+    x, w1, b1, w2, b2 = rnd(m, k, seed=1), rnd(n, k, seed=2) * 0.1, rnd(n, seed=3), rnd(n, k, seed=4) * 0.1, rnd(n, seed=5)
+    ref = [t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    r1, r2 = torch.nn.functional.linear(ref[0], ref[1], ref[2]), torch.nn.functional.linear(ref[0], ref[3], ref[4])
+    g1, g2 = rnd(m, n, seed=6), rnd(m, n, seed=7)
+    (r1 * g1).sum().backward(retain_graph=True)
+    (r2 * g2).sum().backward()
+    dev = [t.cuda().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    assert ops.linear_pair_ok(*dev) == (n % 4 == 0 and k % 4 == 0)
+    y1, y2 = ops.linear_pair(*dev)
+    close(y1, r1, "y1")
+    close(y2, r2, "y2")
+    ((y1 * g1.cuda()).sum() + (y2 * g2.cuda()).sum()).backward()
+    for got, want, nm in zip(dev, ref, ("dx", "dw1", "db1", "dw2", "db2")):
+        close(got.grad, want.grad, nm, rtol=2e-3, atol=2e-4)
+    if not ops.linear_pair_ok(*dev):
+        return
+    # batched pull-back: G cotangent groups at once, one of the two outputs without a cotangent in the second case
+    keep = ops.linear_pair(*dev)  # (a fresh tape: the backward above released the first one's saved tensors)
+    fn = keep[0].grad_fn
+    for G, with2 in ((2, True), (5, True), (3, False)):
+        c1 = torch.stack([rnd(m, n, seed=10 + g) for g in range(G)])
+        c2 = torch.stack([rnd(m, n, seed=30 + g) for g in range(G)]) if with2 else None
+        with torch.no_grad():
+            dx, dw1, db1, dw2, db2 = fn._forward_cls.backward_batched(fn, G, c1.cuda(), c2.cuda() if with2 else None)
+        for g in range(G):
+            want_dx = c1[g] @ w1 + (c2[g] @ w2 if with2 else 0)
+            close(dx[g], want_dx, f"G={G} dx[{g}]", rtol=2e-3, atol=2e-4)
+            close(dw1[g], c1[g].t() @ x, f"G={G} dw1[{g}]", rtol=2e-3, atol=2e-4)
+            close(db1[g], c1[g].sum(0), f"G={G} db1[{g}]", rtol=2e-3, atol=2e-4)
+            close(dw2[g], (c2[g].t() @ x) if with2 else torch.zeros(n, k), f"G={G} dw2[{g}]", rtol=2e-3, atol=2e-4)
+            close(db2[g], c2[g].sum(0) if with2 else torch.zeros(n), f"G={G} db2[{g}]", rtol=2e-3, atol=2e-4)
