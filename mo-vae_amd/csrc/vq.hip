@@ -342,7 +342,9 @@ static int segmented_code_sum(const float* x, const float* q, const int64_t* idx
     MOVAE_CHECK_LAUNCH("vq_keys");
     int kbits = 1;
     while ((1 << kbits) < k) ++kbits;
-    if (hipcub::DeviceRadixSort::SortKeys(temp, temp_bytes, keys, sorted, rows, 0, 32 + kbits, st) != hipSuccess) {
+    // keys are (code << 32 | row) in row order: a STABLE sort on the code bits alone leaves every code's rows ascending -- the order of
+    // the full 41-bit sort at a quarter of its digit passes
+    if (hipcub::DeviceRadixSort::SortKeys(temp, temp_bytes, keys, sorted, rows, 32, 32 + kbits, st) != hipSuccess) {
         movae_set_error("segmented_code_sum: radix sort failed");
         return MOVAE_ELAUNCH;
     }
