@@ -150,6 +150,7 @@ struct FwdArgs {
     Norm nrm;      // virtual gathered operand (zero-initialised: plain)
     float* stats;  // column partial sums of the stored result [gx * WM][2][N], or null (only without split-K)
     BnBwd bb;      // the result is a fused BatchNorm's output gradient: its backward sums (only without split-K)
+    int side_lds;  // host: the side products leave through the LDS tile epilogue -- ONE partial pair per block (else one per wave row)
     FastDiv fd_cr, fd_kw, fd_wlen;  // divisions of the k loop: by g.Cr, g.KW, g.wlen
     ActMul am;     // the stored result is multiplied by the previous layer's activation derivative (only without split-K: else the reduce)
 };
@@ -328,7 +329,7 @@ __device__ __forceinline__ void igemm2_fwd_body(const FwdArgs& a, float* __restr
     // only with act == none); `bb` = the stored value is dout of a fused BatchNorm over bb.y: sums (d, d * y).  One partial pair
     // per wave and column; the two lane halves fold with one shuffle.  (No row block straddles two cotangent groups: host.)
     const bool st_on = a.stats && !to_slab, bb_on = a.bb.y && !to_slab, am_on = actmul_on(a.am) && !to_slab;
-    const long pidx = (long)bx * T::WM + wm;
+    const long pidx = (long)bx * T::WM + wm;  // (per-wave partials: the scalar epilogue, side_lds == 0)
     // the block's first row inside its cotangent group (bb / am: the auxiliary tensor is shared by the groups)
     const int yrow0 = bb_on ? m0 % a.bb.rows_per_group : ((am_on && a.am.y) ? (int)(m0 % (a.am.per_group / N)) : 0);
     // Every epilogue that emits no BatchNorm side product moves its tile through LDS once (free after the loop's last barrier)
@@ -375,11 +376,10 @@ __device__ __forceinline__ void igemm2_fwd_body(const FwdArgs& a, float* __restr
         }
         return;
     }
-    if ((st_on || bb_on) && (N & 3) == 0 &&
-        ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(ep.bias) | reinterpret_cast<uintptr_t>(a.bb.y)) & 15) == 0) {
+    if ((st_on || bb_on) && a.side_lds) {
         // the same through-LDS epilogue with a BatchNorm side product: a thread owns one column quad and every (256 / QPR)-th row
         // of the tile, adds up its part of the column sums, the row lanes fold through LDS in fixed order.  ONE partial pair per
-        // block: it goes to the block's first wave-row slot, the other WM - 1 slots of the layout read zero.
+        // block, and the host sized the partial layout for that (side_lds: N % 4 == 0, 16-byte aligned operands).
         constexpr int LDT = BN + 4, QPR = BN / 4, RSTEP = 256 / QPR;
         float* Ts = smem;
 #pragma unroll
@@ -436,10 +436,8 @@ __device__ __forceinline__ void igemm2_fwd_body(const FwdArgs& a, float* __restr
             float c1 = 0.f, c2 = 0.f;
             for (int i = 0; i < RSTEP; ++i) c1 += Ts[i * BN + t], c2 += Ts[(RSTEP + i) * BN + t];
             float* P = st_on ? a.stats : a.bb.part;
-            const long p0 = (long)bx * T::WM;
-            P[(p0 * 2 + 0) * N + n0 + t] = c1;
-            P[(p0 * 2 + 1) * N + n0 + t] = c2;
-            for (int w = 1; w < T::WM; ++w) P[((p0 + w) * 2 + 0) * N + n0 + t] = 0.f, P[((p0 + w) * 2 + 1) * N + n0 + t] = 0.f;
+            P[((long)bx * 2 + 0) * N + n0 + t] = c1;
+            P[((long)bx * 2 + 1) * N + n0 + t] = c2;
         }
         return;
     }
@@ -515,7 +513,8 @@ struct BwdArgs {
     Norm nrm;
     float* stats;  // [classes * gx * WM][2][N] or null (only without split-K)
     int stats_gx;  // row blocks per class (the launch's grid x) -- the partial index is (class * gx + bx) * WM + wave row
-    BnBwd bb;      // backward sums of a fused BatchNorm (only without split-K; ppg = classes * (gx / groups) * WM)
+    BnBwd bb;      // backward sums of a fused BatchNorm (only without split-K; ppg = classes * (gx / groups) * slots)
+    int side_lds;  // host: side products through the LDS tile epilogue, one partial pair (slot) per block; else WM slots per block
     FastDiv fd_cr;         // k loop: by g.Cr ...
     FastDiv fd_nb[4];      // ... and, per output-parity class, by the class's tap columns nB
     FastDiv fd_hw[4], fd_w[4];  // epilogue, per output-parity class: by Hoc * Woc and by Woc
@@ -722,14 +721,15 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
     float* out = to_slab ? slab + (long)split * total : Y;
     // fused BatchNorm side products of the stores (see igemm2_fwd_body); the output pixel p is computed once for both
     const bool st_on = a.stats && !to_slab, bb_on = a.bb.y && !to_slab, am_on = actmul_on(a.am) && !to_slab;
-    long pidx = ((long)cls * a.stats_gx + bx) * T::WM + wm;
+    const int SL = a.side_lds ? 1 : T::WM, sw = a.side_lds ? 0 : wm;  // partial slots per block, this wave's slot
+    long pidx = ((long)cls * a.stats_gx + bx) * SL + sw;
     long ybase = 0;  // first pixel of the block's cotangent group
     if (am_on && a.am.y && a.am.gx_per_group > 0) ybase = (long)(bx / a.am.gx_per_group) * (a.am.per_group / N);
     if (bb_on) {
         // classes are equally large and no row block straddles two cotangent groups (host): group gi owns bpg row blocks of
         // every class; its partials are [gi * ppg, (gi + 1) * ppg), ordered (class, block in group, wave row)
-        const int bpg = a.bb.ppg / (s * s * T::WM), gi = bx / bpg;
-        pidx = (long)gi * a.bb.ppg + ((long)cls * bpg + (bx - gi * bpg)) * T::WM + wm;
+        const int bpg = a.bb.ppg / (s * s * SL), gi = bx / bpg;
+        pidx = (long)gi * a.bb.ppg + ((long)cls * bpg + (bx - gi * bpg)) * SL + sw;
         ybase = (long)gi * a.bb.rows_per_group;
     }
     const bool lds_ep = am_on || (!st_on && !bb_on && (N & 3) == 0 &&
@@ -775,9 +775,8 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
         }
         return;
     }
-    if ((st_on || bb_on) && (N & 3) == 0 &&
-        ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(ep.bias) | reinterpret_cast<uintptr_t>(a.bb.y)) & 15) == 0) {
-        // through-LDS epilogue with a BatchNorm side product: see igemm2_fwd_body (one partial pair per block, in its first slot)
+    if ((st_on || bb_on) && a.side_lds) {
+        // through-LDS epilogue with a BatchNorm side product: see igemm2_fwd_body (one partial pair per block)
         constexpr int LDT = BN + 4, QPR = BN / 4, RSTEP = 256 / QPR;
         float* Ts = smem;
 #pragma unroll
@@ -841,10 +840,8 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
             float c1 = 0.f, c2 = 0.f;
             for (int i = 0; i < RSTEP; ++i) c1 += Ts[i * BN + t], c2 += Ts[(RSTEP + i) * BN + t];
             float* P = st_on ? a.stats : a.bb.part;
-            const long p0 = pidx - wm;  // the block's first wave-row slot
-            P[(p0 * 2 + 0) * N + n0 + t] = c1;
-            P[(p0 * 2 + 1) * N + n0 + t] = c2;
-            for (int w = 1; w < T::WM; ++w) P[((p0 + w) * 2 + 0) * N + n0 + t] = 0.f, P[((p0 + w) * 2 + 1) * N + n0 + t] = 0.f;
+            P[(pidx * 2 + 0) * N + n0 + t] = c1;  // (side_lds: pidx is the block's one slot)
+            P[(pidx * 2 + 1) * N + n0 + t] = c2;
         }
         return;
     }
@@ -1334,7 +1331,11 @@ int launch_fwd2(const float* X, const float* W, float* Y, const Geom& g, const E
     a.nrm = g_fuse.nrm;
     // statistics of the result for the BatchNorm that follows (never on a backward pass: those are the paired / collected ones)
     const bool want_stats = g_fuse.stats && ep.act == MOVAE_ACT_NONE && !g_pair_collect;
-    if (want_stats && S == 1) a.stats = fuse_stats_claim((long)gx * T2<BM, BN>::WM, g.Nn);
+    // BatchNorm side products through the LDS tile epilogue (one partial pair per block) where its 16-byte pieces apply
+    a.side_lds = (g.Nn % 4 == 0 && ((reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(ep.bias) |
+                                     reinterpret_cast<uintptr_t>(g_fuse.bn_y)) & 15) == 0) ? 1 : 0;
+    const int slots = a.side_lds ? 1 : T2<BM, BN>::WM;
+    if (want_stats && S == 1) a.stats = fuse_stats_claim((long)gx * slots, g.Nn);
     // the result is a fused BatchNorm's output gradient: its backward sums from the epilogue (unsplit) or from the reduce
     BnBwd rbb{};
     int rbb_rpb = 0;
@@ -1342,7 +1343,7 @@ int launch_fwd2(const float* X, const float* W, float* Y, const Geom& g, const E
         const long rpg = M / g_fuse.bn_groups;
         if (S == 1) {
             if (M % g_fuse.bn_groups == 0 && rpg % BM == 0) {
-                const long ppg = rpg / BM * T2<BM, BN>::WM;
+                const long ppg = rpg / BM * slots;
                 if (float* part = fuse_bn_claim(ppg, g.Nn))
                     a.bb = BnBwd{g_fuse.bn_y, g_fuse.bn_scale, g_fuse.bn_shift, g_fuse.bn_slope, part, (int)rpg, (int)ppg};
             }
@@ -1459,7 +1460,10 @@ int launch_bwd2(const float* X, const float* W, float* Y, const Geom& g, const E
     a.nrm = g_fuse.nrm;
     a.stats_gx = gx;
     const bool want_stats = g_fuse.stats && ep.act == MOVAE_ACT_NONE && !g_pair_collect;
-    if (want_stats && Sreal == 1) a.stats = fuse_stats_claim((long)ncls * gx * T2<BM, BN>::WM, g.Nn);
+    a.side_lds = (g.Nn % 4 == 0 && ((reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(ep.bias) |
+                                     reinterpret_cast<uintptr_t>(g_fuse.bn_y)) & 15) == 0) ? 1 : 0;  // (see launch_fwd2)
+    const int slots = a.side_lds ? 1 : T2<BM, BN>::WM;
+    if (want_stats && Sreal == 1) a.stats = fuse_stats_claim((long)ncls * gx * slots, g.Nn);
     BnBwd rbb{};
     int rbb_rpb = 0;
     if (g_fuse.bn_y && ep.act == MOVAE_ACT_NONE && !ep.bias) {
@@ -1468,7 +1472,7 @@ int launch_bwd2(const float* X, const float* W, float* Y, const Geom& g, const E
             // equally large classes (even output grid) and whole row blocks per group and class
             const long rows_c = pix / ncls / g_fuse.bn_groups;
             if (g.Ho % s == 0 && g.Wo % s == 0 && pix % ((long)ncls * g_fuse.bn_groups) == 0 && rows_c % BM == 0) {
-                const long ppg = (long)ncls * (rows_c / BM) * T2<BM, BN>::WM;
+                const long ppg = (long)ncls * (rows_c / BM) * slots;
                 if (float* part = fuse_bn_claim(ppg, g.Nn))
                     a.bb = BnBwd{g_fuse.bn_y, g_fuse.bn_scale, g_fuse.bn_shift, g_fuse.bn_slope, part, (int)(pix / g_fuse.bn_groups), (int)ppg};
             }
