@@ -214,60 +214,92 @@ __global__ __launch_bounds__(256) void tc_fwd_k(const float* __restrict__ z, con
     }
 }
 
-__global__ void tc_mean_k(const float* __restrict__ rows, float* __restrict__ out, int B) {
-    const int q = threadIdx.x;
-    if (q >= 3) return;
-    double s = 0.0;
-    for (int i = 0; i < B; ++i) s += rows[i * 3 + q];
-    out[q] = (float)(s / B);
-}
-
-// dz[i][d] : block per i, thread per d
-__global__ void tc_bwd_dz(const float* __restrict__ z, const float* __restrict__ mu, const float* __restrict__ lv,
-                          const float* __restrict__ liw, const float* __restrict__ lse_joint,
-                          const float* __restrict__ lse_marg, const float* __restrict__ g, float* __restrict__ dz, int B,
-                          int D) {
-    const int i = blockIdx.x;
-    const float gmi = g[0] / B, cq = (g[1] - g[0]) / B, cp = (g[2] - g[1]) / B, gk = g[2] / B;
-    const float lqz = lse_joint[i];
-    for (int d = threadIdx.x; d < D; d += blockDim.x) {
-        const float zi = z[(long)i * D + d], lm = lse_marg[(long)i * D + d];
-        float acc = 0.f;
-        for (int j = 0; j < B; ++j) {
-            const float l = lv[(long)j * D + d];
-            const float iv = expf(-l), df = zi - mu[(long)j * D + d];
-            const float m = -0.5f * (LOG_2PI + l) - 0.5f * (df * df * iv);
-            const float P = expf(lse_joint[B + (long)i * B + j] - lqz);
-            const float Q = expf(m + liw[(long)i * B + j] - lm);
-            const float wgt = cq * P + cp * Q + (j == i ? gmi : 0.f);
-            acc += wgt * (-df * iv);
-        }
-        dz[(long)i * D + d] = acc + gk * zi;
+__global__ void tc_mean_k(const float* __restrict__ rows, float* __restrict__ out, int B) {  // one wave
+    // (three threads walking the B rows one dependent load at a time took ~10 us of L2 round trips for 96 numbers)
+    const int lane = threadIdx.x;
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int i = lane; i < B; i += 64)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) s[q] += (double)rows[i * 3 + q];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s[q] += __shfl_xor(s[q], off, 64);
+        if (lane == 0) out[q] = (float)(s[q] / B);
     }
 }
 
-// dmu[j][d], dlv[j][d] : block per j, thread per d
+// dz[i][d] : block per i; thread (d, jl): the B rows of the inner sum are dealt to JL = blockDim.x / DT row lanes (a thread per d
+// alone walks B x ~80 dependent VALU instructions with 64 waves on the whole chip: 8 us for 0.5 MFLOP), folded through LDS in
+// row-lane order.  DT = threads along d (host: a power of two <= 256).
+__global__ void tc_bwd_dz(const float* __restrict__ z, const float* __restrict__ mu, const float* __restrict__ lv,
+                          const float* __restrict__ liw, const float* __restrict__ lse_joint,
+                          const float* __restrict__ lse_marg, const float* __restrict__ g, float* __restrict__ dz, int B,
+                          int D, int DT) {
+    extern __shared__ float red[];  // [JL][DT]
+    const int i = blockIdx.x, dl = threadIdx.x % DT, jl = threadIdx.x / DT, JL = blockDim.x / DT;
+    const float gmi = g[0] / B, cq = (g[1] - g[0]) / B, cp = (g[2] - g[1]) / B, gk = g[2] / B;
+    const float lqz = lse_joint[i];
+    for (int d0 = 0; d0 < D; d0 += DT) {
+        const int d = d0 + dl;
+        float acc = 0.f;
+        if (d < D) {
+            const float zi = z[(long)i * D + d], lm = lse_marg[(long)i * D + d];
+            for (int j = jl; j < B; j += JL) {
+                const float l = lv[(long)j * D + d];
+                const float iv = expf(-l), df = zi - mu[(long)j * D + d];
+                const float m = -0.5f * (LOG_2PI + l) - 0.5f * (df * df * iv);
+                const float P = expf(lse_joint[B + (long)i * B + j] - lqz);
+                const float Q = expf(m + liw[(long)i * B + j] - lm);
+                const float wgt = cq * P + cp * Q + (j == i ? gmi : 0.f);
+                acc += wgt * (-df * iv);
+            }
+        }
+        red[jl * DT + dl] = acc;
+        __syncthreads();
+        if (jl == 0 && d < D) {
+            float s = 0.f;
+            for (int q = 0; q < JL; ++q) s += red[q * DT + dl];
+            dz[(long)i * D + d] = s + gk * z[(long)i * D + d];
+        }
+        __syncthreads();
+    }
+}
+
+// dmu[j][d], dlv[j][d] : block per j; thread (d, il) as above
 __global__ void tc_bwd_dparams(const float* __restrict__ z, const float* __restrict__ mu, const float* __restrict__ lv,
                                const float* __restrict__ liw, const float* __restrict__ lse_joint,
                                const float* __restrict__ lse_marg, const float* __restrict__ g, float* __restrict__ dmu,
-                               float* __restrict__ dlv, int B, int D) {
-    const int j = blockIdx.x;
+                               float* __restrict__ dlv, int B, int D, int DT) {
+    extern __shared__ float red[];  // [2][IL][DT]
+    const int j = blockIdx.x, dl = threadIdx.x % DT, il = threadIdx.x / DT, IL = blockDim.x / DT;
     const float gmi = g[0] / B, cq = (g[1] - g[0]) / B, cp = (g[2] - g[1]) / B;
-    for (int d = threadIdx.x; d < D; d += blockDim.x) {
-        const float l = lv[(long)j * D + d], mj = mu[(long)j * D + d];
-        const float iv = expf(-l);
+    for (int d0 = 0; d0 < D; d0 += DT) {
+        const int d = d0 + dl;
         float am = 0.f, al = 0.f;
-        for (int i = 0; i < B; ++i) {
-            const float df = z[(long)i * D + d] - mj;
-            const float m = -0.5f * (LOG_2PI + l) - 0.5f * (df * df * iv);
-            const float P = expf(lse_joint[B + (long)i * B + j] - lse_joint[i]);
-            const float Q = expf(m + liw[(long)i * B + j] - lse_marg[(long)i * D + d]);
-            const float wgt = cq * P + cp * Q + (j == i ? gmi : 0.f);
-            am += wgt * (df * iv);
-            al += wgt * (-0.5f + 0.5f * df * df * iv);
+        if (d < D) {
+            const float l = lv[(long)j * D + d], mj = mu[(long)j * D + d];
+            const float iv = expf(-l);
+            for (int i = il; i < B; i += IL) {
+                const float df = z[(long)i * D + d] - mj;
+                const float m = -0.5f * (LOG_2PI + l) - 0.5f * (df * df * iv);
+                const float P = expf(lse_joint[B + (long)i * B + j] - lse_joint[i]);
+                const float Q = expf(m + liw[(long)i * B + j] - lse_marg[(long)i * D + d]);
+                const float wgt = cq * P + cp * Q + (j == i ? gmi : 0.f);
+                am += wgt * (df * iv);
+                al += wgt * (-0.5f + 0.5f * df * df * iv);
+            }
         }
-        dmu[(long)j * D + d] = am;
-        dlv[(long)j * D + d] = al;
+        red[il * DT + dl] = am;
+        red[(IL + il) * DT + dl] = al;
+        __syncthreads();
+        if (il == 0 && d < D) {
+            float s1 = 0.f, s2 = 0.f;
+            for (int q = 0; q < IL; ++q) s1 += red[q * DT + dl], s2 += red[(IL + q) * DT + dl];
+            dmu[(long)j * D + d] = s1;
+            dlv[(long)j * D + d] = s2;
+        }
+        __syncthreads();
     }
 }
 
@@ -353,11 +385,17 @@ int movae_tc_decomp_bwd(const float* z, const float* mu, const float* log_var, c
     MOVAE_CHECK_ARG(z && mu && log_var && log_iw && lse_joint && lse_marg && g && dz && dmu && dlog_var,
                     "movae_tc_decomp_bwd: null pointer");
     MOVAE_CHECK_ARG(b > 1 && d > 0, "movae_tc_decomp_bwd: bad shape");
-    const int th = d >= 256 ? 256 : (d >= 128 ? 128 : 64);
-    hipLaunchKernelGGL(tc_bwd_dz, dim3(b), dim3(th), 0, (hipStream_t)stream, z, mu, log_var, log_iw, lse_joint, lse_marg, g, dz, b, d);
+    // DT threads along d, 1024 / DT row lanes (at most one per row)
+    int dt = 32;
+    while (dt < d && dt < 256) dt *= 2;
+    int lanes = 1024 / dt;
+    while (lanes > 1 && lanes > b) lanes /= 2;
+    const int th = dt * lanes;
+    hipLaunchKernelGGL(tc_bwd_dz, dim3(b), dim3(th), (size_t)th * sizeof(float), (hipStream_t)stream, z, mu, log_var, log_iw, lse_joint,
+                       lse_marg, g, dz, b, d, dt);
     MOVAE_CHECK_LAUNCH("tc_bwd_dz");
-    hipLaunchKernelGGL(tc_bwd_dparams, dim3(b), dim3(th), 0, (hipStream_t)stream, z, mu, log_var, log_iw, lse_joint, lse_marg, g,
-                       dmu, dlog_var, b, d);
+    hipLaunchKernelGGL(tc_bwd_dparams, dim3(b), dim3(th), (size_t)2 * th * sizeof(float), (hipStream_t)stream, z, mu, log_var, log_iw,
+                       lse_joint, lse_marg, g, dmu, dlog_var, b, d, dt);
     MOVAE_CHECK_LAUNCH("tc_bwd_dparams");
     return MOVAE_OK;
 }
