@@ -34,7 +34,9 @@ struct AdamTable {
     float* m[ADAM_MT];
     float* v[ADAM_MT];
     unsigned n[ADAM_MT];
+    unsigned first[ADAM_MT + 1];  // first block of tensor t in the flat grid: a block owns ADAM_BLK consecutive elements of ONE tensor
 };
+constexpr unsigned ADAM_BLK = 4096;  // four 16-byte pieces per thread and array: sixteen loads in flight per thread
 
 __device__ __forceinline__ void adam_one(float& pi, float gi, float& mi, float& vi, float lr, float b1, float b2, float eps,
                                          float wd, int decoupled, float step_size, float bc2_sqrt) {
@@ -48,13 +50,15 @@ __device__ __forceinline__ void adam_one(float& pi, float gi, float& mi, float& 
     pi = pi - step_size * (mi / denom);
 }
 
-// grid = (blocks per tensor, tensors).  hyper (optional) = device {step, lr}: the step counter has already been
-// incremented by adam_tick on the same stream, so a captured hipGraph replays with a live counter / learning rate.
-__global__ __launch_bounds__(256) void adam_multi_k(AdamTable tab, float lr, float b1, float b2, float eps, float wd, int decoupled,
-                                                    float bc1, float bc2_sqrt, const float* __restrict__ hyper) {
-    const int t = blockIdx.y;
-    const unsigned n = tab.n[t];
-    if ((unsigned)blockIdx.x * 1024u >= n) return;
+// A flat grid of ceil(n_t / ADAM_BLK) blocks per tensor (a 2-D grid of <= 256 blocks x tensors left the two 4-8 M element tensors of
+// C5 to 256 blocks -- one per CU, 3.4 TB/s -- and launched mostly empty blocks for the small ones).  hyper (optional) = device
+// {step, lr}: the step counter has already been incremented by adam_tick on the same stream, so a captured hipGraph replays with a
+// live counter / learning rate.
+__global__ __launch_bounds__(256) void adam_multi_k(AdamTable tab, int cnt, float lr, float b1, float b2, float eps, float wd,
+                                                    int decoupled, float bc1, float bc2_sqrt, const float* __restrict__ hyper) {
+    int t = 0;
+    while (t + 1 < cnt && blockIdx.x >= tab.first[t + 1]) ++t;  // (uniform: <= 64 scalar compares)
+    const unsigned n = tab.n[t], base = (blockIdx.x - tab.first[t]) * ADAM_BLK;
     if (hyper) {
         const double step = (double)hyper[0];
         lr = hyper[1];
@@ -68,9 +72,31 @@ __global__ __launch_bounds__(256) void adam_multi_k(AdamTable tab, float lr, flo
     float* __restrict__ v = tab.v[t];
     const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
                        reinterpret_cast<uintptr_t>(v)) & 15) == 0;
-    const unsigned stride = gridDim.x * 1024u;
-    for (unsigned base = blockIdx.x * 1024u; base < n; base += stride) {
-        const unsigned i = base + threadIdx.x * 4;
+    if (vec && base + ADAM_BLK <= n) {  // a whole block of 16-byte pieces: every load ahead of the arithmetic
+        f32x4 pv[4], mv[4], vv[4], gv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned i = base + u * 1024u + threadIdx.x * 4;
+            pv[u] = *reinterpret_cast<f32x4*>(p + i), mv[u] = *reinterpret_cast<f32x4*>(m + i), vv[u] = *reinterpret_cast<f32x4*>(v + i);
+            gv[u] = *reinterpret_cast<const f32x4*>(g + i);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned i = base + u * 1024u + threadIdx.x * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float pj = pv[u][j], mj = mv[u][j], vj = vv[u][j];
+                adam_one(pj, gv[u][j], mj, vj, lr, b1, b2, eps, wd, decoupled, step_size, bc2_sqrt);
+                pv[u][j] = pj; mv[u][j] = mj; vv[u][j] = vj;
+            }
+            *reinterpret_cast<f32x4*>(p + i) = pv[u];
+            *reinterpret_cast<f32x4*>(m + i) = mv[u];
+            *reinterpret_cast<f32x4*>(v + i) = vv[u];
+        }
+        return;
+    }
+    for (unsigned u = 0; u < 4; ++u) {
+        const unsigned i = base + u * 1024u + threadIdx.x * 4;
         if (i >= n) break;
         if (vec && i + 4 <= n) {
             f32x4 pv = *reinterpret_cast<f32x4*>(p + i), mv = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
@@ -191,19 +217,19 @@ int movae_adam_multi(int n_tensors, float* const* p, const float* const* g, floa
     for (int t0 = 0; t0 < n_tensors; t0 += ADAM_MT) {
         AdamTable tab;
         const int cnt = n_tensors - t0 < ADAM_MT ? n_tensors - t0 : ADAM_MT;
-        size_t nmax = 0;
+        unsigned nblk = 0;
         for (int i = 0; i < cnt; ++i) {
             MOVAE_CHECK_ARG(p[t0 + i] && g[t0 + i] && m[t0 + i] && v[t0 + i], "movae_adam_multi: null tensor");
             MOVAE_CHECK_ARG(numel[t0 + i] > 0 && numel[t0 + i] < 0xffffffffUL, "movae_adam_multi: tensor size out of range");
             tab.p[i] = p[t0 + i]; tab.g[i] = g[t0 + i]; tab.m[i] = m[t0 + i]; tab.v[i] = v[t0 + i];
             tab.n[i] = (unsigned)numel[t0 + i];
-            if (numel[t0 + i] > nmax) nmax = numel[t0 + i];
+            tab.first[i] = nblk;
+            nblk += (unsigned)((numel[t0 + i] + ADAM_BLK - 1) / ADAM_BLK);
         }
         for (int i = cnt; i < ADAM_MT; ++i) { tab.p[i] = nullptr; tab.g[i] = nullptr; tab.m[i] = nullptr; tab.v[i] = nullptr; tab.n[i] = 0; }
-        size_t bx = (nmax + 1023) / 1024;
-        if (bx > 256) bx = 256;
-        hipLaunchKernelGGL(adam_multi_k, dim3((unsigned)bx, (unsigned)cnt), dim3(256), 0, (hipStream_t)stream, tab, lr, beta1, beta2,
-                           eps, weight_decay, decoupled_wd, bc1, bc2_sqrt, (const float*)hyper_dev);
+        for (int i = cnt; i <= ADAM_MT; ++i) tab.first[i] = nblk;
+        hipLaunchKernelGGL(adam_multi_k, dim3(nblk), dim3(256), 0, (hipStream_t)stream, tab, cnt, lr, beta1, beta2, eps, weight_decay,
+                           decoupled_wd, bc1, bc2_sqrt, (const float*)hyper_dev);
         MOVAE_CHECK_LAUNCH("adam_multi");
     }
     return MOVAE_OK;
