@@ -1,15 +1,16 @@
-// conv_thin.h -- direct (VALU) kernels for the 3-channel image ends of the networks (included inside
-// conv_igemm.hip's anonymous namespace).
+// conv_thin.h -- kernels for the 3-channel image ends of the networks (included inside conv_igemm.hip's anonymous namespace).
 //
-// A 32-wide MFMA tile wastes 29/32 of its rows or columns when one side of the contraction has 3
-// channels (first encoder conv, last decoder conv and their gradients), and those layers touch the largest
-// activation tensors of the step, so they are HBM-bound: each kernel below streams its big operand once
-// with one output pixel per thread, keeps the tiny weight matrix in LDS (broadcast ds_read_b128) and the
-// per-pixel accumulators in registers.
-//   thin_in  : reduction channels Cr <= 4, NN (32|64) outputs per thread         conv1 fwd, last-conv dgrad
-//   thin_out : Nn <= 4 outputs, reduction channels Cr % 4 == 0                    last-conv fwd
-//   thin_wgrad: one side of dW has <= 4 channels; (tap, wide-channel) per thread, pixels split over
-//               blocks, deterministic slab reduce                                 conv1 / last-conv wgrad
+// Used as a plain GEMM dimension, 3 channels waste 29/32 of a 32-wide MFMA tile (first encoder conv, last decoder conv / transposed
+// conv and their gradients), and those layers touch the largest activation tensors of the step, so they are HBM-bound.  Two
+// generations live here:
+//  * MFMA forms (round 2, preferred): the thin side becomes a GEMM dimension of (tap, channel) pairs -- 27 or 48 columns --
+//      thin_in_mfma_k    3 reduction channels -> 32 k outputs: K = taps * 3, input rows staged once in LDS     conv1 fwd, last-conv dgrad
+//      thin_out_mfma_k   C -> 3, 3x3 stride 1: P[input pixel][tap, co] = X W, then a 27-term gather per output pixel   last-conv fwd
+//      thin_outT_mfma_k  C -> 3, 4x4 stride 2 transposed: the same with 48 columns and a 2 x 2 parity gather   VQ last layer fwd
+//      thin_wgrad_mfma_k dW[c][tap, j] = sum over pixels, two pixels per MFMA, persistent blocks              conv1 / last-conv wgrad
+//  * VALU forms (round 1; the shapes the MFMA forms do not take): one output pixel per thread, the tiny weight matrix in LDS
+//    (broadcast ds_read_b128 -- whose return bandwidth bounds them), per-pixel accumulators in registers --
+//      thin_in_k, thin_out_fwd_k / thin_out_tile_k, thin_wgrad_k / thin_wgrad_tiled_k / thin_wgrad_sweep_k
 #pragma once
 
 namespace thin {
