@@ -1167,7 +1167,8 @@ int launch_wgrad(const float* S, const float* Bg, float* const* dW, int G, long 
         return (g_last_kernel = "igemm2_wgrad<64,64>", v2::launch_wgrad2<64, 64>(S, Bg, dW, G, s_gs, b_gs, g, (int)Kl, accumulate, ws, ws_bytes, st, cs));
     }
     if (thin::thin_wgrad_ok(g) && ws)
-        return (g_last_kernel = "thin_wgrad", thin::launch_thin_wgrad_grouped(S, Bg, dW, G, s_gs, b_gs, g, (int)Kl, accumulate, ws, ws_bytes, st));
+        return (g_last_kernel = "thin_wgrad",
+                thin::launch_thin_wgrad_grouped(S, Bg, dW, G, s_gs, b_gs, g, (int)Kl, accumulate, ws, ws_bytes, st, colsum_S, colsum_done));
     MOVAE_NO_NORM("generic wgrad");
     for (int i = 0; i < G; ++i)
         if (int rc = launch_wgrad1(S + i * s_gs, Bg + i * b_gs, dW[i], g, accumulate, ws, ws_bytes, st)) return rc;

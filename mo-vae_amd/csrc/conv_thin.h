@@ -1002,7 +1002,9 @@ __global__ __launch_bounds__(256) void thin_wgrad_mfma_k(const float* __restrict
                                                          float* __restrict__ slab, int Hw, int Ww, int Cw, int Ht, int Wt,
                                                          int stride, int pad, int TH, int TW, int tiles_h, int tiles_w,
                                                          int Cs, int Cb, long wide_gs, long thin_gs, long slab_gs, Norm nrm, int ntiles,
-                                                         FastDiv fd_tw, FastDiv fd_bw) {
+                                                         FastDiv fd_tw, FastDiv fd_bw, int cs_on, long row_stride) {
+    // cs_on (REV, the two images equally large: host): the column sums of the thin operand -- the bias gradient when it is dy --
+    // ride along: the blockIdx.y == 0 blocks add up the pixels their tiles own while they stage them; TC floats behind the slab row
     constexpr int TAPS = KH * KW, NA = TAPS * TC, NT = (NA + 31) / 32;
     static_assert(NT <= 2, "at most 64 columns");
     Wide += blockIdx.z * wide_gs;
@@ -1078,6 +1080,10 @@ __global__ __launch_bounds__(256) void thin_wgrad_mfma_k(const float* __restrict
         nsh = *reinterpret_cast<const f32x4*>(nrm.shift + c0 + q * 4);
     }
     if (t < 8) *reinterpret_cast<f32x4*>(wideT + npix * 32 + t * 4) = f32x4{0.f, 0.f, 0.f, 0.f};  // the zero pixel behind the tile
+    float csum[TC];
+#pragma unroll
+    for (int j = 0; j < TC; ++j) csum[j] = 0.f;
+    const bool cs_here = REV && cs_on && blockIdx.y == 0;
     if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
     // persistent: the block walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and keeps ONE accumulator set -- one fold, one slab
     // row and one reduce input per block instead of per tile (the per-tile epilogue and the 8192-slab reduce were the cost)
@@ -1090,6 +1096,14 @@ __global__ __launch_bounds__(256) void thin_wgrad_mfma_k(const float* __restrict
             if (nrm.scale && (wok >> u & 1)) v = norm_apply(v, nsc, nsh, nrm.slope);
             if (pix < npix) *reinterpret_cast<f32x4*>(wideT + pix * 32 + q * 4) = v;
         }
+        int oy0 = 0, ox0 = 0;  // cs_here: the tile's first owned thin pixel inside the staged region (rows / columns KH - 1 - pad on)
+        if (cs_here) {
+            int b = tile;
+            const int tw = b % tiles_w;
+            b /= tiles_w;
+            const int th = b % tiles_h;
+            oy0 = min(TH, Hw - th * TH), ox0 = min(TW, Ww - tw * TW);  // owned extent (the image may end inside the tile)
+        }
 #pragma unroll
         for (int u = 0; u < TPF; ++u) {
             const int pix = t + 256 * u;
@@ -1097,6 +1111,14 @@ __global__ __launch_bounds__(256) void thin_wgrad_mfma_k(const float* __restrict
 #pragma unroll
             for (int j = 0; j < TC; ++j) v[j] = tv[u][j];
             if (pix < BH * BW) *reinterpret_cast<f32x4*>(thinF + pix * 4) = v;
+            if (cs_here) {
+                const int r = fdiv(pix, fd_bw), c = pix - r * BW;
+                const int ry = r - (KH - 1 - pad), rx = c - (KW - 1 - pad);  // position inside the tile
+                if (pix < BH * BW && ry >= 0 && ry < oy0 && rx >= 0 && rx < ox0) {
+#pragma unroll
+                    for (int j = 0; j < TC; ++j) csum[j] += tv[u][j];
+                }
+            }
         }
         if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);  // in flight under this tile's MFMA loop
         __syncthreads();
@@ -1128,7 +1150,19 @@ __global__ __launch_bounds__(256) void thin_wgrad_mfma_k(const float* __restrict
         for (int r = 0; r < 16; ++r) wideT[((wave * NT + u) * 16 + r) * 64 + lane] = acc[u][r];
     __syncthreads();
     const int N = TAPS * Cb;
-    float* out = slab + (long)blockIdx.x * Cs * N;
+    float* out = slab + (long)blockIdx.x * row_stride;
+    if (cs_here) {  // wave sums by shuffle, the four waves in fixed order
+        __shared__ float csr[4][TC];
+#pragma unroll
+        for (int j = 0; j < TC; ++j) {
+            float v = csum[j];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            if (lane == 0) csr[wave][j] = v;
+        }
+        __syncthreads();
+        if (t < TC) out[(long)Cs * N + t] = (csr[0][t] + csr[1][t]) + (csr[2][t] + csr[3][t]);
+    }
     for (int idx = t; idx < NT * 1024; idx += 256) {
         const int u = idx >> 10, r = (idx >> 6) & 15, ln = idx & 63;
         const int n = u * 32 + (ln & 31);
@@ -1316,10 +1350,12 @@ int launch_thin_wgrad(const float* S, const float* Bg, float* dW, const WGeom& g
 
 // G cotangent groups: one sweep launch (blockIdx.z = group) when the sweep kernel applies, else group by group
 int launch_thin_wgrad_grouped(const float* S, const float* Bg, float* const* dW, int G, long s_gs, long b_gs, const WGeom& g, int K,
-                              int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+                              int accumulate, void* ws, size_t ws_bytes, hipStream_t st, float* const* colsum = nullptr,
+                              bool* colsum_done = nullptr);
 
 int launch_thin_wgrad_impl(const float* S, const float* Bg, float* const* dW, int G, long s_gs, long b_gs, const WGeom& g, int K,
-                           int accumulate, void* ws, size_t ws_bytes, hipStream_t st, bool* handled) {
+                           int accumulate, void* ws, size_t ws_bytes, hipStream_t st, bool* handled, float* const* colsum = nullptr,
+                           bool* colsum_done = nullptr) {
     const int M = g.Cs, N = g.KH * g.KW * g.Cb;
     *handled = true;
     const bool thin_small = g.Cs <= 4;
@@ -1370,11 +1406,17 @@ int launch_thin_wgrad_impl(const float* S, const float* Bg, float* const* dW, in
                 const long cap = persist / ((long)(wide / 32) * G) > 64 ? persist / ((long)(wide / 32) * G) : 64;
                 if (nblk > cap) nblk = cap;
             }
-            const size_t per1 = (size_t)M * N * sizeof(float);
+            // column sums of S (the bias gradient when S is dy) from the MFMA kernel: S is its thin operand, the images equally large
+            // (from 512 k pixels: the three extra floats per slab row take the reduce off its 16-byte path, which costs a small layer
+            // -- C2's last conv: +5 us -- more than the stand-alone column sum it saves; C5's last conv: 34 us saved)
+            bool cs_on = use_mfma && thin_small && colsum && g.Hs == g.Hb && g.Ws == g.Wb && (long)K >= (1L << 19);
+            for (int i = 0; cs_on && i < G; ++i) cs_on = colsum[i] != nullptr;
+            const long row = (long)M * N + (cs_on ? M : 0);  // floats per slab row
+            const size_t per1 = (size_t)row * sizeof(float);
             if (lds_bytes(TH, TW) <= 60 * 1024 && ntiles <= 0x7fffffffL && per1 * (size_t)nblk * G <= ws_bytes) {
                 float* slab = static_cast<float*>(ws);
                 const dim3 grid((unsigned)nblk, wide / 32, G);
-                const long slab_gs = (long)nblk * M * N;
+                const long slab_gs = (long)nblk * row;
                 const long wide_gs = thin_small ? b_gs : s_gs, thin_gs = thin_small ? s_gs : b_gs;
                 const size_t shb = (size_t)lds_bytes(TH, TW);
                 const float* Wd = thin_small ? Bg : S;
@@ -1394,7 +1436,7 @@ int launch_thin_wgrad_impl(const float* S, const float* Bg, float* const* dW, in
 #define MOVAE_MF(K, REVV)                                                                                                      \
     hipLaunchKernelGGL((thin_wgrad_mfma_k<3, K, K, REVV>), grid, dim3(256), shb, st, Wd, Tn, slab, Hw, Ww, wide, Ht, Wt, g.stride, \
                        g.pad, TH, TW, tiles_h, tiles_w, g.Cs, g.Cb, wide_gs, thin_gs, slab_gs, wide_nrm, (int)ntiles, fastdiv_make(TW),    \
-                       fastdiv_make(thin_small ? TW + g.KW - 1 : (TW - 1) * g.stride + g.KW))
+                       fastdiv_make(thin_small ? TW + g.KW - 1 : (TW - 1) * g.stride + g.KW), cs_on ? 1 : 0, row)
                 if (use_mfma) {
                     if (thin_small) {
                         if (k33) MOVAE_MF(3, true); else MOVAE_MF(4, true);
@@ -1410,8 +1452,10 @@ int launch_thin_wgrad_impl(const float* S, const float* Bg, float* const* dW, in
 #undef MOVAE_MF
                 MOVAE_CHECK_LAUNCH("thin_wgrad_sweep");
                 for (int i = 0; i < G; ++i)
-                    if (int rc = launch_reduce(slab + i * slab_gs, dW[i], (long)M * N, (int)nblk, N, nullptr, 0, 0.f, accumulate, st))
+                    if (int rc = launch_reduce(slab + i * slab_gs, dW[i], (long)M * N, (int)nblk, N, nullptr, 0, 0.f, accumulate, st,
+                                               cs_on ? colsum[i] : nullptr, M))
                         return rc;
+                if (colsum_done) *colsum_done = cs_on;
                 return MOVAE_OK;
             }
         }
@@ -1422,9 +1466,10 @@ int launch_thin_wgrad_impl(const float* S, const float* Bg, float* const* dW, in
 }
 
 int launch_thin_wgrad_grouped(const float* S, const float* Bg, float* const* dW, int G, long s_gs, long b_gs, const WGeom& g, int K,
-                              int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+                              int accumulate, void* ws, size_t ws_bytes, hipStream_t st, float* const* colsum, bool* colsum_done) {
     bool handled = false;
-    if (int rc = launch_thin_wgrad_impl(S, Bg, dW, G, s_gs, b_gs, g, K, accumulate, ws, ws_bytes, st, &handled)) return rc;
+    if (int rc = launch_thin_wgrad_impl(S, Bg, dW, G, s_gs, b_gs, g, K, accumulate, ws, ws_bytes, st, &handled, colsum, colsum_done))
+        return rc;
     if (handled) return MOVAE_OK;
     for (int i = 0; i < G; ++i)
         if (int rc = launch_thin_wgrad(S + i * s_gs, Bg + i * b_gs, dW[i], g, K, accumulate, ws, ws_bytes, st)) return rc;
