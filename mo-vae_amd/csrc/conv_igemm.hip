@@ -678,6 +678,35 @@ __global__ __launch_bounds__(256) void splitk_reduce_wide(const float* __restric
     }
 }
 
+// 8 <= S < 64 slabs over MANY outputs (>= 2^19): a thread owns four consecutive outputs and walks the slabs with four 16-byte loads
+// in flight -- the 16-split-lane kernel above reads 4-byte pieces in 64-byte runs, which is what a few hundred outputs per CU need
+// to fill the chip but half the achievable rate on the 2-10 MB results of the C3-C5 weight gradients (14.4 us for 33 MB of slabs).
+__global__ __launch_bounds__(256) void splitk_reduce_vec(const float* __restrict__ slab, float* __restrict__ out, long total, int S,
+                                                         int N, const float* __restrict__ bias, int act, float slope, int accumulate,
+                                                         float* __restrict__ out2, long n1, ActMul am) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= total) return;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    int z = 0;
+    for (; z + 3 < S; z += 4) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(slab + (long)z * total + i),
+                    a1 = *reinterpret_cast<const f32x4*>(slab + (long)(z + 1) * total + i),
+                    a2 = *reinterpret_cast<const f32x4*>(slab + (long)(z + 2) * total + i),
+                    a3 = *reinterpret_cast<const f32x4*>(slab + (long)(z + 3) * total + i);
+        v += (a0 + a1) + (a2 + a3);
+    }
+    for (; z < S; ++z) v += *reinterpret_cast<const f32x4*>(slab + (long)z * total + i);
+    float* dst = i < n1 ? out + i : out2 + (i - n1);  // (n1 % 4 == 0: a quad never straddles the two)
+    f32x4 o = accumulate ? *reinterpret_cast<const f32x4*>(dst) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float r = v[j];
+        if (bias) r += bias[(i + j) % N];
+        o[j] += actmul_on(am) ? actmul_apply(am, r, i + j) : apply_act(r, act, slope);
+    }
+    *reinterpret_cast<f32x4*>(dst) = o;
+}
+
 // few slabs over many outputs: one thread per output, grid-stride
 __global__ __launch_bounds__(256) void splitk_reduce_flat(const float* __restrict__ slab, float* __restrict__ out, long total,
                                                           int S, int N, const float* __restrict__ bias, int act, float slope,
@@ -802,6 +831,10 @@ inline int launch_reduce(const float* slab, float* out, long n1, int S, int N, c
     if (S >= 64 && total % 4 == 0 && n1 % 4 == 0 && total <= (1L << 20) &&
         ((reinterpret_cast<uintptr_t>(slab) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(out2)) & 15) == 0) {
         hipLaunchKernelGGL(splitk_reduce_wide, dim3(ceil_div(total, 16)), dim3(256), 0, st, slab, out, total, S, N, bias, act,
+                           slope, accumulate, out2, n1, am);
+    } else if (S >= 8 && total >= (1L << 19) && total % 4 == 0 && n1 % 4 == 0 &&
+               ((reinterpret_cast<uintptr_t>(slab) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(out2)) & 15) == 0) {
+        hipLaunchKernelGGL(splitk_reduce_vec, dim3((unsigned)ceil_div(total / 4, 256)), dim3(256), 0, st, slab, out, total, S, N, bias, act,
                            slope, accumulate, out2, n1, am);
     } else if (S >= 8 && total <= (1L << 20)) {
         hipLaunchKernelGGL(splitk_reduce, dim3(ceil_div(total, 16)), dim3(256), 0, st, slab, out, total, S, N, bias, act, slope,
