@@ -823,6 +823,11 @@ const char* g_last_kernel = "";  // movae_bench_last_kernel(): main kernel chose
 int g_force_split = 0;           // movae_bench_force_split(): > 0 pins the split-K factor (tuning sweeps)
 bool g_bench_main_only = false;  // movae_bench_main_kernel_only(): time the MFMA kernel without its epilogue launches
 
+inline long reduce_vec_min() {  // outputs from which the 16-byte reduce serves 8 <= S < 64 (tuning knob)
+    static const long v = getenv("MOVAE_REDUCE_VEC_MIN") ? atol(getenv("MOVAE_REDUCE_VEC_MIN")) : (1L << 19);
+    return v;
+}
+
 inline int launch_reduce(const float* slab, float* out, long n1, int S, int N, const float* bias, int act, float slope,
                          int accumulate, hipStream_t st, float* out2 = nullptr, long n2 = 0, ActMul am = ActMul{nullptr, 0, 0.f, 0, 0, nullptr}) {
     if (g_bench_main_only) return MOVAE_OK;
@@ -832,7 +837,7 @@ inline int launch_reduce(const float* slab, float* out, long n1, int S, int N, c
         ((reinterpret_cast<uintptr_t>(slab) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(out2)) & 15) == 0) {
         hipLaunchKernelGGL(splitk_reduce_wide, dim3(ceil_div(total, 16)), dim3(256), 0, st, slab, out, total, S, N, bias, act,
                            slope, accumulate, out2, n1, am);
-    } else if (S >= 8 && total >= (1L << 19) && total % 4 == 0 && n1 % 4 == 0 &&
+    } else if (S >= 8 && total >= reduce_vec_min() && total % 4 == 0 && n1 % 4 == 0 &&
                ((reinterpret_cast<uintptr_t>(slab) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(out2)) & 15) == 0) {
         hipLaunchKernelGGL(splitk_reduce_vec, dim3((unsigned)ceil_div(total / 4, 256)), dim3(256), 0, st, slab, out, total, S, N, bias, act,
                            slope, accumulate, out2, n1, am);
