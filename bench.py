@@ -140,6 +140,21 @@ def build_workload(cfg, device, seed=0, capturable=False, pool=None):
     return net, opt, agg, a, pool
 
 
+def _fp64_oracle(tr):
+    """The oracle of `tr` in float64 with the same initial values and its own Adam (the yardstick of elbo_check)."""
+    from collections import OrderedDict
+
+    from oracle.step import OracleTrainer
+
+    t64 = OracleTrainer(tr.cfg, seed=0, agg=tr.agg)
+    with torch.no_grad():
+        for k, v in tr.sd.items():
+            t64.sd[k] = v.detach().double().requires_grad_(v.requires_grad) if v.is_floating_point() else v.detach().clone()
+    t64.params = OrderedDict((n, t64.sd[n]) for n in tr.params)
+    t64.opt = torch.optim.Adam(list(t64.params.values()), lr=1e-3)
+    return t64
+
+
 def cpu_baseline(cfg, seconds, device=None, check_steps=20):
     """The CPU oracle ("port" of the reference step, oracle/step.py) timed on this box's host cores; with `device`, also the
     ELBO check: a fresh HIP model and the oracle take the same `check_steps` optimisation steps (same init, same batches, same
@@ -166,16 +181,28 @@ def cpu_baseline(cfg, seconds, device=None, check_steps=20):
 
         BetaTCVAE.num_iter = 0
         net, opt, agg, a, _ = build_workload(cfg, device, seed=0, pool=0)
-        hip = ora = None
+        hip = ora = ora64 = None
+        # the yardstick: the same oracle in float64, stepped alongside.  A fp32 trajectory is chaotic in its small components
+        # (the weighted KL term): what two correct fp32 runs may differ by is what the fp32 oracle differs from float64 by.
+        t64 = _fp64_oracle(tr) if cfg["arch"] in ("vae", "betatc_vae") else None  # (VQ: float64 quantises near-tied rows differently)
         for i in range(check_steps):
             if need_eps:
                 net.eps_override = es[i % nb].to(device)
             ld, _ = train_step(net, xs[i % nb].to(device), opt, agg, a)
-            hip = {k: float(v) for k, v in ld.items()}
+            hip = {k: v.detach().item() for k, v in ld.items()}
             ora = tr.step(xs[i % nb], es[i % nb])
+            if t64 is not None:
+                ora64 = t64.step(xs[i % nb].double(), es[i % nb].double() if es[i % nb] is not None else None)
         rel = {k: abs(hip[k] - ora[k]) / max(abs(ora[k]), 1e-12) for k in ora}
-        check = dict(steps=check_steps, hip_losses=hip, oracle_losses=ora, max_rel_diff=max(rel.values()),
+        check = dict(steps=check_steps, hip_losses=hip, oracle_losses=ora, max_rel_diff=max(rel.values()), rel_diff=rel,
                      note="same init / batches / eps on both sides; eager HIP step vs oracle/step.py")
+        if ora64 is not None:
+            own = {k: abs(ora[k] - ora64[k]) / max(abs(ora64[k]), 1e-12) for k in ora}
+            lim = {k: max(1e-3, 4.0 * own[k]) for k in ora}
+            check.update(oracle_fp64_losses=ora64, oracle_fp32_vs_fp64_rel=own, limit_rel=lim,
+                         within_limit=all(rel[k] <= lim[k] for k in ora),
+                         yardstick="limit = max(1e-3, 4 x |fp32 oracle - fp64 oracle|) per component, relative "
+                                   "(tests/test_hip_parity_full.py::trajectory_limits)")
         del net, opt
         BetaTCVAE.num_iter = 0
         tr = OracleTrainer(ocfg, seed=0, agg=cfg["agg"])
@@ -426,6 +453,7 @@ def main():
     final_loss = float(ld["total_loss"].item())
 
     roofline = None
+    issued_gflop = issued_gflop_x = None
     if want_roofline:
         live = graphed is not None and len(graphed.calls) > 0
         if live:
@@ -440,6 +468,7 @@ def main():
         rows = [r for r in all_rows if _base(r["call"]) in CONV_CALLS or r["call"] in PAIR_CALLS]
         tot_us = sum(r["us"] for r in rows)
         tot_gf = sum(r["gflop"] for r in rows)
+        issued_gflop, issued_gflop_x = tot_gf, sum(r.get("gflop_executed", 0.0) for r in rows)
         # group the main-kernel timings by kernel symbol (the way rocprofv3 --stats does) and report the one with
         # the largest time per step; the whole conv family (all kernels + their epilogue launches) is given beside it
         groups = {}
@@ -495,6 +524,12 @@ def main():
                                         "ms_per_step_median": elapsed / args.steps * 1e3, "ms_per_step_max": ts[-1] / args.steps * 1e3},
                        "distinct_batches": len(pool),
                        "step_gflop": cfg["flops_per_img"] * cfg["batch"] / 1e9,
+                       "step_gflop_note": ("step_gflop is SURVEY 8d's nominal formula ((1+2K) F_s + 3 F_t with K = every loss); "
+                                           "step_gflop_issued sums the nominal FLOPs of the conv-family calls the step really makes "
+                                           "(a loss with no path to the features costs no pull-back: K_eff < K for the VQ archs), "
+                                           "step_gflop_issued_executed_taps counts only taps that meet data -- divide THOSE by ms_per_step"),
+                       "step_gflop_issued": round(issued_gflop, 3) if issued_gflop is not None else None,
+                       "step_gflop_issued_executed_taps": round(issued_gflop_x, 3) if issued_gflop_x is not None else None,
                        "parity": ("fp32 end to end (the reference's arithmetic; BASELINE's bf16 leg is not built); models / losses / "
                                   "MGDA / Aligned-MTL pinned by golden vectors of the reference, UPGrad + mtl_backward restate torchjd "
                                   "(absent: docstring KAT, unit-weights invariant, scipy cross-check); element-wise vs the oracle at "

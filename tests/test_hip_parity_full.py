@@ -171,10 +171,18 @@ class masked:
             assert self.k == len(self.masks), f"the oracle applied {self.k} LeakyReLUs, the HIP path recorded {len(self.masks)}"
 
 
+#: Two correct fp32 evaluations put a handful of the ~1.6e7 pre-activations of a step on different sides of the LeakyReLU kink
+#: (measured: C1 3, C2 5, C5 6 -- values within fp32 rounding distance of zero).  The fp64 yardstick is evaluated on the HIP step's
+#: sides, so the COUNT has to be bounded too: a kernel bug that flipped thousands would otherwise be absorbed by the mask.
+MAX_KINK_FLIPS = 32
+
+
 def _kink_report(hip_masks, ora_masks, what):
     n = sum(int((a != b).sum()) for a, b in zip(hip_masks, ora_masks))
     tot = sum(a.numel() for a in hip_masks)
     print(f"[{what}] {n} of {tot} pre-activations fell on different sides of the LeakyReLU kink in the HIP step and the fp32 oracle")
+    assert n <= max(MAX_KINK_FLIPS, int(2e-6 * tot)), (
+        f"{what}: {n} of {tot} pre-activations on different sides of the LeakyReLU kink (fp32 rounding explains <= {MAX_KINK_FLIPS})")
     return n
 
 
@@ -331,11 +339,49 @@ def test_full_size_aggregated_step_matches_oracle(tag, gpu_device, monkeypatch):
 
 EPOCH_STEPS = int(os.environ.get("MOVAE_TEST_EPOCH_STEPS", "196"))  # ceil(50000 / 256): one CIFAR-10 epoch at bs 256
 
+#: the oracle trajectories (fp32 and fp64) are the same for both launch modes: computed once per process
+_ORACLE_TRAJ = {}
+
+
+def _fp64_stepper(tr):
+    """_fp64_twin with an optimizer bound to the float64 parameters (the twin's constructor made one for its own fp32 init)."""
+    t64 = _fp64_twin(tr)
+    t64.opt = torch.optim.Adam(list(t64.params.values()), lr=1e-3)
+    return t64
+
+
+def _oracle_trajectories(tr, xs, eps_list, steps):
+    """(keys, fp32 oracle history [steps, K+1], fp64 oracle history): OracleTrainer.step on the same batches and noise."""
+    key = (steps, len(xs))
+    if key not in _ORACLE_TRAJ:
+        t64 = _fp64_stepper(tr)
+        keys, h32, h64 = None, [], []
+        for i in range(steps):
+            ol = tr.step(xs[i % len(xs)], eps_list[i])
+            keys = keys or list(ol.keys())
+            h32.append([ol[k] for k in keys])
+            o64 = t64.step(xs[i % len(xs)].double(), eps_list[i].double())
+            assert list(o64.keys()) == keys
+            h64.append([o64[k] for k in keys])
+        _ORACLE_TRAJ[key] = (keys, np.asarray(h32, dtype=np.float64), np.asarray(h64, dtype=np.float64))
+    return _ORACLE_TRAJ[key]
+
+
+def trajectory_limits(ora32, ora64, floor=1e-3, factor=4.0):
+    """Per component: the relative tolerance a fp32 implementation is held to against the fp32 oracle -- 1e-3 (the north-star
+    target) or `factor` x the fp32 oracle's own distance from the float64 oracle, whichever is larger.  A fp32 trajectory is
+    chaotic in its small components (the weighted KL term of a near-collapsed posterior is ~4e-4 of the ELBO): two correct
+    fp32 runs that add in different orders drift apart in it by more than 1e-3 of ITS value while the ELBO stays within 1e-3,
+    and the fp32-vs-fp64 distance of the oracle itself measures exactly that."""
+    own = np.abs(ora32 - ora64) / np.maximum(np.abs(ora64), 1e-12)
+    return np.maximum(floor, factor * own), own
+
 
 @pytest.mark.parametrize("mode", ["eager", "graph"])
 def test_c2_one_epoch_elbo_trajectory_matches_oracle(mode, gpu_device):
     """main.py:154-229 for one epoch at C2 (vae, upgrad, bs 256, Adam 1e-3): the loss dict of the LAST step and the epoch
-    averages must agree with the oracle's within 1e-3 relative, component by component."""
+    averages must agree with the oracle's, component by component (utils/objectives.py:141-144 for the KL term), within
+    max(1e-3, 4 x the fp32 oracle's own distance from a float64 oracle stepped alongside) relative."""
     import movae_amd  # noqa: F401
     from movae_amd import aggregation
     from movae_amd.train import GraphedTrainStep, make_optimizer, train_step
@@ -349,39 +395,42 @@ def test_c2_one_epoch_elbo_trajectory_matches_oracle(mode, gpu_device):
     gx, ge = torch.Generator().manual_seed(1234), torch.Generator().manual_seed(4321)
     pool = 24  # distinct batches, cycled (the epoch's order is the same on both sides)
     xs = [torch.rand(B, 3, size, size, generator=gx) for _ in range(pool)]
+    eps_list = [torch.randn(B, D, generator=ge) for _ in range(EPOCH_STEPS)]
     static_eps = torch.zeros(B, D, device=gpu_device)
     net.eps_override = static_eps  # the graph reads the noise from this address; refreshed before every step
     gs = None
     if mode == "graph":
         gs = GraphedTrainStep(net, opt, A, a, xs[0].to(gpu_device), preserve_state=True)  # warm-up steps are rewound
     xs_dev = [t.to(gpu_device) for t in xs]
-    keys, hip_hist, ora_hist = None, [], []
+    keys, hip_hist = None, []
     for i in range(EPOCH_STEPS):
-        eps = torch.randn(B, D, generator=ge)
-        static_eps.copy_(eps)
+        static_eps.copy_(eps_list[i])
         if gs is not None:
             ld, _ = gs.step(xs_dev[i % pool])
         else:
             ld, _ = train_step(net, xs_dev[i % pool], opt, A, a)
         keys = keys or list(ld.keys())
         hip_hist.append(torch.stack([ld[k].detach().reshape(()) for k in keys]))
-        ol = tr.step(xs[i % pool], eps)
-        assert list(ol.keys()) == keys
-        ora_hist.append([ol[k] for k in keys])
+    okeys, ora, ora64 = _oracle_trajectories(tr, xs, eps_list, EPOCH_STEPS)
+    assert okeys == keys
     hip = torch.stack(hip_hist).double().cpu().numpy()
-    ora = np.asarray(ora_hist, dtype=np.float64)
+    assert np.isfinite(hip).all()
     rel = np.abs(hip - ora) / np.maximum(np.abs(ora), 1e-12)
     drift = {k: float(rel[:, j].max()) for j, k in enumerate(keys)}
-    print(f"[C2 {mode}] {EPOCH_STEPS} steps; max relative drift per component: {drift}; final HIP {dict(zip(keys, hip[-1]))} "
-          f"oracle {dict(zip(keys, ora[-1]))}")
-    assert np.isfinite(hip).all()
-    # the target: after one epoch the ELBO (total_loss) within 1e-3 relative -- last step and the epoch mean (what main.py logs);
-    # every component within 1e-3 of the ELBO as well (the weighted KL term is ~4e-4 of the total at the end of the epoch:
-    # relative to ITSELF it carries the noise of a near-collapsed posterior)
+    lim_last, own_last = trajectory_limits(ora[-1], ora64[-1])
+    lim_mean, own_mean = trajectory_limits(ora.mean(0), ora64.mean(0))
+    rel_last = np.abs(hip[-1] - ora[-1]) / np.maximum(np.abs(ora[-1]), 1e-12)
+    rel_mean = np.abs(hip.mean(0) - ora.mean(0)) / np.maximum(np.abs(ora.mean(0)), 1e-12)
+    print(f"[C2 {mode}] {EPOCH_STEPS} steps; three-way table (HIP fp32 | oracle fp32 | oracle fp64), relative distances to the fp32 oracle:")
+    for j, k in enumerate(keys):
+        print(f"    {k:22s} last {hip[-1, j]:.8f} | {ora[-1, j]:.8f} | {ora64[-1, j]:.8f}   HIP {rel_last[j]:.2e}  fp64 {own_last[j]:.2e}  limit {lim_last[j]:.2e}"
+              f"   epoch mean HIP {rel_mean[j]:.2e}  fp64 {own_mean[j]:.2e}  limit {lim_mean[j]:.2e}   max drift {drift[k]:.2e}")
     it = keys.index("total_loss")
+    # the north-star target itself: after one epoch the ELBO within 1e-3 relative -- last step and the epoch mean (what main.py logs)
     np.testing.assert_allclose(hip[-1, it], ora[-1, it], rtol=1e-3, err_msg="last-step ELBO")
     np.testing.assert_allclose(hip[:, it].mean(), ora[:, it].mean(), rtol=1e-3, err_msg="epoch-average ELBO")
-    np.testing.assert_allclose(hip[-1], ora[-1], rtol=1e-3, atol=1e-3 * abs(ora[-1, it]), err_msg=f"last-step losses {keys}")
-    np.testing.assert_allclose(hip.mean(0), ora.mean(0), rtol=1e-3, atol=1e-3 * abs(ora[:, it].mean()), err_msg=f"epoch-average losses {keys}")
+    # every component, relative to ITSELF, against the fp64 yardstick
+    assert (rel_last <= lim_last).all(), f"last-step components {keys}: rel {rel_last} > limits {lim_last} (fp32 oracle vs fp64: {own_last})"
+    assert (rel_mean <= lim_mean).all(), f"epoch-average components {keys}: rel {rel_mean} > limits {lim_mean} (fp32 oracle vs fp64: {own_mean})"
     assert drift["total_loss"] < 5e-3 and drift["reconstruction_loss"] < 5e-3, drift  # and never far apart on the way
-    assert ora[-1][keys.index("total_loss")] < 0.5 * ora[0][keys.index("total_loss")], "the epoch must actually train"
+    assert ora[-1][it] < 0.5 * ora[0][it], "the epoch must actually train"
