@@ -70,11 +70,19 @@ def _ones_like(t):
     return o
 
 
-def _accumulate(p, g):
+def _accumulate(p, g, taken=()):
+    """p.grad += g.  `taken`: parameters whose gradient a kernel already added into p.grad in place (ops.GRAD_ACCUM_TAKEN).
+    Such a parameter must come back as that very tensor: a parameter that feeds TWO nodes of one loss (weight sharing) is
+    accumulated in place by the first node only, autograd then sums the two results into a NEW tensor (old + g1) + g2, and adding
+    that to p.grad would count old + g1 twice -- raised, not silently added."""
     if p.grad is None:
         p.grad = g
     elif g.data_ptr() == p.grad.data_ptr() and g.shape == p.grad.shape:
         pass  # the kernels already added this loss's gradient into p.grad (ops.GRAD_ACCUM)
+    elif p.data_ptr() in taken:
+        raise RuntimeError("a parameter's gradient was accumulated in place by a weight-gradient kernel, but autograd returned a "
+                           "different tensor for it (the parameter feeds more than one node of this loss?): in-place accumulation "
+                           "does not support shared weights")
     else:
         ops.join_wgrad()  # both operands may still be in flight on the weight-gradient side stream
         p.grad = p.grad + g
@@ -308,15 +316,18 @@ def mtl_backward_begin(losses, features, aggregator, tasks_params=None, shared_p
         seed = _ones_like(loss) if loss.dim() == 0 and loss.dtype == torch.float32 else None
         # task-side parameters an earlier loss already reached get this loss's gradient added inside the weight-gradient kernels
         ops.GRAD_ACCUM.clear()
+        ops.GRAD_ACCUM_TAKEN.clear()
         if i > 0 and ops.L.DEFER is None:
             ops.GRAD_ACCUM.update({p.data_ptr(): p.grad for p in tp if p.grad is not None})
         try:
             got = torch.autograd.grad(loss, tp + st.feat_diff, grad_outputs=seed, retain_graph=True, allow_unused=True)
         finally:
             ops.GRAD_ACCUM.clear()
+            taken = frozenset(ops.GRAD_ACCUM_TAKEN)
+            ops.GRAD_ACCUM_TAKEN.clear()
         for p, g in zip(tp, got[: len(tp)]):
             if g is not None:
-                _accumulate(p, g)
+                _accumulate(p, g, taken)
                 st.task_params.append(p)
         st.feat_grads.append(got[len(tp):])
     return st

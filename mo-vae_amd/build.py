@@ -32,9 +32,8 @@ def _digest(paths):
     return h.hexdigest()
 
 
-def build(force=False, verbose=True):
-    os.makedirs(BUILD, exist_ok=True)
-    hipcc = _hipcc()
+def _stale(force):
+    """(objects, compile jobs) against the digests on disk."""
     headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
     headers.append(os.path.join(HERE, "..", "include", "movae.h"))
     objs, jobs = [], []
@@ -46,31 +45,60 @@ def build(force=False, verbose=True):
         objs.append(obj)
         if force or not os.path.exists(obj) or not os.path.exists(stamp) or open(stamp).read() != dig:
             jobs.append((src, obj, stamp, dig))
+    return objs, jobs
 
-    def compile_one(job):
-        src, obj, stamp, dig = job
-        cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", src, "-o", obj]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
-        if verbose and r.stderr.strip():
-            print(r.stderr, file=sys.stderr)
-        with open(stamp, "w") as f:
-            f.write(dig)
-        return src
 
-    if jobs:
-        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
-            for done in ex.map(compile_one, jobs):
+def build(force=False, verbose=True):
+    """Rebuilds what changed.  Safe under concurrent callers (every rank of a torchrun launch imports the package): the
+    rebuild is serialised by an exclusive flock on _build/.lock, the digests are re-checked after the lock is taken (a peer
+    may have finished the work meanwhile), and objects / stamps / the .so are written to temporary names and os.replace()d
+    into place, so a process that dlopens the library concurrently sees the old file or the new one, never a partial one."""
+    import fcntl
+
+    os.makedirs(BUILD, exist_ok=True)
+    hipcc = _hipcc()
+    objs, jobs = _stale(force)
+    if not jobs and os.path.exists(LIB):
+        return LIB  # (the common case takes no lock)
+    with open(os.path.join(BUILD, ".lock"), "w") as lockf:
+        fcntl.flock(lockf, fcntl.LOCK_EX)
+        try:
+            objs, jobs = _stale(force)
+            tag = f".tmp{os.getpid()}"
+
+            def compile_one(job):
+                src, obj, stamp, dig = job
+                cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", src, "-o", obj + tag]
+                r = subprocess.run(cmd, capture_output=True, text=True)
+                if r.returncode != 0:
+                    if os.path.exists(obj + tag):
+                        os.remove(obj + tag)
+                    raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
+                if verbose and r.stderr.strip():
+                    print(r.stderr, file=sys.stderr)
+                os.replace(obj + tag, obj)
+                with open(stamp + tag, "w") as f:
+                    f.write(dig)
+                os.replace(stamp + tag, stamp)
+                return src
+
+            if jobs:
+                with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+                    for done in ex.map(compile_one, jobs):
+                        if verbose:
+                            print("compiled", os.path.basename(done))
+            if jobs or not os.path.exists(LIB):
+                cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + tag] + objs
+                r = subprocess.run(cmd, capture_output=True, text=True)
+                if r.returncode != 0:
+                    if os.path.exists(LIB + tag):
+                        os.remove(LIB + tag)
+                    raise RuntimeError(f"link failed:\n{r.stderr}")
+                os.replace(LIB + tag, LIB)
                 if verbose:
-                    print("compiled", os.path.basename(done))
-    if jobs or not os.path.exists(LIB):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"link failed:\n{r.stderr}")
-        if verbose:
-            print("linked", LIB)
+                    print("linked", LIB)
+        finally:
+            fcntl.flock(lockf, fcntl.LOCK_UN)
     return LIB
 
 

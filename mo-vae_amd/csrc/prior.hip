@@ -108,7 +108,9 @@ __global__ void xent_bwd_k(const float* __restrict__ logits, const int64_t* __re
         const long r = i / k;
         const int c = (int)(i - r * k);
         const float p = expf(logits[i] - lse[r]);
-        dlogits[i] = f * (p - (target[r] == c ? 1.f : 0.f));
+        long t = target[r];
+        t = t < 0 ? 0 : (t >= k ? k - 1 : t);  // the same clamp as xent_fwd_k: the gradient is the gradient of the loss that was reported
+        dlogits[i] = f * (p - (t == c ? 1.f : 0.f));
     }
 }
 

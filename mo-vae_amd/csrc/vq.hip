@@ -201,9 +201,14 @@ __global__ void vq_bwd_dx_k(const float* __restrict__ x, const float* __restrict
 // ascending row order, and the item partials are folded in fixed order: bit-reproducible, no atomics, no memset.
 constexpr int VQ_CHUNK = 128;  // rows per work item of the segmented sum
 
-__global__ void vq_keys_k(const int64_t* __restrict__ idx, unsigned long long* __restrict__ keys, int rows) {
+__global__ void vq_keys_k(const int64_t* __restrict__ idx, unsigned long long* __restrict__ keys, int rows, int K) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < rows) keys[r] = ((unsigned long long)idx[r] << 32) | (unsigned)r;
+    if (r < rows) {
+        // clamped like the forward lookups (embedding_fwd_k, vq gather): a code outside [0, K) must not index the segment tables
+        long c = idx[r];
+        c = c < 0 ? 0 : (c >= K ? K - 1 : c);
+        keys[r] = ((unsigned long long)c << 32) | (unsigned)r;
+    }
 }
 
 __device__ __forceinline__ int lower_bound_key(const unsigned long long* __restrict__ keys, int n, unsigned long long key) {
@@ -338,7 +343,7 @@ static int segmented_code_sum(const float* x, const float* q, const int64_t* idx
     temp = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(temp) + 255) & ~(uintptr_t)255);
     size_t temp_bytes = 0;
     (void)hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, keys, sorted, rows, 0, 64);
-    hipLaunchKernelGGL(vq_keys_k, dim3(ceil_div(rows, 256)), dim3(256), 0, st, idx, keys, rows);
+    hipLaunchKernelGGL(vq_keys_k, dim3(ceil_div(rows, 256)), dim3(256), 0, st, idx, keys, rows, k);
     MOVAE_CHECK_LAUNCH("vq_keys");
     int kbits = 1;
     while ((1 << kbits) < k) ++kbits;

@@ -35,6 +35,11 @@ def _sink(param, shape):
 GRAD_ACCUM = {}
 
 
+#: data_ptr of every parameter whose gradient a kernel accumulated in place during the current autograd call (filled by
+#: _accum_targets, cleared together with GRAD_ACCUM): autojac._accumulate checks what autograd hands back against it.
+GRAD_ACCUM_TAKEN = set()
+
+
 def _accum_targets(w, b, need_b):
     """(dW destination in memory order, dbias destination) when BOTH of a layer's gradients can be accumulated in place."""
     if not GRAD_ACCUM:
@@ -47,8 +52,10 @@ def _accum_targets(w, b, need_b):
     if not v.is_contiguous() or gw.shape != w.shape:
         return None, None
     GRAD_ACCUM.pop(w.data_ptr(), None)
+    GRAD_ACCUM_TAKEN.add(w.data_ptr())
     if gb is not None:
         GRAD_ACCUM.pop(b.data_ptr(), None)
+        GRAD_ACCUM_TAKEN.add(b.data_ptr())
     return v, gb
 
 

@@ -51,14 +51,17 @@ def extract_codes(net, train_loader, device, is_hierarchical):
     """One pass of the frozen VQ model over the training set (utils/vq_codes_lmdb.py:47-93): code grids on the host."""
     net.eval()
     tops, bots = [], []
+    # held as int16 / int32 on the host (a code is < num_embeddings): an int64 grid per ImageNet-scale VQ-VAE-2 sample would be
+    # ~50 GB where the reference spills to LMDB; VQCodeDataset.__getitem__ hands out .long() like the reference's Dataset
+    store = torch.int16 if int(getattr(net, "num_embeddings", 1 << 20)) <= (1 << 15) else torch.int32
     for images, _ in train_loader:
         images = images.to(device)
         if is_hierarchical:
             cd = net.get_code_indices(images)
-            tops.append(cd["indices_top"].cpu())
-            bots.append(cd["indices_bottom"].cpu())
+            tops.append(cd["indices_top"].to(store).cpu())
+            bots.append(cd["indices_bottom"].to(store).cpu())
         else:
-            tops.append(net.get_code_indices(images).cpu())
+            tops.append(net.get_code_indices(images).to(store).cpu())
     if is_hierarchical:
         return VQCodeDataset((torch.cat(tops), torch.cat(bots)), True)
     return VQCodeDataset((torch.cat(tops),), False)

@@ -225,10 +225,11 @@ class GraphedTrainStep:
         # (graph, eager all-reduce, graph) cost ~110 us per step in cross-queue hand-offs on MI355X (1.415 vs 1.306 ms with one
         # hardware queue); inside one graph the collective is just another kernel node.  gloo cannot be captured, and
         # MOVAE_DP_CAPTURE_COLLECTIVE=0 (or a failing capture) falls back to the pieces.
-        # MOVAE_DP_CAPTURE_COLLECTIVE: "1" (default) capture the collective and RAISE if that fails; "auto" fall back to the
-        # pieces -- but only when EVERY rank agrees (a rank that fell back alone would issue collectives its peers never
-        # post: the pieces all-reduce while they are built); "0" never capture it
-        cc_mode = os.environ.get("MOVAE_DP_CAPTURE_COLLECTIVE", "1")
+        # MOVAE_DP_CAPTURE_COLLECTIVE: "auto" (default) capture the collective and fall back to the pieces if that fails -- but
+        # only when EVERY rank agrees (MIN all-reduce of an ok-flag: a rank that fell back alone would issue collectives its
+        # peers never post: the pieces all-reduce while they are built); "1" capture it and RAISE if that fails (strict
+        # opt-in); "0" never capture it.  The form taken is recorded in self.dp_form and logged once on rank 0 (train.main).
+        cc_mode = os.environ.get("MOVAE_DP_CAPTURE_COLLECTIVE", "auto")
         self.dp_form = "graph | all-reduce | graph"
         if not overlap and dp.backend == "nccl" and cc_mode != "0":
             err = None
@@ -372,6 +373,8 @@ def train_epoch(net, train_loader, optimizer, aggregator, step, device, args, dp
             try:
                 graphed["step"] = GraphedTrainStep(net, optimizer, aggregator, args, images, dp=dp, preserve_state=True)
                 graphed["hooks"] = dict(_hook_values)  # the weighting's forward hooks ran while capturing: static tensors
+                if dp is not None and dp.rank == 0:
+                    print(f"[movae] data-parallel step form: {graphed['step'].dp_form}", flush=True)
             except NotImplementedError as e:
                 graphed["failed"] = True
                 print(f"[movae] hipGraph capture not possible ({e}); running the eager step", flush=True)
@@ -748,7 +751,12 @@ def main(args):
     if rank0 and _is_vq_arch(args.arch) and not getattr(args, "skip_pixelcnn", False):  # main.py:1438-1497
         from . import prior as _prior
 
-        _prior.train_pixelcnn_prior(net, train_loader, device, args, save_root)
+        # The prior sees the WHOLE training set at the CLI batch size, like the single-process reference: under data parallelism
+        # the training loader is a DistributedSampler shard at the per-rank batch size, so rank 0 builds a plain loader of its own.
+        prior_loader = train_loader
+        if dp is not None:
+            prior_loader = torch.utils.data.DataLoader(train_ds, batch_size=args.batch_size, shuffle=True, **loader_kw)
+        _prior.train_pixelcnn_prior(net, prior_loader, device, args, save_root)
     if dp is not None:
         dp.shutdown()
     return history

@@ -251,3 +251,49 @@ def test_fuse_struct_layout_matches_the_header(pkg, tmp_path):
     assert int(out[0]) == C.sizeof(L.MovaeFuse)
     want = {ln.split()[0]: int(ln.split()[1]) for ln in out[1:] if ln.strip()}
     assert want == {n: getattr(L.MovaeFuse, n).offset for n in names}
+
+
+def test_concurrent_rebuilds_are_serialised(pkg, tmp_path):
+    """Every rank of a torchrun launch imports the package and consults build.build(): with a stale csrc/ they must not compile the
+    same objects / relink the same .so at once.  Four processes rebuild a scratch tree through a stand-in compiler that logs its
+    invocations: each object is compiled once, the library is linked once, nothing partial is left behind."""
+    import stat
+    import subprocess
+    import sys
+    import textwrap
+
+    csrc, bdir = tmp_path / "csrc", tmp_path / "_build"
+    csrc.mkdir()
+    for s in ("a.hip", "b.hip"):
+        (csrc / s).write_text("// " + s)
+    (tmp_path / "include").mkdir()
+    log = tmp_path / "cc.log"
+    cc = tmp_path / "fakecc"
+    cc.write_text(textwrap.dedent(f"""\
+        #!/bin/sh
+        out=""
+        while [ $# -gt 0 ]; do if [ "$1" = "-o" ]; then out="$2"; fi; shift; done
+        printf 'partial' > "$out"; sleep 0.3; printf 'complete-object' > "$out"
+        echo "$out" >> {log}
+        """))
+    cc.chmod(cc.stat().st_mode | stat.S_IEXEC)
+    child = textwrap.dedent(f"""\
+        import os, sys
+        sys.path.insert(0, {str(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))!r})
+        import movae_amd  # noqa: F401
+        from movae_amd import build as B
+        B.CSRC, B.BUILD, B.LIB, B.HERE = {str(csrc)!r}, {str(bdir)!r}, {str(tmp_path / 'lib.so')!r}, {str(tmp_path / 'pkg')!r}
+        B.SOURCES = ["a.hip", "b.hip"]
+        os.makedirs({str(tmp_path / 'pkg')!r}, exist_ok=True)
+        open({str(tmp_path / 'include' / 'movae.h')!r}, "a").close()
+        B.build(verbose=False)
+        assert open(B.LIB).read() == "complete-object"
+        """)
+    env = dict(os.environ, HIPCC=str(cc), MOVAE_NO_REBUILD="1")
+    procs = [subprocess.Popen([sys.executable, "-c", child], env=env, stderr=subprocess.PIPE) for _ in range(4)]
+    errs = [p.communicate()[1].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), errs
+    lines = log.read_text().split()
+    assert len(lines) == 3, lines  # two objects + one link, not 4 x 3
+    left = [f for f in os.listdir(bdir) if ".tmp" in f] + [f for f in os.listdir(tmp_path) if ".tmp" in f]
+    assert not left, left

@@ -230,6 +230,36 @@ def test_batched_pullback_residual_graph_and_native_nodes(gpu_device, monkeypatc
         np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-4, atol=1e-6 * max(1.0, float(b.abs().max())))
 
 
+def test_shared_task_side_weight_is_not_double_counted(gpu_device):
+    """A task-side conv applied twice (weight sharing) under two losses: the second loss's weight gradient is added in place by the
+    FIRST of the two nodes (ops.GRAD_ACCUM) and autograd sums both nodes' results into a new tensor -- adding that to .grad would
+    count the first loss's gradient twice.  Either the result is exact or the step refuses loudly; never a silent double count."""
+    import movae_amd  # noqa: F401
+    from movae_amd import aggregation, autojac, nn as mnn
+
+    torch.manual_seed(5)
+    trunk = mnn.Conv2d(8, 8, 3, 1, 1).to(gpu_device)
+    head = mnn.Conv2d(8, 8, 3, 1, 1).to(gpu_device)   # applied twice below
+    x = torch.randn(4, 6, 6, 8, device=gpu_device)
+
+    def losses():
+        feat = trunk(x)
+        y = head(head(feat))
+        return feat, [y.square().mean(), y.abs().mean()]
+
+    feat, ls = losses()
+    want = torch.autograd.grad(ls[0] + ls[1], list(head.parameters()), retain_graph=True)
+    for p in list(trunk.parameters()) + list(head.parameters()):
+        p.grad = None
+    try:
+        autojac.mtl_backward(losses=ls, features=[feat], aggregator=aggregation.Sum(), retain_graph=True)
+    except RuntimeError as e:
+        assert "shared weights" in str(e)
+        return
+    for p, w in zip(head.parameters(), want):
+        np.testing.assert_allclose(p.grad.cpu().numpy(), w.cpu().numpy(), rtol=1e-4, atol=1e-6 * float(w.abs().max()))
+
+
 def _full_case(tag):
     fx = load_golden("full_configs")
     m = {}
