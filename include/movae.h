@@ -295,6 +295,10 @@ const char* movae_bench_last_kernel(void);
 /* s > 0 pins the conv family's split-K factor (tools/conv_microbench.py tuning sweeps); 0 restores the heuristic.
  * Returns the previous value. */
 int movae_bench_force_split(int s);
+/* mode > 0: every conv-family call whose shape the block-internal split-K kernels (csrc/kgemm.h) can serve takes them, whatever
+ * the size heuristic says; mode < 0: none does; 0: the heuristic (small, latency-bound problems only).  Lets the parity tests run
+ * the whole conv test matrix through either family.  Returns the previous mode. */
+int movae_bench_force_kgemm(int mode);
 
 /* ---- BatchNorm fused into its neighbouring convolutions -----------------------------------------
  * models/vae.py:119-126,149-158: Conv2d / ConvTranspose2d -> BatchNorm2d (training statistics) -> LeakyReLU chains.  Instead of

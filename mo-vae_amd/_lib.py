@@ -124,6 +124,7 @@ SIGNATURES = {
     "movae_bench_main_kernel_only": ([_i], _i),
     "movae_bench_last_kernel": ([], C.c_char_p),
     "movae_bench_force_split": ([_i], _i),
+    "movae_bench_force_kgemm": ([_i], _i),
 }
 
 _lib = None

@@ -822,6 +822,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats(const float* __restri
 const char* g_last_kernel = "";  // movae_bench_last_kernel(): main kernel chosen by the most recent conv-family dispatch
 int g_force_split = 0;           // movae_bench_force_split(): > 0 pins the split-K factor (tuning sweeps)
 bool g_bench_main_only = false;  // movae_bench_main_kernel_only(): time the MFMA kernel without its epilogue launches
+int g_force_kgemm = 0;           // movae_bench_force_kgemm(): 1 = every shape kgemm.h can serve takes it, -1 = none does (tests, A/B)
 
 inline long reduce_vec_min() {  // outputs from which the 16-byte reduce serves 8 <= S < 64 (tuning knob)
     static const long v = getenv("MOVAE_REDUCE_VEC_MIN") ? atol(getenv("MOVAE_REDUCE_VEC_MIN")) : (1L << 19);
@@ -949,6 +950,10 @@ inline int choose_split(int form, int tile_area, int bk, long tiles, int nk, siz
 #include "igemm_v2.h"
 #include "conv_thin.h"
 #include "linear_small.h"
+#include "kgemm.h"
+namespace kg {
+inline bool g_force_kgemm_on() { return g_force_kgemm > 0; }
+}
 
 inline bool is_linear(const Geom& g) {
     return g.KH == 1 && g.KW == 1 && g.Hi == 1 && g.Wi == 1 && g.Ho == 1 && g.Wo == 1 && g.stride == 1 && g.pad == 0 && g.wlen == 0;
@@ -1039,6 +1044,11 @@ int launch_fwd(const float* X, const float* W, float* Y, const Geom& g_in, const
     // fast path (igemm_v2.h); its 32-bit buffer offsets need every row block's images and the weights within 2 GiB of their bases
     const bool span_ok = v2::buf_span_ok((128L / ((long)g.Ho * g.Wo) + 2) * g.Hi * g.Wi * g.Cr) &&
                          v2::buf_span_ok((long)g.Nn * (g.wlen ? g.wrow : Kl) + g.woff);
+    if (g_force_kgemm >= 0) {  // small, latency-bound problems: the reduction split inside the block (kgemm.h)
+        bool handled = false;
+        if (int rc = kg::launch_kfwd(X, W, Y, g, ep, M, K, st, &handled)) return rc;
+        if (handled) return MOVAE_OK;
+    }
     if (g.Cr % 4 == 0 && aligned16(X) && aligned16(W) && span_ok) {
         if (g.Nn <= 32) return (g_last_kernel = "igemm2_fwd<128,32>", v2::launch_fwd2<128, 32>(X, W, Y, g, ep, M, K, ws, ws_bytes, st));
         // 2x2 register tiling (64x64 per wave) once the 128x128 grid alone fills the chip
@@ -1103,6 +1113,11 @@ int launch_bwd(const float* X, const float* W, float* Y, const Geom& g, const Ep
     // fast path (igemm_v2.h); 32-bit buffer offsets: a row block's images (smallest output-parity class) and the weights within 2 GiB
     const long hwc_min = (long)(g.Ho / g.stride > 0 ? g.Ho / g.stride : 1) * (g.Wo / g.stride > 0 ? g.Wo / g.stride : 1);
     const bool span_ok = v2::buf_span_ok((128L / hwc_min + 2) * g.Hi * g.Wi * g.Cr) && v2::buf_span_ok((long)g.Cr * g.KH * g.KW * g.Nn);
+    if (g_force_kgemm >= 0) {
+        bool handled = false;
+        if (int rc = kg::launch_kbwd(X, W, Y, g, ep, st, &handled)) return rc;
+        if (handled) return MOVAE_OK;
+    }
     if (g.Cr % 4 == 0 && g.Nn % 4 == 0 && g.stride <= 2 && aligned16(X) && aligned16(W) && aligned16(Y) && span_ok) {
         if (g.Nn <= 32) return (g_last_kernel = "igemm2_bwd<128,32>", v2::launch_bwd2<128, 32>(X, W, Y, g, ep, ws, ws_bytes, st));
         if (g.Nn >= 128 && (Mc / 128) * (g.Nn / 128) * g.stride * g.stride >= big_tile_min())
@@ -1182,6 +1197,11 @@ int launch_wgrad(const float* S, const float* Bg, float* const* dW, int G, long 
     const bool vec = g.Cs % 4 == 0 && g.Cb % 4 == 0 && aligned16(S) && aligned16(Bg) && s_gs % 4 == 0 && b_gs % 4 == 0 &&
                      v2::buf_span_ok(Kl * g.Cs) && v2::buf_span_ok((long)g.Nimg * g.Hb * g.Wb * g.Cb);
     const int N = g.KH * g.KW * g.Cb;
+    if (g_force_kgemm >= 0 && !colsum_S && !thin::thin_wgrad_ok(g)) {  // kgemm.h (no bias-gradient column sums there)
+        bool handled = false;
+        if (int rc = kg::launch_kwgrad(S, Bg, dW, G, s_gs, b_gs, g, (int)Kl, accumulate, ws, ws_bytes, st, &handled)) return rc;
+        if (handled) return MOVAE_OK;
+    }
     if (vec && !(thin::thin_wgrad_ok(g) && ws)) {  // fast path (igemm_v2.h)
         // the column sums of S (bias gradient) ride along: the by == 0 blocks stage every S value of their split anyway
         float* const* cs = nullptr;
@@ -1295,6 +1315,12 @@ const char* movae_bench_last_kernel(void) { return g_last_kernel; }
 int movae_bench_force_split(int s) {
     const int prev = g_force_split;
     g_force_split = s > 0 ? s : 0;
+    return prev;
+}
+
+int movae_bench_force_kgemm(int mode) {
+    const int prev = g_force_kgemm;
+    g_force_kgemm = mode > 0 ? 1 : (mode < 0 ? -1 : 0);
     return prev;
 }
 
@@ -1461,6 +1487,7 @@ static int pair_calls(bool transposed, int groups, const float* dy, const float*
                       int accumulate, void* ws, size_t ws_bytes, movae_stream_t stream, const movae_fuse_t* fuse) {
     static const bool enabled = !getenv("MOVAE_NO_PAIR");
     v2::g_pending.active = false;
+    kg::g_kpend.active = false;
     v2::g_pair_collect = enabled;
     g_fuse = FuseCtx();
     fuse_bn_install(const_cast<movae_fuse_t*>(fuse), groups);  // (the dgrad's plan -- also a stashed one -- keeps what it claimed)
@@ -1471,6 +1498,7 @@ static int pair_calls(bool transposed, int groups, const float* dy, const float*
     const char* dgrad_kernel = g_last_kernel;
     if (rc) {
         v2::g_pending.active = false;
+        kg::g_kpend.active = false;
         return rc;
     }
     size_t used = v2::g_pending.active ? (v2::g_pending.ws_used + 255) / 256 * 256 : 0;
@@ -1484,11 +1512,11 @@ static int pair_calls(bool transposed, int groups, const float* dy, const float*
                                                     ws_bytes - used, stream, fuse)
                     : movae_conv2d_wgrad_grouped_f(groups, dy, x, dw, dbias, n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, accumulate, ws2,
                                                    ws_bytes - used, stream, fuse);
-    if (v2::g_pending.active) {  // the wgrad took a kernel that does not pair (thin / linear / generic)
+    if (v2::g_pending.active || kg::g_kpend.active) {  // the wgrad took a kernel that does not pair (thin / linear / generic)
         const int rc2 = v2::flush_pending((hipStream_t)stream);
         if (!rc) rc = rc2;
     }
-    if (strncmp(g_last_kernel, "igemm2_pair", 11) != 0) {  // two main launches: movae_bench_last_kernel() names both
+    if (strncmp(g_last_kernel, "igemm2_pair", 11) != 0 && strncmp(g_last_kernel, "kpair_k", 7) != 0) {  // two main launches: movae_bench_last_kernel() names both
         static thread_local char both[128];
         snprintf(both, sizeof(both), "%s + %s", dgrad_kernel, g_last_kernel);
         g_last_kernel = both;

@@ -1273,6 +1273,16 @@ constexpr bool pair_dgrad_tile() { return (BM == 64 && BN == 64) || (BM == 128 &
 template <int BM, int BN>
 constexpr bool pair_wgrad_tile() { return (BM == 64 && BN == 64) || (BM == 32 && BN == 128); }
 
+// The block-internal split-K kernels (kgemm.h, included after this file) stash their input-gradient launch the same way; the
+// weight-gradient launchers below reach it through these hooks: pending? / launch it together with this weight gradient (one
+// kernel: kpair_k) / launch it on its own.
+struct KPairHooks {
+    bool (*pending)();
+    int (*pair)(const WgArgs& wa, int wgx, int wgy, int wgz, bool w64, hipStream_t st);
+    int (*flush)(hipStream_t st);
+};
+static KPairHooks g_kpair{nullptr, nullptr, nullptr};
+
 inline int finish_pending(hipStream_t st) {  // the stashed dgrad's reduce
     PendingDgrad& p = g_pending;
     if (!p.reduce || g_bench_main_only) return MOVAE_OK;
@@ -1300,6 +1310,8 @@ inline int finish_pending(hipStream_t st) {  // the stashed dgrad's reduce
 }
 
 inline int flush_pending(hipStream_t st) {  // launch the stashed dgrad on its own
+    if (g_kpair.flush)
+        if (int rc = g_kpair.flush(st)) return rc;
     PendingDgrad& p = g_pending;
     if (!p.active) return MOVAE_OK;
     p.active = false;
@@ -1546,7 +1558,7 @@ int launch_wgrad2(const float* Sm, const float* Bg, float* const* dW, int G, lon
     const long stride = (long)M * N + (colsum ? M : 0);  // floats per slab
     const int gx = ceil_div(M, BM), gy = ceil_div(N, BN);
     // the G groups run side by side, so the split factor is chosen for G times the tiles
-    int Sp = choose_split(FORM_WGRAD, BM * BN, BK2, pair_tiles((long)gx * gy * G, g_pending.active && pair_wgrad_tile<BM, BN>()),
+    int Sp = choose_split(FORM_WGRAD, BM * BN, BK2, pair_tiles((long)gx * gy * G, (g_pending.active || (g_kpair.pending && g_kpair.pending())) && pair_wgrad_tile<BM, BN>()),
                           ceil_div(K, BK2), (size_t)stride * sizeof(float) * G, ws_bytes, ws != nullptr);
     const int kchunk = ceil_div(ceil_div(K, Sp), BK2) * BK2;
     Sp = ceil_div(K, kchunk);
@@ -1566,7 +1578,9 @@ int launch_wgrad2(const float* Sm, const float* Bg, float* const* dW, int G, lon
     a.slab_stride = stride;
     for (int i = 0; i < 8; ++i) a.cs.p[i] = (colsum && i < G) ? colsum[i] : nullptr;
     PendingDgrad& p = g_pending;
-    if (p.active && pair_wgrad_tile<BM, BN>() && (long)p.gx * p.gy * p.gz + (long)gx * gy * Sp * G < 0x7fffffffL) {
+    if (g_kpair.pending && g_kpair.pending() && pair_wgrad_tile<BM, BN>()) {  // a kgemm.h input gradient waits: one launch for both
+        if (int rc = g_kpair.pair(a, gx, gy, Sp * G, BM == 64, st)) return rc;
+    } else if (p.active && pair_wgrad_tile<BM, BN>() && (long)p.gx * p.gy * p.gz + (long)gx * gy * Sp * G < 0x7fffffffL) {
         p.active = false;
         constexpr int W64 = BM == 64 ? 1 : 0;  // wgrad tile: <64,64> or <32,128>
         // names as rocprofv3 prints the instantiations: <form, dgrad tile, wgrad tile>

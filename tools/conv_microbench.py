@@ -76,11 +76,15 @@ def main():
     ap.add_argument("--sweep-split", type=int, nargs="*", default=None,
                     help="time every call with the split-K factor pinned to each value (0 = the library's heuristic)")
     ap.add_argument("--lib", type=str, default="", help="A/B: load this prebuilt libmovae_hip.so instead of the in-tree one")
+    ap.add_argument("--kgemm", type=int, default=0, help="movae_bench_force_kgemm: 1 = the block-internal split-K kernels wherever they "
+                    "can serve, -1 = never, 0 = the library's heuristic")
+    ap.add_argument("--no-dbias", action="store_true", help="weight gradient without the bias gradient (a conv in front of a BatchNorm)")
     a = ap.parse_args()
     if a.lib:
         L.LIB_PATH = os.path.abspath(a.lib)
         os.environ["MOVAE_NO_REBUILD"] = "1"
     lib = L.load()
+    lib.movae_bench_force_kgemm(a.kgemm)
     dev = torch.device("cuda:0")
     ws = L.workspace(dev)
     shapes = {"c2": C2, "c3": C3, "c3big": C3BIG, "thin": THIN}[a.shapes]
@@ -98,7 +102,7 @@ def main():
         calls = {
             "fwd": (getattr(lib, pre + "fwd"), (x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr()) + geom + (0, 0.01) + tail),
             "dgrad": (getattr(lib, pre + "dgrad"), (y.data_ptr(), w.data_ptr(), x.data_ptr()) + geom + tail),
-            "wgrad": (getattr(lib, pre + "wgrad"), (y.data_ptr(), x.data_ptr(), w.data_ptr(), b.data_ptr()) + geom + (0,) + tail),
+            "wgrad": (getattr(lib, pre + "wgrad"), (y.data_ptr(), x.data_ptr(), w.data_ptr(), None if a.no_dbias else b.data_ptr()) + geom + (0,) + tail),
         }
         pix = hi * wi if kind == "convT" else ho * wo
         gf = 2.0 * n * pix * k * k * ci * co / 1e9
@@ -120,7 +124,8 @@ def main():
                 continue
             us = time_call(fn, args, a.reps)
             tot += us
-            line += f" {name} {us:7.1f}us {gf / us * 1e3:6.1f}TF/s |"
+            kern = lib.movae_bench_last_kernel().decode()
+            line += f" {name} {us:7.1f}us {gf / us * 1e3:6.1f}TF/s {kern[:18]:18s}|"
         if not a.sweep_split:
             print(line, flush=True)
     print(f"sum {tot:.1f} us")
