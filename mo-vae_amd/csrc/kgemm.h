@@ -537,7 +537,10 @@ inline bool small_problem(long rows, long cols, long k, long copies) {
     const double flop = 2.0 * (double)rows * (double)cols * (double)k * (double)copies;
     static const long tmax = getenv("MOVAE_KGEMM_TILES64") ? atol(getenv("MOVAE_KGEMM_TILES64")) : 384;
     static const double fmax = getenv("MOVAE_KGEMM_GFLOP") ? atof(getenv("MOVAE_KGEMM_GFLOP")) * 1e9 : 4e9;
-    return tiles64 <= tmax && flop <= fmax && k >= 128;
+    // a short reduction (K = 288: 32 -> 64 channels on 16x16 images) leaves a wave's slice nine groups long -- the fold and the
+    // epilogue then outweigh the slabs they replace (measured 18.6 vs 13.5 us per call)
+    static const long kmin = getenv("MOVAE_KGEMM_KMIN") ? atol(getenv("MOVAE_KGEMM_KMIN")) : 512;
+    return tiles64 <= tmax && flop <= fmax && k >= kmin;
 }
 
 template <int FORM, bool NRM>
