@@ -164,6 +164,11 @@ int movae_recon_loss_bwd(const float* recons, const float* inputs, const float* 
 /* kl: utils/objectives.py:141-144, out[0] = scale * mean_b(-0.5 sum_d(1 + lv - mu^2 - e^lv)) */
 int movae_kl_fwd(const float* mu, const float* log_var, float* out, int b, int d, float scale,
                  void* ws, size_t ws_bytes, movae_stream_t stream);
+/* VAE.loss_function (models/vae.py:211-228) in three launches: out[3] = (reconstruction_loss, kld_loss, total_loss = their fp32 sum);
+ * the same arithmetic as movae_recon_loss_fwd + movae_kl_fwd + a tensor add.  ws >= the two reductions' workspaces together. */
+int movae_vae_losses_fwd(const float* recons, const float* inputs, size_t n, int kind, float rec_scale,
+                         const float* mu, const float* log_var, int b, int d, float kl_scale, float* out,
+                         void* ws, size_t ws_bytes, movae_stream_t stream);
 int movae_kl_bwd(const float* mu, const float* log_var, const float* gscale_dev, float* dmu, float* dlog_var,
                  int b, int d, float scale, movae_stream_t stream);
 /* Beta-TC decomposition: models/betatc_vae.py:262-296.  out[0..2] = mi, tc, kld (unweighted means).

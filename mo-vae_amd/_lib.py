@@ -67,6 +67,7 @@ SIGNATURES = {
     "movae_recon_loss_fwd": ([_p, _p, _p, _z, _i, _f, _p, _z, _p], _i),
     "movae_recon_loss_bwd": ([_p, _p, _p, _p, _z, _i, _f, _p], _i),
     "movae_kl_fwd": ([_p, _p, _p, _i, _i, _f, _p, _z, _p], _i),
+    "movae_vae_losses_fwd": ([_p, _p, _z, _i, _f, _p, _p, _i, _i, _f, _p, _p, _z, _p], _i),
     "movae_kl_bwd": ([_p, _p, _p, _p, _p, _i, _i, _f, _p], _i),
     "movae_tc_decomp_fwd": ([_p] * 7 + [_i, _i, _p, _z, _p], _i),
     "movae_tc_decomp_bwd": ([_p] * 10 + [_i, _i, _p], _i),

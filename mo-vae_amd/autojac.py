@@ -88,8 +88,18 @@ def _accumulate(p, g, taken=()):
         p.grad = p.grad + g
 
 
+#: MOVAE_PERSISTENT_J=0: a fresh zero-filled Jacobian arena per step (A/B knob)
+PERSISTENT_J = os.environ.get("MOVAE_PERSISTENT_J", "1") != "0"
+_J_CACHE = {}  # (device, K, parameter identities) -> JacobianBuffer, the few most recently used
+
+
 class JacobianBuffer:
-    """[K, ld] fp32 arena; ld is padded to a multiple of 4 floats so every row is 16-byte aligned."""
+    """[K, ld] fp32 arena; ld is padded to a multiple of 4 floats so every row is 16-byte aligned.
+
+    A slice nobody writes must read zero (a loss with no path to a parameter; the bias in front of a training-mode BatchNorm).
+    `JacobianBuffer.persistent` keeps the arena across steps instead of zero-filling K x m floats per step (13.6 MB at C2,
+    180 MB at C5): the slices written in a step are known from ops.SINK_LOG / write_row, `settle()` zeroes exactly those that
+    an EARLIER step wrote and this one did not (normally none: the step's graph does not change)."""
 
     def __init__(self, params, k, device):
         self.params = params
@@ -100,6 +110,44 @@ class JacobianBuffer:
         self.m = off
         self.ld = (off + 3) // 4 * 4
         self.buf = torch.zeros((k, max(self.ld, 4)), dtype=torch.float32, device=device)
+        self.dirty = None      # persistent use: data_ptr -> (row, parameter index) of every slice some step wrote
+        self.copied = set()    # slices written by write_row / the walker's leaf copies in the current step
+
+    @classmethod
+    def persistent(cls, params, k, device):
+        if not PERSISTENT_J:
+            return cls(params, k, device)
+        key = (str(device), k, tuple((id(p), p.numel()) for p in params))
+        jb = _J_CACHE.pop(key, None)
+        if jb is None or any(a is not b for a, b in zip(jb.params, params)):
+            jb = cls(list(params), k, device)
+            jb.dirty = {}
+        _J_CACHE[key] = jb  # (re-inserted last: most recently used)
+        while len(_J_CACHE) > 4:
+            _J_CACHE.pop(next(iter(_J_CACHE)))
+        jb.copied = set()
+        ops.SINK_LOG.clear()
+        ops.SINK_ZERO_LOG.clear()
+        return jb
+
+    def settle(self):
+        """After the step's backward: zero the slices an earlier step wrote and this one did not."""
+        if self.dirty is None:
+            return
+        where = {}
+        for i in range(self.buf.shape[0]):
+            base = self.buf[i].data_ptr()
+            for j, (p, off) in enumerate(zip(self.params, self.offsets)):
+                where[base + 4 * off] = (i, j)
+        now = {ptr for ptr in list(ops.SINK_LOG) + list(self.copied) if ptr in where}
+        for ptr in [q for q in self.dirty if q not in now]:
+            i, j = self.dirty[ptr]
+            self.buf[i][self.offsets[j]: self.offsets[j] + self.params[j].numel()].zero_()
+            del self.dirty[ptr]
+        for ptr in now:
+            self.dirty[ptr] = where[ptr]
+        ops.SINK_LOG.clear()
+        ops.SINK_ZERO_LOG.clear()
 
     @property
     def J(self):
@@ -115,6 +163,7 @@ class JacobianBuffer:
         for p, off, g in zip(self.params, self.offsets, grads):
             if g is not None:
                 dst = row[off: off + p.numel()]
+                self.copied.add(dst.data_ptr())
                 if g.data_ptr() != dst.data_ptr():  # already written in place through the sink
                     ops.join_wgrad()
                     dst.copy_(_mem_flat(g))
@@ -194,7 +243,7 @@ def _batched_pullback(features, feat_grads, rows, jb):
             continue
         ref = next(x for x in gs if x is not None)
         gs = [x if x is not None else torch.zeros_like(ref) for x in gs]
-        roots.append((fn, feat.output_nr, gs))
+        roots.append((fn, feat.output_nr, _restack(gs)))  # (adjacent slices of one buffer -- ops.COT_SINK -- become one [G, ...] view)
     deps, seen, stack = {}, set(), [fn for fn, _, _ in roots]
     while stack:
         fn = stack.pop()
@@ -225,6 +274,7 @@ def _batched_pullback(features, feat_grads, rows, jb):
                     for g in range(G):
                         src = _group(got[0], g)
                         dst = jb.buf[rows[g]][off: off + p.numel()]
+                        jb.copied.add(dst.data_ptr())
                         if src.data_ptr() != dst.data_ptr():  # not already written in place through the sink
                             dst.copy_(_mem_flat(src))
                 continue
@@ -306,10 +356,14 @@ def mtl_backward_begin(losses, features, aggregator, tasks_params=None, shared_p
     st = _MtlState()
     st.shared_params = list(shared_params)
     st.aggregator = aggregator
-    st.jb = JacobianBuffer(st.shared_params, len(losses), features[0].device)
+    st.jb = JacobianBuffer.persistent(st.shared_params, len(losses), features[0].device)
     st.feat_diff = [f for f in features if f.requires_grad]
     st.feat_grads = []
     st.task_params = []
+    # the K cotangents of every feature are born stacked: [K, ...] buffers whose slice i the op that produces d(loss i)/d(feature)
+    # writes directly (ops.COT_SINK) -- no torch.stack launch in front of the batched pull-back
+    cot = [torch.empty((len(losses),) + tuple(f.shape), dtype=f.dtype, device=f.device) if f.is_contiguous() else None
+           for f in st.feat_diff]
     for i, (loss, tp) in enumerate(zip(losses, tasks_params)):
         tp = list(tp)
         # the seed cotangent is a persistent ones tensor: autograd would launch a fill per loss for its implicit ones_like
@@ -319,9 +373,12 @@ def mtl_backward_begin(losses, features, aggregator, tasks_params=None, shared_p
         ops.GRAD_ACCUM_TAKEN.clear()
         if i > 0 and ops.L.DEFER is None:
             ops.GRAD_ACCUM.update({p.data_ptr(): p.grad for p in tp if p.grad is not None})
+        ops.COT_SINK.clear()
+        ops.COT_SINK.update({f.data_ptr(): c[i] for f, c in zip(st.feat_diff, cot) if c is not None})
         try:
             got = torch.autograd.grad(loss, tp + st.feat_diff, grad_outputs=seed, retain_graph=True, allow_unused=True)
         finally:
+            ops.COT_SINK.clear()
             ops.GRAD_ACCUM.clear()
             taken = frozenset(ops.GRAD_ACCUM_TAKEN)
             ops.GRAD_ACCUM_TAKEN.clear()
@@ -359,6 +416,7 @@ def mtl_backward_finish(st):
         jb.write_row(i, js)
     if shared_params:
         ops.join_wgrad()  # the Jacobian rows are written by deferred weight-gradient launches
+        jb.settle()
         _aggregate_into_grads(jb, st.aggregator)
 
 

@@ -605,9 +605,19 @@ __global__ __launch_bounds__(256) void igemm_wgrad(const float* __restrict__ S, 
 // (64-byte coalesced rows), then the 16 split-lanes are folded with 4 shuffles.  Deterministic.
 // (all three plain reduces: outputs [0, n1) go to `out`, the tail [n1, total) to `out2` -- the bias-gradient partials a weight-
 // gradient slab carries behind its M * N floats; n1 == total, out2 == null otherwise)
-__global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ slab, float* __restrict__ out, long total,
+// (all four plain reduces: blockIdx.y = cotangent group -- the group's slabs start rg.slab_gs floats further, its destinations are
+// rg.out / rg.out2[group]; one launch for the G weight gradients of a grouped call instead of G)
+struct RGroups {
+    float* out[8];
+    float* out2[8];
+    long slab_gs;
+};
+__global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ slab, RGroups rg, long total,
                                                      int S, int N, const float* __restrict__ bias, int act, float slope,
-                                                     int accumulate, float* __restrict__ out2, long n1, ActMul am) {
+                                                     int accumulate, long n1, ActMul am) {
+    slab += blockIdx.y * rg.slab_gs;
+    float* __restrict__ out = rg.out[blockIdx.y];
+    float* __restrict__ out2 = rg.out2[blockIdx.y];
     const int il = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const long i = (long)blockIdx.x * 16 + il;
     float v = 0.f;
@@ -631,9 +641,11 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ s
 
 // many slabs (S >= 64) over few outputs: 64 split-lanes x 4 float4 columns per block, 4 independent 16-byte loads in
 // flight per lane; the 16 split-lanes of a wave fold with shuffles, the 4 waves through LDS.  Deterministic.
-__global__ __launch_bounds__(256) void splitk_reduce_wide(const float* __restrict__ slab, float* __restrict__ out, long total,
-                                                          int S, int N, const float* __restrict__ bias, int act, float slope,
-                                                          int accumulate, float* __restrict__ out2, long n1, ActMul am) {
+__global__ __launch_bounds__(256) void splitk_reduce_wide(const float* __restrict__ slab, RGroups rg, long total, int S, int N,
+        const float* __restrict__ bias, int act, float slope, int accumulate, long n1, ActMul am) {
+    slab += blockIdx.y * rg.slab_gs;
+    float* __restrict__ out = rg.out[blockIdx.y];
+    float* __restrict__ out2 = rg.out2[blockIdx.y];
     const int il = threadIdx.x & 3, sl = threadIdx.x >> 2;
     const long i = ((long)blockIdx.x * 4 + il) * 4;
     f32x4 acc[4];
@@ -681,9 +693,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_wide(const float* __restric
 // 8 <= S < 64 slabs over MANY outputs (>= 2^19): a thread owns four consecutive outputs and walks the slabs with four 16-byte loads
 // in flight -- the 16-split-lane kernel above reads 4-byte pieces in 64-byte runs, which is what a few hundred outputs per CU need
 // to fill the chip but half the achievable rate on the 2-10 MB results of the C3-C5 weight gradients (14.4 us for 33 MB of slabs).
-__global__ __launch_bounds__(256) void splitk_reduce_vec(const float* __restrict__ slab, float* __restrict__ out, long total, int S,
-                                                         int N, const float* __restrict__ bias, int act, float slope, int accumulate,
-                                                         float* __restrict__ out2, long n1, ActMul am) {
+__global__ __launch_bounds__(256) void splitk_reduce_vec(const float* __restrict__ slab, RGroups rg, long total, int S, int N,
+        const float* __restrict__ bias, int act, float slope, int accumulate, long n1, ActMul am) {
+    slab += blockIdx.y * rg.slab_gs;
+    float* __restrict__ out = rg.out[blockIdx.y];
+    float* __restrict__ out2 = rg.out2[blockIdx.y];
     const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= total) return;
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -708,9 +722,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec(const float* __restrict
 }
 
 // few slabs over many outputs: one thread per output, grid-stride
-__global__ __launch_bounds__(256) void splitk_reduce_flat(const float* __restrict__ slab, float* __restrict__ out, long total,
-                                                          int S, int N, const float* __restrict__ bias, int act, float slope,
-                                                          int accumulate, float* __restrict__ out2, long n1, ActMul am) {
+__global__ __launch_bounds__(256) void splitk_reduce_flat(const float* __restrict__ slab, RGroups rg, long total, int S, int N,
+        const float* __restrict__ bias, int act, float slope, int accumulate, long n1, ActMul am) {
+    slab += blockIdx.y * rg.slab_gs;
+    float* __restrict__ out = rg.out[blockIdx.y];
+    float* __restrict__ out2 = rg.out2[blockIdx.y];
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         float v = 0.f;
@@ -829,30 +845,37 @@ inline long reduce_vec_min() {  // outputs from which the 16-byte reduce serves 
     return v;
 }
 
-inline int launch_reduce(const float* slab, float* out, long n1, int S, int N, const float* bias, int act, float slope,
-                         int accumulate, hipStream_t st, float* out2 = nullptr, long n2 = 0, ActMul am = ActMul{nullptr, 0, 0.f, 0, 0, nullptr}) {
+inline int launch_reduce_groups(const float* slab, const RGroups& rg, int G, long n1, long n2, int S, int N, const float* bias, int act,
+                                float slope, int accumulate, hipStream_t st, ActMul am = ActMul{nullptr, 0, 0.f, 0, 0, nullptr}) {
     if (g_bench_main_only) return MOVAE_OK;
-    if (!out2) n2 = 0;
     const long total = n1 + n2;  // floats per slab: n1 outputs for `out`, then n2 for `out2`
-    if (S >= 64 && total % 4 == 0 && n1 % 4 == 0 && total <= (1L << 20) &&
-        ((reinterpret_cast<uintptr_t>(slab) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(out2)) & 15) == 0) {
-        hipLaunchKernelGGL(splitk_reduce_wide, dim3(ceil_div(total, 16)), dim3(256), 0, st, slab, out, total, S, N, bias, act,
-                           slope, accumulate, out2, n1, am);
-    } else if (S >= 8 && total >= reduce_vec_min() && total % 4 == 0 && n1 % 4 == 0 &&
-               ((reinterpret_cast<uintptr_t>(slab) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(out2)) & 15) == 0) {
-        hipLaunchKernelGGL(splitk_reduce_vec, dim3((unsigned)ceil_div(total / 4, 256)), dim3(256), 0, st, slab, out, total, S, N, bias, act,
-                           slope, accumulate, out2, n1, am);
+    uintptr_t al = reinterpret_cast<uintptr_t>(slab) | (uintptr_t)(rg.slab_gs * 4);
+    for (int i = 0; i < G; ++i) al |= reinterpret_cast<uintptr_t>(rg.out[i]) | reinterpret_cast<uintptr_t>(rg.out2[i]);
+    const bool al16 = (al & 15) == 0;
+    if (S >= 64 && total % 4 == 0 && n1 % 4 == 0 && total <= (1L << 20) && al16) {
+        hipLaunchKernelGGL(splitk_reduce_wide, dim3(ceil_div(total, 16), G), dim3(256), 0, st, slab, rg, total, S, N, bias, act, slope,
+                           accumulate, n1, am);
+    } else if (S >= 8 && total >= reduce_vec_min() && total % 4 == 0 && n1 % 4 == 0 && al16) {
+        hipLaunchKernelGGL(splitk_reduce_vec, dim3((unsigned)ceil_div(total / 4, 256), G), dim3(256), 0, st, slab, rg, total, S, N, bias, act,
+                           slope, accumulate, n1, am);
     } else if (S >= 8 && total <= (1L << 20)) {
-        hipLaunchKernelGGL(splitk_reduce, dim3(ceil_div(total, 16)), dim3(256), 0, st, slab, out, total, S, N, bias, act, slope,
-                           accumulate, out2, n1, am);
+        hipLaunchKernelGGL(splitk_reduce, dim3(ceil_div(total, 16), G), dim3(256), 0, st, slab, rg, total, S, N, bias, act, slope, accumulate,
+                           n1, am);
     } else {
         long gq = (total + 255) / 256;
         if (gq > 4096) gq = 4096;
-        hipLaunchKernelGGL(splitk_reduce_flat, dim3((int)gq), dim3(256), 0, st, slab, out, total, S, N, bias, act, slope,
-                           accumulate, out2, n1, am);
+        hipLaunchKernelGGL(splitk_reduce_flat, dim3((int)gq, G), dim3(256), 0, st, slab, rg, total, S, N, bias, act, slope, accumulate, n1, am);
     }
     MOVAE_CHECK_LAUNCH("splitk_reduce");
     return MOVAE_OK;
+}
+
+inline int launch_reduce(const float* slab, float* out, long n1, int S, int N, const float* bias, int act, float slope,
+                         int accumulate, hipStream_t st, float* out2 = nullptr, long n2 = 0, ActMul am = ActMul{nullptr, 0, 0.f, 0, 0, nullptr}) {
+    if (!out2) n2 = 0;
+    RGroups rg{};
+    rg.out[0] = out, rg.out2[0] = out2, rg.slab_gs = 0;
+    return launch_reduce_groups(slab, rg, 1, n1, n2, S, N, bias, act, slope, accumulate, st, am);
 }
 
 // The reduce of a split-K forward whose result feeds a BatchNorm: sums, adds the bias and emits the column statistics.

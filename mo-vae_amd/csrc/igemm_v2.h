@@ -1604,11 +1604,12 @@ int launch_wgrad2(const float* Sm, const float* Bg, float* const* dW, int G, lon
         hipLaunchKernelGGL((igemm2_wgrad<BM, BN>), dim3(gx, gy, Sp * G), dim3(256), 0, st, a);
         MOVAE_CHECK_LAUNCH("igemm2_wgrad");
     }
-    if (slab)
-        for (int i = 0; i < G; ++i)
-            if (int rc = launch_reduce(out + (long)i * Sp * stride, dW[i], (long)M * N, Sp, N, nullptr, 0, 0.f, accumulate, st,
-                                       colsum ? colsum[i] : nullptr, colsum ? M : 0))
-                return rc;
+    if (slab) {  // ONE reduce launch for all groups (blockIdx.y = group)
+        RGroups rg{};
+        for (int i = 0; i < G; ++i) rg.out[i] = dW[i], rg.out2[i] = colsum ? colsum[i] : nullptr;
+        rg.slab_gs = (long)Sp * stride;
+        return launch_reduce_groups(out, rg, G, (long)M * N, colsum ? M : 0, Sp, N, nullptr, 0, 0.f, accumulate, st);
+    }
     return MOVAE_OK;
 }
 

@@ -66,6 +66,22 @@ __global__ __launch_bounds__(256) void final_sum(const double* __restrict__ part
     if (threadIdx.x == 0) out[0] = (float)(s * factor);
 }
 
+// two loss terms and their sum in one launch: out[0] = f1 * sum(part[0 .. n1)), out[1] = f2 * sum(part[n1 .. n1 + n2)),
+// out[2] = out[0] + out[1] in fp32 (the total_loss of models/vae.py:226: a tensor add of the two fp32 scalars)
+__global__ __launch_bounds__(256) void final_sum2(const double* __restrict__ part, int n1, int n2, double f1, double f2,
+                                                  float* __restrict__ out) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n1; i += 256) s += part[i];
+    s = block_sum_256(s, sh);
+    const float a = (float)(s * f1);
+    double q = 0.0;
+    for (int i = threadIdx.x; i < n2; i += 256) q += part[n1 + i];
+    q = block_sum_256(q, sh);
+    const float b = (float)(q * f2);
+    if (threadIdx.x == 0) out[0] = a, out[1] = b, out[2] = a + b;
+}
+
 __global__ void recon_bwd_k(const float* __restrict__ r, const float* __restrict__ x, const float* __restrict__ gs,
                             float* __restrict__ dr, long n, int kind, float factor) {
     const float f = factor * (gs ? gs[0] : 1.f);
@@ -351,6 +367,29 @@ int movae_kl_fwd(const float* mu, const float* log_var, float* out, int b, int d
     MOVAE_CHECK_LAUNCH("kl_partial");
     hipLaunchKernelGGL(final_sum, dim3(1), dim3(256), 0, (hipStream_t)stream, part, nb, -0.5 * (double)scale / (double)b, out);
     MOVAE_CHECK_LAUNCH("final_sum");
+    return MOVAE_OK;
+}
+
+// models/vae.py:211-228 in three launches instead of five: the two partial-sum passes of movae_recon_loss_fwd / movae_kl_fwd and ONE
+// final kernel that also forms total_loss.  out[3] = (reconstruction_loss, kld_loss, total_loss), each value bit-identical to what
+// the separate entry points + a tensor add give.
+int movae_vae_losses_fwd(const float* recons, const float* inputs, size_t n, int kind, float rec_scale, const float* mu,
+                         const float* log_var, int b, int d, float kl_scale, float* out, void* ws, size_t ws_bytes,
+                         movae_stream_t stream) {
+    MOVAE_WS_SCRATCH(ws, ws_bytes);
+    MOVAE_CHECK_ARG(recons && inputs && mu && log_var && out && n > 0 && b > 0 && d > 0, "movae_vae_losses_fwd: bad argument");
+    MOVAE_CHECK_ARG(kind >= 0 && kind <= 3, "movae_vae_losses_fwd: unknown objective %d", kind);
+    const size_t nk = (size_t)b * d;
+    MOVAE_CHECK_ARG(ws && ws_bytes >= movae_reduce_ws_bytes(n) + movae_reduce_ws_bytes(nk), "movae_vae_losses_fwd: workspace too small");
+    const int nb1 = red_blocks(n), nb2 = red_blocks(nk);
+    double* part = static_cast<double*>(ws);
+    hipLaunchKernelGGL(recon_partial, dim3(nb1), dim3(256), 0, (hipStream_t)stream, recons, inputs, part, (long)n, kind);
+    MOVAE_CHECK_LAUNCH("recon_partial");
+    hipLaunchKernelGGL(kl_partial, dim3(nb2), dim3(256), 0, (hipStream_t)stream, mu, log_var, part + nb1, (long)nk);
+    MOVAE_CHECK_LAUNCH("kl_partial");
+    hipLaunchKernelGGL(final_sum2, dim3(1), dim3(256), 0, (hipStream_t)stream, part, nb1, nb2, (double)rec_scale / (double)n,
+                       -0.5 * (double)kl_scale / (double)b, out);
+    MOVAE_CHECK_LAUNCH("final_sum2");
     return MOVAE_OK;
 }
 

@@ -1,5 +1,7 @@
 """Convolutional VAE on the HIP kernels -- drop-in for the reference's models/vae.py:27-228
 (same constructor signature, state_dict keys, forward / loss_function dictionaries)."""
+import os
+
 import torch
 
 from .. import nn as mnn
@@ -89,6 +91,13 @@ class VAE(HotPathModel):
 
     def loss_function(self, inputs, args: dict) -> dict:
         lw = self.lambda_weights
+        rec_fn, kld_fn = self.objectives["reconstruction_loss"], self.objectives["kld_loss"]
+        if (type(self) is VAE and getattr(rec_fn, "kind", None) in ops.L.RECON and kld_fn is O.kl_divergence and inputs.dim() == 4
+                and args["mu"].dim() == 2 and os.environ.get("MOVAE_FUSE_LOSSES", "1") != "0"):
+            # both terms and their sum from one final kernel (ops.VAELosses): the same values, two launches fewer
+            x, r = ops.to_nhwc(inputs), ops.to_nhwc(args["recons"])
+            rec, kld, total = ops.vae_losses(r, x, rec_fn.kind, lw["reconstruction_loss"], args["mu"], args["log_var"], lw["kld_loss"])
+            return {"reconstruction_loss": rec, "kld_loss": kld, "total_loss": total}
         rec = self.objectives["reconstruction_loss"](inputs, args["recons"], lw["reconstruction_loss"])
         kld = self.objectives["kld_loss"](args["mu"], args["log_var"], lw["kld_loss"])
         return {"reconstruction_loss": rec, "kld_loss": kld, "total_loss": rec + kld}

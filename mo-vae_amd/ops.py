@@ -22,9 +22,17 @@ _call = L.call
 GRAD_SINK = {}
 
 
+#: data_ptr of every sink slice a kernel was handed for WRITING since the log was last cleared (SINK_LOG), and of every slice
+#: handed out as an untouched all-zero gradient (SINK_ZERO_LOG): autojac.JacobianBuffer keeps its arena across steps without
+#: re-zeroing it and uses the two logs to find slices that were written in an earlier step but not in this one.
+SINK_LOG = []
+SINK_ZERO_LOG = []
+
+
 def _sink(param, shape):
     dst = GRAD_SINK.pop(param.data_ptr(), None) if GRAD_SINK else None
     if dst is not None and dst.numel() == param.numel():
+        SINK_LOG.append(dst.data_ptr())
         return dst.view(shape)
     return torch.empty(shape, dtype=param.dtype, device=param.device)
 
@@ -59,6 +67,20 @@ def _accum_targets(w, b, need_b):
     return v, gb
 
 
+#: data_ptr of a FEATURE tensor (autojac.mtl_backward's `features`) -> destination for the gradient of the loss being differentiated
+#: w.r.t. that feature: slice i of a stacked [K, ...] buffer.  The op that produces the feature's cotangent (reparameterize, the KL
+#: term, ...) writes there, so the K cotangents of a feature are born stacked -- no torch.stack launch before the batched
+#: pull-back.  Consumed on first use; an op that does not know about it simply returns its own buffer (and the stack copies).
+COT_SINK = {}
+
+
+def _cot(feature_ptr, like):
+    dst = COT_SINK.pop(feature_ptr, None) if COT_SINK else None
+    if dst is not None and dst.shape == like.shape and dst.dtype == like.dtype and dst.is_contiguous():
+        return dst
+    return torch.empty_like(like)
+
+
 #: batched pull-back (autojac._batched_pullback): one sink dict per cotangent group, same keys as GRAD_SINK
 GRAD_SINK_ROWS = None
 
@@ -68,6 +90,7 @@ def _sink_row(g, param, shape, zeros=False):
     rows = GRAD_SINK_ROWS
     dst = rows[g].pop(param.data_ptr(), None) if rows else None
     if dst is not None and dst.numel() == param.numel():
+        (SINK_ZERO_LOG if zeros else SINK_LOG).append(dst.data_ptr())  # (zeros: the slice is handed out untouched)
         return dst.view(shape)
     return (torch.zeros if zeros else torch.empty)(shape, dtype=param.dtype, device=param.device)
 
@@ -89,6 +112,7 @@ def _sink_zeros(param, shape):
     accumulated into this tensor later is zero as well); nothing here launches a fill per step."""
     dst = GRAD_SINK.pop(param.data_ptr(), None) if GRAD_SINK else None
     if dst is not None and dst.numel() == param.numel():
+        SINK_ZERO_LOG.append(dst.data_ptr())
         return dst.view(shape)
     key = (param.data_ptr(), param.numel(), param.dtype)
     z = _ZERO_GRADS.get(key)
@@ -1211,6 +1235,7 @@ class Reparameterize(Function):
         z = torch.empty_like(mu)
         _call("movae_reparam_fwd", mu.data_ptr(), log_var.data_ptr(), eps.data_ptr(), z.data_ptr(), mu.numel(), _st(mu))
         ctx.save_for_backward(log_var, eps)
+        ctx.in_ptrs = (mu.data_ptr(), log_var.data_ptr())  # (the cotangent sinks are keyed by the feature tensors)
         return z
 
     @staticmethod
@@ -1219,7 +1244,7 @@ class Reparameterize(Function):
             return (None,) * 3
         log_var, eps = ctx.saved_tensors
         dz = _c(dz)
-        dmu, dlv = torch.empty_like(dz), torch.empty_like(dz)
+        dmu, dlv = _cot(ctx.in_ptrs[0], dz), _cot(ctx.in_ptrs[1], dz)
         _call("movae_reparam_bwd", dz.data_ptr(), log_var.data_ptr(), eps.data_ptr(), dmu.data_ptr(), dlv.data_ptr(), dz.numel(), _st(dz))
         return dmu, dlv, None
 
@@ -1360,7 +1385,7 @@ class KLDivergence(Function):
         mu, log_var = ctx.saved_tensors
         g = _c(g)
         b, d = mu.shape
-        dmu, dlv = torch.empty_like(mu), torch.empty_like(mu)
+        dmu, dlv = _cot(mu.data_ptr(), mu), _cot(log_var.data_ptr(), mu)
         _call("movae_kl_bwd", mu.data_ptr(), log_var.data_ptr(), g.data_ptr(), dmu.data_ptr(), dlv.data_ptr(), b, d,
               float(ctx.scale), _st(mu))
         return dmu, dlv, None
@@ -1368,6 +1393,51 @@ class KLDivergence(Function):
 
 def kl_divergence(mu, log_var, scale=1.0):
     return KLDivergence.apply(mu, log_var, scale)
+
+
+class VAELosses(Function):
+    """(reconstruction_loss, kld_loss, total_loss) of models/vae.py:211-228 in three launches instead of five (the two partial-sum
+    passes and ONE final kernel that also adds the two): scale_r * mean(objective(recons, inputs)), scale_k * kl(mu, log_var) and
+    their fp32 sum.  Bit-identical to ReconLoss + KLDivergence + a tensor add.  The backward serves whichever of the three
+    cotangents arrive (mtl_backward differentiates the components one at a time, `--agg sum` the total)."""
+
+    @staticmethod
+    def forward(ctx, recons, inputs, kind, scale_r, mu, log_var, scale_k):
+        ctx.set_materialize_grads(False)
+        L.require_gpu(recons)
+        recons, inputs, mu, log_var = _c(recons), _c(inputs), _c(mu), _c(log_var)
+        assert recons.shape == inputs.shape, (recons.shape, inputs.shape)
+        b, d = mu.shape
+        out = torch.empty(3, dtype=recons.dtype, device=recons.device)
+        wsp, wsb = _ws(recons)
+        _call("movae_vae_losses_fwd", recons.data_ptr(), inputs.data_ptr(), recons.numel(), L.RECON[kind], float(scale_r), mu.data_ptr(),
+              log_var.data_ptr(), b, d, float(scale_k), out.data_ptr(), wsp, wsb, _st(recons))
+        ctx.kind, ctx.scale_r, ctx.scale_k = kind, scale_r, scale_k
+        ctx.save_for_backward(recons, inputs, mu, log_var)
+        return out[0], out[1], out[2]
+
+    @staticmethod
+    def backward(ctx, g_rec, g_kld, g_tot):
+        recons, inputs, mu, log_var = ctx.saved_tensors
+        both = lambda a, b: a if b is None else (b if a is None else a + b)  # noqa: E731  (total_loss feeds both terms)
+        gr, gk = both(g_rec, g_tot), both(g_kld, g_tot)
+        dr = dmu = dlv = None
+        if gr is not None and ctx.needs_input_grad[0]:
+            gr = _c(gr)
+            dr = torch.empty_like(recons)
+            _call("movae_recon_loss_bwd", recons.data_ptr(), inputs.data_ptr(), gr.data_ptr(), dr.data_ptr(), recons.numel(),
+                  L.RECON[ctx.kind], float(ctx.scale_r), _st(recons))
+        if gk is not None and (ctx.needs_input_grad[4] or ctx.needs_input_grad[5]):
+            gk = _c(gk)
+            b, d = mu.shape
+            dmu, dlv = _cot(mu.data_ptr(), mu), _cot(log_var.data_ptr(), mu)
+            _call("movae_kl_bwd", mu.data_ptr(), log_var.data_ptr(), gk.data_ptr(), dmu.data_ptr(), dlv.data_ptr(), b, d,
+                  float(ctx.scale_k), _st(mu))
+        return dr, None, None, None, dmu, dlv, None
+
+
+def vae_losses(recons, inputs, kind, scale_r, mu, log_var, scale_k):
+    return VAELosses.apply(recons, inputs, kind, scale_r, mu, log_var, scale_k)
 
 
 class TCDecomposition(Function):

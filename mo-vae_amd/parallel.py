@@ -49,6 +49,21 @@ class DataParallelGrads:
     def __init__(self, rank, world_size, local_rank, backend):
         self.rank, self.world_size, self.local_rank, self.backend = rank, world_size, local_rank, backend
         self.params = []
+        self.flat, self.views, self._arena_sig = None, None, None  # the eager path's persistent flat arena and one view per parameter
+
+    def _arena(self):
+        """One flat fp32 buffer for the whole gradient, allocated once; views[i] has parameter i's shape AND strides (conv
+        weights are channels_last), so a gradient copied into it lies in the parameter's memory order and `.grad = views[i]`
+        afterwards needs no unflatten pass."""
+        if self.flat is None or self.flat.device != self.params[0].device or self._arena_sig != [(id(p), p.numel()) for p in self.params]:
+            n = sum(p.numel() for p in self.params)
+            self.flat = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
+            self.views, off = [], 0
+            for p in self.params:
+                self.views.append(self.flat[off: off + p.numel()].as_strided(p.shape, p.stride()))
+                off += p.numel()
+            self._arena_sig = [(id(p), p.numel()) for p in self.params]
+        return self.flat, self.views
 
     @classmethod
     def from_env(cls, backend=None):
@@ -76,12 +91,31 @@ class DataParallelGrads:
         for t in list(net.parameters()) + list(net.buffers()):
             dist.broadcast(t.data, src=0)
 
+    @torch.no_grad()
     def all_reduce_grads(self):
-        """mean over ranks of the full flat gradient: ONE collective per step."""
-        flat = flatten_grads(self.params)
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat.div_(self.world_size)
-        unflatten_into_grads(flat, self.params)
+        """mean over ranks of the full flat gradient: ONE collective per step, on a PERSISTENT arena -- no per-step
+        torch.cat into a fresh 13-68 MB tensor: the step's gradients are copied into the arena's views by one multi-tensor
+        copy, RCCL averages in the collective (ncclAvg; gloo, the CPU rehearsal, has no AVG: sum, then scale), and `.grad`
+        becomes the arena's views (the optimizer reads the bucket in place)."""
+        flat, views = self._arena()
+        src, dst = [], []
+        for p, v in zip(self.params, views):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                if p.grad.shape != p.shape:
+                    raise RuntimeError(f"gradient shape {tuple(p.grad.shape)} does not match its parameter {tuple(p.shape)}")
+                src.append(p.grad)
+                dst.append(v)
+        if src:
+            torch._foreach_copy_(dst, src)
+        if self.backend == "nccl":
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            flat.div_(self.world_size)
+        for p, v in zip(self.params, views):
+            p.grad = v
         return flat
 
     def barrier(self):

@@ -30,7 +30,7 @@ def pytest_collection_finish(session):
     import subprocess
     import tempfile
 
-    if not any(it.name.startswith("test_two_rank_data_parallel") for it in session.items) or not os.path.exists("/dev/kfd"):
+    if not any(it.name.startswith("test_two_rank_") for it in session.items) or not os.path.exists("/dev/kfd"):
         return
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

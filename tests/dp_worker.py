@@ -20,6 +20,18 @@ class Args:
 
 
 CFG = dict(arch="vae", input_size=32, latent_dim=16, hidden_dims=[16, 32, 64], dataset_size=1000, global_batch=16, ragged=5)
+#: the overlapped two-bucket form (MOVAE_DP_OVERLAP=1: graph 1 | all-reduce(task-side bucket) under graph 1b | all-reduce(shared
+#: bucket) | graph 2) on a model whose task-side / shared split is not trivial: the VQ-VAE's codebook and decoder are task-side
+#: (early bucket), the encoder is shared (late bucket)
+CFG_VQ = dict(arch="vq_vae", input_size=16, embedding_dim=8, num_embeddings=16, hidden_dims=[8, 16], num_residual_layers=2,
+              dataset_size=1000, global_batch=8, agg="aligned_mtl")
+
+
+def make_inputs_vq():
+    import torch
+
+    g = torch.Generator().manual_seed(91)
+    return torch.rand(CFG_VQ["global_batch"], 3, CFG_VQ["input_size"], CFG_VQ["input_size"], generator=g)
 
 
 def make_inputs():
@@ -92,11 +104,34 @@ def main():
     train_step(net, x2[rg].to(dev), opt, agg, a, dp)
     torch.cuda.synchronize()
     res["ragged"] = {n: p.detach().cpu().numpy().copy() for n, p in net.named_parameters()}
+    # (d) the overlapped two-bucket form, VQ-VAE with Aligned-MTL: one replayed step from rank 0's init
+    xv = make_inputs_vq()
+    perv = CFG_VQ["global_batch"] // o.world
+    av = Args(arch=CFG_VQ["arch"], batch_size=CFG_VQ["global_batch"], dataset_size=CFG_VQ["dataset_size"], recons_objective="mse",
+              recons_activation=None, loss_weights=None, agg_norm_eps=1e-4, agg_reg_eps=1e-4, mgda_epsilon=1e-5, mgda_max_iters=250,
+              pref_weights=None, optimizer="adam", lr=1e-3, wd=0, momentum=0.9, embedding_dim=CFG_VQ["embedding_dim"],
+              num_embeddings=CFG_VQ["num_embeddings"], hidden_dims=CFG_VQ["hidden_dims"],
+              num_residual_layers=CFG_VQ["num_residual_layers"], aggregator=CFG_VQ["agg"], max_grad_norm=None)
+    torch.manual_seed(9 + 100 * o.rank)
+    netv = get_network(CFG_VQ["input_size"], 3, av, dev).to(dev).train()
+    dp.attach(netv)
+    res["vq_init"] = {n: p.detach().cpu().numpy().copy() for n, p in netv.named_parameters()}
+    os.environ["MOVAE_DP_OVERLAP"] = "1"
+    try:
+        gv = GraphedTrainStep(netv, make_optimizer(netv, av, capturable=True), aggregation.make_aggregator(av), av,
+                              xv[o.rank * perv: (o.rank + 1) * perv].to(dev), dp=dp, preserve_state=True)
+    finally:
+        del os.environ["MOVAE_DP_OVERLAP"]
+    gv.step(xv[o.rank * perv: (o.rank + 1) * perv].to(dev))
+    torch.cuda.synchronize()
+    res["vq_overlap"] = {n: p.detach().cpu().numpy().copy() for n, p in netv.named_parameters()}
     flat = {}
-    for case in ("init", "eager", "graph", "ragged"):
+    for case in ("init", "eager", "graph", "ragged", "vq_init", "vq_overlap"):
         for n, v in res[case].items():
             flat[f"{case}/{n}"] = v
     flat["graph_form"] = np.array(res["graph_form"])
+    flat["vq_form"] = np.array(gv.dp_form)
+    flat["vq_buckets"] = np.array([gv.flat_a.numel(), gv.flat_b.numel() if gv.flat_b is not None else 0])
     np.savez(os.path.join(o.out, f"rank{o.rank}.npz"), **flat)
     dp.barrier()
     dp.shutdown()

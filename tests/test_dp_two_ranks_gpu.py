@@ -61,3 +61,49 @@ def test_two_rank_data_parallel_step_equals_mean_over_shards(gpu_device):
     # the eager and the replayed form of the same step agree tightly with each other
     for n in names:
         np.testing.assert_allclose(r0[f"graph/{n}"], r0[f"eager/{n}"], rtol=1e-4, atol=2e-6, err_msg=f"graph vs eager {n}")
+
+
+def _oracle_vq_overlap_step():
+    from dp_worker import CFG_VQ, make_inputs_vq
+    from oracle import nets
+    from oracle.step import OracleTrainer
+
+    x = make_inputs_vq()
+    cfg = nets.make_cfg(CFG_VQ["arch"], CFG_VQ["input_size"], CFG_VQ["global_batch"], CFG_VQ["dataset_size"],
+                        embedding_dim=CFG_VQ["embedding_dim"], num_embeddings=CFG_VQ["num_embeddings"], hidden_dims=CFG_VQ["hidden_dims"],
+                        num_residual_layers=CFG_VQ["num_residual_layers"])
+    tr = OracleTrainer(cfg, seed=9, agg=CFG_VQ["agg"])
+    init = {n: p.detach().clone().numpy() for n, p in tr.params.items()}
+    per = CFG_VQ["global_batch"] // 2
+    shard_grads = [tr.grads(x[:per])[2], tr.grads(x[per:])[2]]
+    mean = {n: sum(g[n] for g in shard_grads) / 2 for n in tr.params}
+    for n, p in tr.params.items():
+        p.grad = mean[n].detach().clone()
+    tr.opt.step()
+    return init, {n: p.detach().clone().numpy() for n, p in tr.params.items()}, {n: float(mean[n].abs().max()) for n in mean}
+
+
+def test_two_rank_overlapped_two_bucket_step_equals_mean_over_shards(gpu_device):
+    """The form a 68 MB gradient (C5) takes on 8 GPUs -- graph 1 | all-reduce of the task-side bucket while graph 1b pulls the
+    cotangents through the shared trunk | all-reduce of the shared bucket | graph 2 -- with TWO ranks, where a wrong early / late
+    parameter partition or a bucket offset error cannot hide behind a mean over one rank (train.py GraphedTrainStep).  VQ-VAE:
+    the codebook and the decoder are task-side (early bucket), the encoder is shared (late bucket)."""
+    ch = conftest.DP_CHILDREN
+    if not ch:
+        pytest.skip("the two rank processes were not started (no /dev/kfd at collection time)")
+    for r, p in enumerate(ch["procs"]):
+        rc = p.wait(timeout=900)
+        assert rc == 0, f"rank {r} failed (rc {rc}):\n" + open(f"{ch['out']}/rank{r}.log").read()[-4000:]
+    r0, r1 = (np.load(f"{ch['out']}/rank{r}.npz") for r in range(2))
+    assert str(r0["vq_form"]) == "3 graphs, two overlapped all-reduces" and str(r1["vq_form"]) == str(r0["vq_form"])
+    early, late = (int(v) for v in r0["vq_buckets"])
+    init, want, gmax = _oracle_vq_overlap_step()
+    n_shared = sum(v.size for n, v in init.items() if n.startswith("encoder."))
+    n_task = sum(v.size for n, v in init.items() if not n.startswith("encoder."))
+    assert (early, late) == (n_task, n_shared), f"buckets {(early, late)}: expected task-side {n_task} (decoder + codebook), shared {n_shared} (encoder)"
+    for n in init:
+        assert np.array_equal(r0[f"vq_init/{n}"], init[n]) and np.array_equal(r1[f"vq_init/{n}"], init[n]), f"attach(): {n}"
+        a, b = r0[f"vq_overlap/{n}"], r1[f"vq_overlap/{n}"]
+        assert np.array_equal(a, b), f"ranks hold different parameters after the overlapped step: {n}"
+        # (Adam turns a ~zero gradient's rounding noise into a +-lr step: the slack of the test above)
+        np.testing.assert_allclose(a, want[n], rtol=2e-4, atol=(2.1e-3 if gmax[n] < 1e-6 else 3e-5), err_msg=f"overlapped step {n}")
