@@ -42,6 +42,7 @@ CONV_CALLS = {"movae_conv2d_fwd", "movae_conv2d_dgrad", "movae_conv2d_wgrad", "m
 PAIR_CALLS = {"movae_linear_pair_fwd", "movae_linear_pair_bwd"}  # fc_mu || fc_var (conv family: 1x1 convs on a 1x1 image)
 POOL_BATCHES = 24               # distinct synthetic batches cycled by the timed loop (>= 20)
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA, dense (--dtype bf16 only)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -355,6 +356,9 @@ def main():
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the step as one captured hipGraph (auto = on)")
     ap.add_argument("--kernel-table", type=str, default=None, help="write the per-launch conv table (JSON) here")
+    ap.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32",
+                    help="fp32 = the reference's arithmetic (default, the headline).  bf16 (opt-in, never the default): bf16 operands / "
+                         "fp32 accumulate in the 128x128 implicit-GEMM kernels; the line's `dtype` then says bf16")
     args = ap.parse_args()
 
     cfg = dict(CONFIGS[args.config])
@@ -377,6 +381,7 @@ def main():
 
     from movae_amd.train import GraphedTrainStep
 
+    L.set_compute_dtype(args.dtype)  # fp32 unless --dtype bf16 (opt-in; include/movae.h: movae_set_compute_dtype)
     dp = DataParallelGrads.from_env() if (world > 1 or os.environ.get("MOVAE_FORCE_DP")) else None
     use_graph = args.graph != "off"  # every hot-path model is capturable (no host reads inside the step)
     # the CPU leg runs FIRST (rank 0, N = 1): the GPU then stays busy from here to the end of the run, which is what a coarse
@@ -478,7 +483,7 @@ def main():
             gk["gflop"] += r["gflop"]
             gk["gflop_x"] += r["gflop_executed"]
             gk["n"] += 1
-        mfma_groups = {k: v for k, v in groups.items() if k.startswith("igemm")} or groups
+        mfma_groups = {k: v for k, v in groups.items() if k.startswith(("igemm", "kgemm", "kpair"))} or groups
         dom = max(mfma_groups, key=lambda k: mfma_groups[k]["us"])
         d = groups[dom]
         # memory-side bytes per launch of that kernel from the committed PMC passes (profiles/pmc_traffic_<cfg>.json)
@@ -492,10 +497,12 @@ def main():
         achieved = d["gflop"] * 1e9 / (d["us"] * 1e-6) / 1e12 if d["us"] > 0 else 0.0
         achieved_x = d["gflop_x"] * 1e9 / (d["us"] * 1e-6) / 1e12 if d["us"] > 0 else 0.0
         fam = tot_gf * 1e9 / (tot_us * 1e-6) / 1e12 if tot_us > 0 else 0.0
-        roofline = dict(bound="mfma", kernel=dom + " (implicit-GEMM conv, v_mfma_f32_32x32x2_f32)",
-                        achieved=round(achieved, 3), peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_source,
-                        achieved_executed_taps=round(achieved_x, 3), frac_executed_taps=round(achieved_x / FP32_MFMA_PEAK_TFLOPS, 4),
+        bf_dom = ",true>" in dom and dom.startswith("igemm2_")  # the dominant launch multiplies on the bf16 pipe (--dtype bf16)
+        peak = BF16_MFMA_PEAK_TFLOPS if bf_dom else FP32_MFMA_PEAK_TFLOPS
+        roofline = dict(bound="mfma", kernel=dom + (" (implicit-GEMM conv, v_mfma_f32_32x32x16_bf16)" if bf_dom else " (implicit-GEMM conv, v_mfma_f32_32x32x2_f32)"),
+                        achieved=round(achieved, 3), peak=peak, unit="TFLOP/s",
+                        frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_source,
+                        achieved_executed_taps=round(achieved_x, 3), frac_executed_taps=round(achieved_x / peak, 4),
                         flop_counting="achieved: nominal 2*MACs incl. padding taps (SURVEY 8d); *_executed_taps: only taps that meet data",
                         launches_per_step=d["n"], avg_launch_us=round(d["us"] / d["n"], 2),
                         flop_per_launch=round(d["gflop"] * 1e9 / d["n"]), algorithmic_bytes_per_launch=round(alg_bytes),
@@ -515,7 +522,7 @@ def main():
         out = {
             "metric": "training images/sec", "value": n_img / elapsed, "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": cfg["label"], "arch": cfg["arch"], "aggregator": cfg["agg"], "per_gpu_batch": cfg["batch"],
                        "global_batch": cfg["batch"] * world, "image": f"3x{cfg['size']}x{cfg['size']}",
                        "parallelism": f"dp{world}", "optimizer": "adam", "final_total_loss": final_loss,
@@ -530,7 +537,9 @@ def main():
                                            "step_gflop_issued_executed_taps counts only taps that meet data -- divide THOSE by ms_per_step"),
                        "step_gflop_issued": round(issued_gflop, 3) if issued_gflop is not None else None,
                        "step_gflop_issued_executed_taps": round(issued_gflop_x, 3) if issued_gflop_x is not None else None,
-                       "parity": ("fp32 end to end (the reference's arithmetic; BASELINE's bf16 leg is not built); models / losses / "
+                       "parity": ("OPT-IN bf16 operands / fp32 accumulation in the 128x128 implicit-GEMM kernels only (everything else fp32); NOT "
+                                  "the parity path: held to its own tolerance, tests/test_hip_bf16.py" if args.dtype == "bf16" else
+                                  "fp32 end to end (the reference's arithmetic; bf16 operands are an opt-in, --dtype bf16, never this line); models / losses / "
                                   "MGDA / Aligned-MTL pinned by golden vectors of the reference, UPGrad + mtl_backward restate torchjd "
                                   "(absent: docstring KAT, unit-weights invariant, scipy cross-check); element-wise vs the oracle at "
                                   "this shape and the 1-epoch ELBO trajectory: tests/test_hip_parity_full.py")},

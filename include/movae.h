@@ -289,6 +289,16 @@ int movae_clip_grad_norm_multi(int n_tensors, float* const* g, const size_t* num
 int movae_sumsq(const float* x, size_t n, float* out, void* ws, size_t ws_bytes, movae_stream_t stream);
 int movae_scale_by_clip(float* g, size_t n, const float* sumsq_dev, float max_norm, movae_stream_t stream);
 
+/* ---- opt-in reduced-precision operands (BASELINE.json configs[1] names bf16; the reference itself is fp32 end to end) ----------
+ * MOVAE_DTYPE_BF16: the 128x128 implicit-GEMM convolution kernels (forward, input gradient, weight gradient -- the layers that
+ * are MFMA-bound at the C3-C5 shapes) round their two operands to bf16 on the way into LDS and multiply on
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation; tensors in memory, master weights, BatchNorm, losses, aggregation and the
+ * optimizer stay fp32.  Process-wide, returns the previous setting.  The default, MOVAE_DTYPE_F32, is the parity path: results
+ * under bf16 are held to their own, looser tolerance (tests/test_hip_bf16.py), never to the fp32 oracle's. */
+#define MOVAE_DTYPE_F32 0
+#define MOVAE_DTYPE_BF16 1
+int movae_set_compute_dtype(int dtype);
+
 /* ---- measurement hook (bench.py's roofline leg only; no reference counterpart) ------------------------
  * on != 0: the conv family launches ONLY its main MFMA kernel (split-K reduce / bias column-sum launches are
  * skipped, so outputs are incomplete) so that one kernel can be timed between HIP events.  Process-wide;

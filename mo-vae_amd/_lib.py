@@ -126,6 +126,7 @@ SIGNATURES = {
     "movae_bench_last_kernel": ([], C.c_char_p),
     "movae_bench_force_split": ([_i], _i),
     "movae_bench_force_kgemm": ([_i], _i),
+    "movae_set_compute_dtype": ([_i], _i),
 }
 
 _lib = None
@@ -174,6 +175,18 @@ def load():
             fn.restype = res
         _lib = lib
     return _lib
+
+
+DTYPES = {"fp32": 0, "f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
+
+
+def set_compute_dtype(name):
+    """"fp32" (default, the parity path) | "bf16": bf16 operands / fp32 accumulation in the 128x128 implicit-GEMM kernels
+    (include/movae.h: movae_set_compute_dtype).  Returns the previous setting's name."""
+    if name not in DTYPES:
+        raise ValueError(f"compute dtype must be one of {sorted(set(DTYPES))}, got {name!r}")
+    prev = load().movae_set_compute_dtype(DTYPES[name])
+    return "bf16" if prev == 1 else "fp32"
 
 
 TRACE = None  # optional callable(name, args) invoked for every C-ABI launch (bench.py's recorder)

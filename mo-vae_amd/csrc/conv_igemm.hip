@@ -838,6 +838,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats(const float* __restri
 const char* g_last_kernel = "";  // movae_bench_last_kernel(): main kernel chosen by the most recent conv-family dispatch
 int g_force_split = 0;           // movae_bench_force_split(): > 0 pins the split-K factor (tuning sweeps)
 bool g_bench_main_only = false;  // movae_bench_main_kernel_only(): time the MFMA kernel without its epilogue launches
+int g_compute_bf16 = 0;          // movae_set_compute_dtype(): 1 = bf16 operands (fp32 accumulate) in the 128x128 implicit-GEMM kernels
 int g_force_kgemm = 0;           // movae_bench_force_kgemm(): 1 = every shape kgemm.h can serve takes it, -1 = none does (tests, A/B)
 
 inline long reduce_vec_min() {  // outputs from which the 16-byte reduce serves 8 <= S < 64 (tuning knob)
@@ -1075,7 +1076,7 @@ int launch_fwd(const float* X, const float* W, float* Y, const Geom& g_in, const
     if (g.Cr % 4 == 0 && aligned16(X) && aligned16(W) && span_ok) {
         if (g.Nn <= 32) return (g_last_kernel = "igemm2_fwd<128,32>", v2::launch_fwd2<128, 32>(X, W, Y, g, ep, M, K, ws, ws_bytes, st));
         // 2x2 register tiling (64x64 per wave) once the 128x128 grid alone fills the chip
-        if (g.Nn >= 128 && (Ml / 128) * (g.Nn / 128) >= big_tile_min()) return (g_last_kernel = "igemm2_fwd<128,128>", v2::launch_fwd2<128, 128>(X, W, Y, g, ep, M, K, ws, ws_bytes, st));
+        if (g.Nn >= 128 && (Ml / 128) * (g.Nn / 128) >= big_tile_min()) return (g_last_kernel = g_compute_bf16 ? "igemm2_fwd<128,128,true>" : "igemm2_fwd<128,128>", v2::launch_fwd2<128, 128>(X, W, Y, g, ep, M, K, ws, ws_bytes, st));
         if (Ml >= 128 * 512) return (g_last_kernel = "igemm2_fwd<128,64>", v2::launch_fwd2<128, 64>(X, W, Y, g, ep, M, K, ws, ws_bytes, st));
         return (g_last_kernel = "igemm2_fwd<64,64>", v2::launch_fwd2<64, 64>(X, W, Y, g, ep, M, K, ws, ws_bytes, st));
     }
@@ -1144,7 +1145,7 @@ int launch_bwd(const float* X, const float* W, float* Y, const Geom& g, const Ep
     if (g.Cr % 4 == 0 && g.Nn % 4 == 0 && g.stride <= 2 && aligned16(X) && aligned16(W) && aligned16(Y) && span_ok) {
         if (g.Nn <= 32) return (g_last_kernel = "igemm2_bwd<128,32>", v2::launch_bwd2<128, 32>(X, W, Y, g, ep, ws, ws_bytes, st));
         if (g.Nn >= 128 && (Mc / 128) * (g.Nn / 128) * g.stride * g.stride >= big_tile_min())
-            return (g_last_kernel = "igemm2_bwd<128,128>", v2::launch_bwd2<128, 128>(X, W, Y, g, ep, ws, ws_bytes, st));
+            return (g_last_kernel = g_compute_bf16 ? "igemm2_bwd<128,128,true>" : "igemm2_bwd<128,128>", v2::launch_bwd2<128, 128>(X, W, Y, g, ep, ws, ws_bytes, st));
         if (Mc >= 128 * 512) return (g_last_kernel = "igemm2_bwd<128,64>", v2::launch_bwd2<128, 64>(X, W, Y, g, ep, ws, ws_bytes, st));
         return (g_last_kernel = "igemm2_bwd<64,64>", v2::launch_bwd2<64, 64>(X, W, Y, g, ep, ws, ws_bytes, st));
     }
@@ -1238,7 +1239,7 @@ int launch_wgrad(const float* S, const float* Bg, float* const* dW, int G, long 
         // <= 32 rows of dW (32-channel layers): a 64-row tile would multiply half a tile of padding
         if (g.Cs <= 32 && N >= 128) return (g_last_kernel = "igemm2_wgrad<32,128>", v2::launch_wgrad2<32, 128>(S, Bg, dW, G, s_gs, b_gs, g, (int)Kl, accumulate, ws, ws_bytes, st, cs));
         if (g.Cs >= 128 && (long)(g.Cs / 128) * (N / 128) * (Kl / 512) * G >= big_tile_min())
-            return (g_last_kernel = "igemm2_wgrad<128,128>", v2::launch_wgrad2<128, 128>(S, Bg, dW, G, s_gs, b_gs, g, (int)Kl, accumulate, ws, ws_bytes, st, cs));
+            return (g_last_kernel = g_compute_bf16 ? "igemm2_wgrad<128,128,true>" : "igemm2_wgrad<128,128>", v2::launch_wgrad2<128, 128>(S, Bg, dW, G, s_gs, b_gs, g, (int)Kl, accumulate, ws, ws_bytes, st, cs));
         // 64 rows of dW with a long reduction (C5: 32 -> 64 channels on 64 x 64 images, four cotangent groups): a 64-wide tile moves
         // 16 KiB of operands per 64 x 64 x 32 MACs -- 16 flop per byte from L2, bandwidth-bound near 0.6 of the MFMA peak; twice the
         // width reads the S operand half as often.  Unpaired (work of this size fills the chip on its own).
@@ -1338,6 +1339,12 @@ const char* movae_bench_last_kernel(void) { return g_last_kernel; }
 int movae_bench_force_split(int s) {
     const int prev = g_force_split;
     g_force_split = s > 0 ? s : 0;
+    return prev;
+}
+
+int movae_set_compute_dtype(int dtype) {
+    const int prev = g_compute_bf16 ? MOVAE_DTYPE_BF16 : MOVAE_DTYPE_F32;
+    g_compute_bf16 = dtype == MOVAE_DTYPE_BF16 ? 1 : 0;
     return prev;
 }
 

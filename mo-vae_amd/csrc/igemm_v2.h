@@ -107,6 +107,41 @@ __device__ __forceinline__ void mma_kk(const float* __restrict__ As, const float
     }
 }
 
+// ---- opt-in bf16 operands (movae_set_compute_dtype(1); fp32 stays the default and the parity path) --------------------------
+// The SAME kernels with bf16 operand tiles in LDS and v_mfma_f32_32x32x16_bf16 (16x the fp32 matrix rate): global loads, the
+// virtual-operand transform, every epilogue and the fp32 accumulators are unchanged -- operands are rounded to bf16 (RNE,
+// v_cvt_pk_bf16_f32) on their way into LDS, where EVERY operand lives row-major [row][k] (k-major operands are transposed by
+// their 2-byte stores), 32 k = 64 bytes per row + 16 bytes of padding (80-byte rows: conflict-free 16-lane groups for the
+// ds_read_b128 that fetches a lane's 8 consecutive k).  Lane (r, h) of a 32x32x16 MFMA holds A[r][8h + j], B[8h + j][r].
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int LDH = BK2 + 8;  // halfs per LDS row
+static_assert(BK2 == 32, "the bf16 stage is two 16-deep MFMA steps");
+
+__device__ __forceinline__ void st_row4(__bf16* __restrict__ base, int row, int k4, f32x4 v) {  // 4 consecutive k of one row
+    *reinterpret_cast<bf16x4*>(base + row * LDH + k4) = __builtin_convertvector(v, bf16x4);
+}
+__device__ __forceinline__ void st_col4(__bf16* __restrict__ base, int row4, int k, f32x4 v) {  // one k of 4 consecutive rows
+#pragma unroll
+    for (int j = 0; j < 4; ++j) base[(row4 + j) * LDH + k] = (__bf16)v[j];
+}
+
+template <int TM, int TN, int PART>  // PART 0 / 1: the stage's first / second 16 reduction indices
+__device__ __forceinline__ void mma_bf(const __bf16* __restrict__ As, const __bf16* __restrict__ Bs, int a_row, int b_row,
+                                       f32x16 (&acc)[TM * TN]) {
+    const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
+    bf16x8 a[TM], b[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) b[tn] = *reinterpret_cast<const bf16x8*>(Bs + (b_row + tn * 32 + l31) * LDH + 16 * PART + 8 * half);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) a[tm] = *reinterpret_cast<const bf16x8*>(As + (a_row + tm * 32 + l31) * LDH + 16 * PART + 8 * half);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+            acc[tm * TN + tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], b[tn], acc[tm * TN + tn], 0, 0, 0);
+}
+
 #define ZERO4 (f32x4{0.f, 0.f, 0.f, 0.f})
 
 // Stage order inside the (single basic block) k loop: first MFMA half | LDS stores of the prefetched stage | address arithmetic and
@@ -161,12 +196,15 @@ struct FwdSmem {
     static constexpr int FLOATS = (T2<BM, BN>::DB ? 2 : 1) * (ASZ + BSZ);
 };
 
-template <int BM, int BN>
+template <int BM, int BN, bool BF = false>
 __device__ __forceinline__ void igemm2_fwd_body(const FwdArgs& a, float* __restrict__ smem, int bx, int by, int bz) {
     using T = T2<BM, BN>;
     constexpr int ASZ = BM * LDR, BSZ = BN * LDR;
     float* As = smem;                                   // double buffered when it fits
     float* Bs = smem + (T::DB ? 2 : 1) * ASZ;
+    constexpr int ASZH = BM * LDH, BSZH = BN * LDH;    // BF: bf16 tiles (in halfs), both operands [row][k]
+    __bf16* AsH = reinterpret_cast<__bf16*>(smem);
+    __bf16* BsH = AsH + 2 * ASZH;
     const float* __restrict__ X = a.X;
     const float* __restrict__ W = a.W;
     float* __restrict__ Y = a.Y;
@@ -288,10 +326,22 @@ __device__ __forceinline__ void igemm2_fwd_body(const FwdArgs& a, float* __restr
                 for (int i = 0; i < AC; ++i)
                     ra[i] = norm_apply_if((amask >> i) & 1u, ra[i], nsa, nsb, nslope);
             }
+            if constexpr (BF) {
+    #pragma unroll
+                for (int i = 0; i < AC; ++i) st_row4(AsH + buf * ASZH, r8 + RPP * i, kq * 4, ra[i]);
+    #pragma unroll
+                for (int i = 0; i < BC; ++i) st_row4(BsH + buf * BSZH, r8 + RPP * i, kq * 4, rb[i]);
+                return;
+            }
     #pragma unroll
             for (int i = 0; i < AC; ++i) *reinterpret_cast<f32x4*>(As + buf * ASZ + (r8 + RPP * i) * LDR + kq * 4) = ra[i];
     #pragma unroll
             for (int i = 0; i < BC; ++i) *reinterpret_cast<f32x4*>(Bs + buf * BSZ + (r8 + RPP * i) * LDR + kq * 4) = rb[i];
+        };
+        auto mma = [&](auto part_c, int cur) {
+            constexpr int PART = decltype(part_c)::value;
+            if constexpr (BF) mma_bf<T::TM, T::TN, PART>(AsH + cur * ASZH, BsH + cur * BSZH, wm * T::TM * 32, wn * T::TN * 32, acc);
+            else mma_rr<T::TM, T::TN, PART>(As + cur * ASZ, Bs + cur * BSZ, wm * T::TM * 32, wn * T::TN * 32, acc);
         };
         // software pipeline: stage t is multiplied out of LDS buffer t&1 while the registers of stage t+1 are
         // written to the other buffer between the two MFMA halves and the loads of stage t+2 are issued; one
@@ -306,12 +356,12 @@ __device__ __forceinline__ void igemm2_fwd_body(const FwdArgs& a, float* __restr
         }
         for (int it = 0; it < nkt; ++it) {
             const int cur = it & 1;
-            mma_rr<T::TM, T::TN, 0>(As + cur * ASZ, Bs + cur * BSZ, wm * T::TM * 32, wn * T::TN * 32, acc);
+            mma(std::integral_constant<int, 0>{}, cur);
             MOVAE_SCHED_PIN();
             store_tile(cur ^ 1);
             MOVAE_SCHED_PIN();
             load_tile(kt_begin + it + 2);
-            mma_rr<T::TM, T::TN, 1>(As + cur * ASZ, Bs + cur * BSZ, wm * T::TM * 32, wn * T::TN * 32, acc);
+            mma(std::integral_constant<int, 1>{}, cur);
             __syncthreads();
         }
     };
@@ -494,10 +544,10 @@ __device__ __forceinline__ void igemm2_fwd_body(const FwdArgs& a, float* __restr
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool BF = false>
 __global__ __launch_bounds__(256) void igemm2_fwd(FwdArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[FwdSmem<BM, BN>::FLOATS];
-    igemm2_fwd_body<BM, BN>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+    igemm2_fwd_body<BM, BN, BF>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -527,13 +577,16 @@ struct BwdSmem {
     static constexpr int FLOATS = (T2<BM, BN>::DB ? 2 : 1) * (ASZ + BSZ);
 };
 
-template <int BM, int BN>
+template <int BM, int BN, bool BF = false>
 __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restrict__ smem, int bx, int by, int bz) {
     using T = T2<BM, BN>;
     const BwdArgs& a_ = a;  // (the tap loops below name a local `a`)
     constexpr int ASZ = BM * LDR, BSZ = BK2 * T::LDKB;
     float* As = smem;
     float* Bs = smem + (T::DB ? 2 : 1) * ASZ;
+    constexpr int ASZH = BM * LDH, BSZH = BN * LDH;    // BF: bf16 tiles, both [row][k] (the k-major weights are transposed by their stores)
+    __bf16* AsH = reinterpret_cast<__bf16*>(smem);
+    __bf16* BsH = AsH + 2 * ASZH;
     const float* __restrict__ X = a.X;
     const float* __restrict__ W = a.W;
     float* __restrict__ Y = a.Y;
@@ -685,10 +738,22 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
                 for (int i = 0; i < AC; ++i)
                     ra[i] = norm_apply_if((amask >> i) & 1u, ra[i], nsa, nsb, nslope);
             }
+            if constexpr (BF) {
+    #pragma unroll
+                for (int i = 0; i < AC; ++i) st_row4(AsH + buf * ASZH, r8 + RPP * i, kq * 4, ra[i]);
+    #pragma unroll
+                for (int i = 0; i < BC; ++i) st_col4(BsH + buf * BSZH, bq * 4, bk + KSTEP * i, rb[i]);
+                return;
+            }
     #pragma unroll
             for (int i = 0; i < AC; ++i) *reinterpret_cast<f32x4*>(As + buf * ASZ + (r8 + RPP * i) * LDR + kq * 4) = ra[i];
     #pragma unroll
             for (int i = 0; i < BC; ++i) *reinterpret_cast<f32x4*>(Bs + buf * BSZ + (bk + KSTEP * i) * T::LDKB + bq * 4) = rb[i];
+        };
+        auto mma = [&](auto part_c, int cur) {
+            constexpr int PART = decltype(part_c)::value;
+            if constexpr (BF) mma_bf<T::TM, T::TN, PART>(AsH + cur * ASZH, BsH + cur * BSZH, wm * T::TM * 32, wn * T::TN * 32, acc);
+            else mma_rk<T::TM, T::TN, PART>(As + cur * ASZ, Bs + cur * BSZ, T::LDKB, wm * T::TM * 32, wn * T::TN * 32, acc);
         };
         const int nkt = kt_end - kt_begin;  // (one basic block per stage: see igemm2_fwd_body)
         if (nkt > 0) {
@@ -699,13 +764,13 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
         }
         for (int it = 0; it < nkt; ++it) {
             const int cur = it & 1;
-            mma_rk<T::TM, T::TN, 0>(As + cur * ASZ, Bs + cur * BSZ, T::LDKB, wm * T::TM * 32, wn * T::TN * 32, acc);
+            mma(std::integral_constant<int, 0>{}, cur);
             MOVAE_SCHED_PIN();
             store_tile(cur ^ 1);
             MOVAE_SCHED_PIN();
             load_tile(kt_begin + it + 2);
             MOVAE_SCHED_PIN();  // (measured: the gather issued BEFORE the second half beats spreading it under it, this form only)
-            mma_rk<T::TM, T::TN, 1>(As + cur * ASZ, Bs + cur * BSZ, T::LDKB, wm * T::TM * 32, wn * T::TN * 32, acc);
+            mma(std::integral_constant<int, 1>{}, cur);
             __syncthreads();
         }
     };
@@ -917,10 +982,10 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool BF = false>
 __global__ __launch_bounds__(256) void igemm2_bwd(BwdArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[BwdSmem<BM, BN>::FLOATS];
-    igemm2_bwd_body<BM, BN>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+    igemm2_bwd_body<BM, BN, BF>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -955,12 +1020,15 @@ struct WgSmem {
     static constexpr int FLOATS = (T2<BM, BN>::DB ? 2 : 1) * (ASZ + BSZ);
 };
 
-template <int BM, int BN>
+template <int BM, int BN, bool BF = false>
 __device__ __forceinline__ void igemm2_wgrad_body(const WgArgs& a, float* __restrict__ smem, int bx, int by, int bz) {
     using T = T2<BM, BN>;
     constexpr int ASZ = BK2 * T::LDKA, BSZ = BK2 * T::LDKB;
     float* As = smem;
     float* Bs = smem + (T::DB ? 2 : 1) * ASZ;
+    constexpr int ASZH = BM * LDH, BSZH = BN * LDH;    // BF: bf16 tiles [row][k] -- both operands are k-major in memory: transposing stores
+    __bf16* AsH = reinterpret_cast<__bf16*>(smem);
+    __bf16* BsH = AsH + 2 * ASZH;
     const WGeom g = a.g;
     const int K = a.K, kchunk = a.kchunk, to_slab = a.to_slab, Sp = a.Sp;
     float* __restrict__ out = a.out;
@@ -1113,6 +1181,18 @@ __device__ __forceinline__ void igemm2_wgrad_body(const WgArgs& a, float* __rest
     #pragma unroll
                 for (int i = 0; i < ACH; ++i) csum += ra[i];
             }
+            if constexpr (BF) {
+    #pragma unroll
+                for (int i = 0; i < ACH; ++i) st_col4(AsH + buf * ASZH, aq * 4, ak + AKS * i, ra[i]);
+                if constexpr (PLAIN) {
+    #pragma unroll
+                    for (int i = 0; i < BCH; ++i) st_col4(BsH + buf * BSZH, (pq + PL * i) * 4, pk, rb[i]);
+                } else {
+    #pragma unroll
+                    for (int i = 0; i < BCH; ++i) st_col4(BsH + buf * BSZH, bq * 4, bk + BKS * i, rb[i]);
+                }
+                return;
+            }
     #pragma unroll
             for (int i = 0; i < ACH; ++i) *reinterpret_cast<f32x4*>(As + buf * ASZ + (ak + AKS * i) * T::LDKA + aq * 4) = ra[i];
             if constexpr (PLAIN) {
@@ -1123,6 +1203,11 @@ __device__ __forceinline__ void igemm2_wgrad_body(const WgArgs& a, float* __rest
     #pragma unroll
             for (int i = 0; i < BCH; ++i) *reinterpret_cast<f32x4*>(Bs + buf * BSZ + (bk + BKS * i) * T::LDKB + bq * 4) = rb[i];
         };
+        auto mma = [&](auto part_c, int cur) {
+            constexpr int PART = decltype(part_c)::value;
+            if constexpr (BF) mma_bf<T::TM, T::TN, PART>(AsH + cur * ASZH, BsH + cur * BSZH, wm * T::TM * 32, wn * T::TN * 32, acc);
+            else mma_kk<T::TM, T::TN, PART>(As + cur * ASZ, Bs + cur * BSZ, T::LDKA, T::LDKB, wm * T::TM * 32, wn * T::TN * 32, acc);
+        };
         const int nkt = k_begin < k_end ? (k_end - k_begin + BK2 - 1) / BK2 : 0;  // (one basic block per stage: see igemm2_fwd_body)
         if (nkt > 0) {
             load_tile(k_begin);
@@ -1132,12 +1217,12 @@ __device__ __forceinline__ void igemm2_wgrad_body(const WgArgs& a, float* __rest
         }
         for (int it = 0; it < nkt; ++it) {
             const int cur = it & 1;
-            mma_kk<T::TM, T::TN, 0>(As + cur * ASZ, Bs + cur * BSZ, T::LDKA, T::LDKB, wm * T::TM * 32, wn * T::TN * 32, acc);
+            mma(std::integral_constant<int, 0>{}, cur);
             MOVAE_SCHED_PIN();
             store_tile(cur ^ 1);
             MOVAE_SCHED_PIN();
             load_tile(k_begin + (it + 2) * BK2);
-            mma_kk<T::TM, T::TN, 1>(As + cur * ASZ, Bs + cur * BSZ, T::LDKA, T::LDKB, wm * T::TM * 32, wn * T::TN * 32, acc);
+            mma(std::integral_constant<int, 1>{}, cur);
             __syncthreads();
         }
     };
@@ -1199,10 +1284,10 @@ __device__ __forceinline__ void igemm2_wgrad_body(const WgArgs& a, float* __rest
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool BF = false>
 __global__ __launch_bounds__(256) void igemm2_wgrad(WgArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[WgSmem<BM, BN>::FLOATS];
-    igemm2_wgrad_body<BM, BN>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+    igemm2_wgrad_body<BM, BN, BF>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // ---- one launch, two problems: the input gradient (FWD or BWD gather form) and the weight gradient of one layer ----------
@@ -1386,7 +1471,8 @@ int launch_fwd2(const float* X, const float* W, float* Y, const Geom& g, const E
         p.ws_used = S > 1 ? (size_t)M * g.Nn * sizeof(float) * S : 0;
         return MOVAE_OK;
     }
-    hipLaunchKernelGGL((igemm2_fwd<BM, BN>), dim3(gx, gy, S), dim3(256), 0, st, a);
+    if (BM == 128 && BN == 128 && g_compute_bf16) hipLaunchKernelGGL((igemm2_fwd<BM, BN, BM == 128 && BN == 128>), dim3(gx, gy, S), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((igemm2_fwd<BM, BN>), dim3(gx, gy, S), dim3(256), 0, st, a);
     MOVAE_CHECK_LAUNCH("igemm2_fwd");
     if (S > 1) {
         if (rbb.y && !g_bench_main_only) {
@@ -1522,7 +1608,8 @@ int launch_bwd2(const float* X, const float* W, float* Y, const Geom& g, const E
         p.ws_used = Sreal > 1 ? (size_t)total * sizeof(float) * Sreal : 0;
         return MOVAE_OK;
     }
-    hipLaunchKernelGGL((igemm2_bwd<BM, BN>), dim3(gx, gy, zsum), dim3(256), 0, st, a);
+    if (BM == 128 && BN == 128 && g_compute_bf16) hipLaunchKernelGGL((igemm2_bwd<BM, BN, BM == 128 && BN == 128>), dim3(gx, gy, zsum), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((igemm2_bwd<BM, BN>), dim3(gx, gy, zsum), dim3(256), 0, st, a);
     MOVAE_CHECK_LAUNCH("igemm2_bwd");
     if (Sreal > 1 && !g_bench_main_only) {
         if (rbb.y) {
@@ -1601,7 +1688,8 @@ int launch_wgrad2(const float* Sm, const float* Bg, float* const* dW, int G, lon
         if (int rc = finish_pending(st)) return rc;
     } else {
         if (int rc = flush_pending(st)) return rc;
-        hipLaunchKernelGGL((igemm2_wgrad<BM, BN>), dim3(gx, gy, Sp * G), dim3(256), 0, st, a);
+        if (BM == 128 && BN == 128 && g_compute_bf16) hipLaunchKernelGGL((igemm2_wgrad<BM, BN, BM == 128 && BN == 128>), dim3(gx, gy, Sp * G), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((igemm2_wgrad<BM, BN>), dim3(gx, gy, Sp * G), dim3(256), 0, st, a);
         MOVAE_CHECK_LAUNCH("igemm2_wgrad");
     }
     if (slab) {  // ONE reduce launch for all groups (blockIdx.y = group)

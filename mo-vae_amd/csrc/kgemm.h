@@ -540,7 +540,11 @@ inline bool small_problem(long rows, long cols, long k, long copies) {
     // a short reduction (K = 288: 32 -> 64 channels on 16x16 images) leaves a wave's slice nine groups long -- the fold and the
     // epilogue then outweigh the slabs they replace (measured 18.6 vs 13.5 us per call)
     static const long kmin = getenv("MOVAE_KGEMM_KMIN") ? atol(getenv("MOVAE_KGEMM_KMIN")) : 512;
-    return tiles64 <= tmax && flop <= fmax && k >= kmin;
+    // ... and enough 32x32 tiles to occupy half the chip: the reduction is only split INSIDE a block, so a problem with a handful
+    // of tiles and a very long reduction (BetaTC-VAE's fc 32768 -> 256 at batch 32: 8 tiles) belongs to the split-K kernels
+    // (measured at C5: 309 us here against 54 us there)
+    const long tiles32 = ((rows + 31) / 32) * ((cols + 31) / 32) * copies;
+    return tiles64 <= tmax && tiles32 >= 128 && flop <= fmax && k >= kmin;
 }
 
 template <int FORM, bool NRM>
@@ -676,8 +680,9 @@ inline int launch_kfwd(const float* X, const float* W, float* Y, const Geom& g, 
     if (!plan_side(a, ep, M, 1, g.Nn)) return MOVAE_OK;
     const int tx = ceil_div(M, 32), ty = ceil_div(g.Nn, 32);
     const KSplit ks = choose_ks((long)tx * ty);
-    static const char* const names[4] = {"kgemm_k<0,8,8>", "kgemm_k<0,4,4>", "kgemm_k<0,4,2>", "kgemm_k<0,4,1>"};
-    g_last_kernel = ks_name(names, ks);
+    static const char* const names[4] = {"kgemm_k<0,8,8,false>", "kgemm_k<0,4,4,false>", "kgemm_k<0,4,2,false>", "kgemm_k<0,4,1,false>"};
+    static const char* const names_n[4] = {"kgemm_k<0,8,8,true>", "kgemm_k<0,4,4,true>", "kgemm_k<0,4,2,true>", "kgemm_k<0,4,1,true>"};
+    g_last_kernel = a.nrm.scale ? ks_name(names_n, ks) : ks_name(names, ks);  // (as rocprofv3 prints the instantiation)
     if (v2::g_pair_collect && ks.ks == 4 && !a.nrm.scale) {  // an input gradient with its layer's weight gradient to follow: stash it
         g_kpend.active = true, g_kpend.form = 0, g_kpend.a = a, g_kpend.tiles = dim3(tx, ty, 1);
         *handled = true;
@@ -726,8 +731,9 @@ inline int launch_kbwd(const float* X, const float* W, float* Y, const Geom& g, 
     if (!plan_side(a, ep, pix, ncls, g.Nn)) return MOVAE_OK;
     const int tx = ceil_div(Mc, 32), ty = ceil_div(g.Nn, 32);
     const KSplit ks = choose_ks((long)tx * ty * ncls);
-    static const char* const names[4] = {"kgemm_k<1,8,8>", "kgemm_k<1,4,4>", "kgemm_k<1,4,2>", "kgemm_k<1,4,1>"};
-    g_last_kernel = ks_name(names, ks);
+    static const char* const names[4] = {"kgemm_k<1,8,8,false>", "kgemm_k<1,4,4,false>", "kgemm_k<1,4,2,false>", "kgemm_k<1,4,1,false>"};
+    static const char* const names_n[4] = {"kgemm_k<1,8,8,true>", "kgemm_k<1,4,4,true>", "kgemm_k<1,4,2,true>", "kgemm_k<1,4,1,true>"};
+    g_last_kernel = a.nrm.scale ? ks_name(names_n, ks) : ks_name(names, ks);
     if (v2::g_pair_collect && ks.ks == 4 && !a.nrm.scale) {
         g_kpend.active = true, g_kpend.form = 1, g_kpend.a = a, g_kpend.tiles = dim3(tx, ty, ncls);
         *handled = true;
@@ -786,8 +792,10 @@ inline int launch_kwgrad(const float* Sm, const float* Bg, float* const* dW, int
     else MOVAE_KW(4, 1);
 #undef MOVAE_KW
     MOVAE_CHECK_LAUNCH("kwgrad_k");
-    static const char* const names[4] = {"kwgrad_k<8,8>", "kwgrad_k<4,4>", "kwgrad_k<4,2>", "kwgrad_k<4,1>"};
-    g_last_kernel = ks_name(names, ks);
+    static const char* const names[3][4] = {{"kwgrad_k<8,8,0>", "kwgrad_k<4,4,0>", "kwgrad_k<4,2,0>", "kwgrad_k<4,1,0>"},
+                                            {"kwgrad_k<8,8,1>", "kwgrad_k<4,4,1>", "kwgrad_k<4,2,1>", "kwgrad_k<4,1,1>"},
+                                            {"kwgrad_k<8,8,2>", "kwgrad_k<4,4,2>", "kwgrad_k<4,2,2>", "kwgrad_k<4,1,2>"}};
+    g_last_kernel = ks_name(names[nside], ks);
     if (Sp > 1)
         for (int i = 0; i < G; ++i)
             if (int rc = launch_reduce(a.slab + (long)i * Sp * stride, dW[i], stride, Sp, N, nullptr, 0, 0.f, accumulate, st)) return rc;

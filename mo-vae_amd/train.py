@@ -602,6 +602,10 @@ def build_parser():
                    help="auto / on: capture the step into a hipGraph on the first full batch and replay it (device-bound "
                         "instead of host-bound; the capture's warm-up steps are rewound, so the run makes the eager loop's "
                         "steps -- only random draws inside the step come from the graph's own Philox offsets); auto falls back to the eager step silently where replay is not possible, on says so")
+    p.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32",
+                   help="fp32 (default): the reference's arithmetic, the parity path.  bf16 (opt-in): bf16 operands / fp32 "
+                        "accumulation in the 128x128 implicit-GEMM convolution kernels (the MFMA-bound layers of the 64x64+ "
+                        "configurations); master weights, BatchNorm, losses, aggregation and optimizer stay fp32")
     p.add_argument("--max_items", type=int, default=None, help="cap the synthetic dataset length")
     p.add_argument("--max_steps", type=int, default=None, help="stop after this many optimisation steps")
     return p
@@ -663,6 +667,7 @@ def main(args):
     if device.type != "cuda":
         raise RuntimeError("the MI355X hot path needs a HIP device (--device cuda:N); there is no CPU path")
     torch.cuda.set_device(device)
+    L.set_compute_dtype(getattr(args, "dtype", "fp32"))
     train_ds, test_ds, input_size = get_dataset(args.dataset, data_dir=args.data_dir, normalize=args.normalize_inputs,
                                                 max_items=args.max_items)
     per_rank_bs = args.batch_size if dp is None else max(1, args.batch_size // dp.world_size)

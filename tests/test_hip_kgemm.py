@@ -124,7 +124,7 @@ x = torch.randn(12, 64, 4, 4, generator=g); w = torch.randn(96, 64, 3, 3, genera
 ref = F.conv2d(x.double(), w.double(), None, stride=2, padding=1)
 xg = x.permute(0, 2, 3, 1).contiguous().cuda(); wg = w.cuda().contiguous(memory_format=torch.channels_last)
 y1 = ops.conv2d(xg, wg, None, 2, 1, None, 0.01); y2 = ops.conv2d(xg, wg, None, 2, 1, None, 0.01)
-assert L.load().movae_bench_last_kernel().decode() == "kgemm_k<0,{8 if ks == 8 else 4},{ks}>", L.load().movae_bench_last_kernel()
+assert L.load().movae_bench_last_kernel().decode() == "kgemm_k<0,{8 if ks == 8 else 4},{ks},false>", L.load().movae_bench_last_kernel()
 assert torch.equal(y1, y2)
 err = (y1.permute(0, 3, 1, 2).cpu().double() - ref).abs().max().item() / ref.abs().max().item()
 assert err < 2e-6, err

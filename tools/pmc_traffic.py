@@ -21,7 +21,7 @@ from collections import defaultdict
 def short(name):
     name = re.sub(r"^void ", "", name)
     name = name.replace("(anonymous namespace)::", "")
-    name = re.sub(r"^(v2|thin|lin)::", "", name)
+    name = re.sub(r"^(v2|thin|lin|kg)::", "", name)
     depth, out = 0, []
     for ch in name:  # cut the argument list: the first '(' outside template brackets
         if ch == "<":
@@ -31,7 +31,10 @@ def short(name):
         elif ch == "(" and depth == 0:
             break
         out.append(ch)
-    return re.sub(r",\s+", ",", "".join(out)).strip()
+    name = re.sub(r",\s+", ",", "".join(out)).strip()
+    # igemm2_fwd / _bwd / _wgrad carry a trailing `BF` template flag (bf16 operands, opt-in): the fp32 instantiations keep the
+    # names bench.py and the earlier rounds' profiles use
+    return re.sub(r"^(igemm2_(?:fwd|bwd|wgrad)<[^>]*),false>$", r"\1>", name)
 
 
 def per_kernel(directory, counter):

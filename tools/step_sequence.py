@@ -13,7 +13,7 @@ def short(name):
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void ", "", name)
     m = re.match(r"([A-Za-z_0-9:]+(<[^(]*>)?)", name)
-    return (m.group(1) if m else name)[:70]
+    return re.sub(r"^(v2::igemm2_(?:fwd|bwd|wgrad)<[^>]*), false>$", r"\1>", m.group(1) if m else name)[:70]
 
 
 def main():
