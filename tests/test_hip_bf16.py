@@ -6,7 +6,8 @@ two operands to bf16 on the way into LDS and multiply on v_mfma_f32_32x32x16_bf1
     relative L2 error <= 1e-2 -- an operand rounded to 8 significant bits carries 2^-9 relative error, a product of two 2^-8,
     and the errors of a K-term sum add like its terms (measured 2-4e-3);
   * a C3-shaped VQ-VAE step (`--arch vq_vae`, 64x64, K=512, D=64, Aligned-MTL) against the fp32 ORACLE on the same inputs:
-    every loss within 2e-2 relative, every parameter's aggregated gradient within 6e-2 relative L2 of the oracle's;
+    every loss within 2e-2 relative, every parameter's aggregated gradient within 3e-2 relative L2 of the oracle's
+    (measured: worst parameter 7.6e-3);
   * the fp32 mode is bit-for-bit unaffected by having visited the bf16 mode.
 GPU only."""
 import numpy as np
@@ -105,7 +106,7 @@ def test_bf16_c3_shaped_step_against_the_fp32_oracle(bf16, gpu_device):
     ld = net.loss_function(xg, args=out)
     assert list(ld.keys()) == list(old.keys())
     for k, v in ld.items():
-        np.testing.assert_allclose(v.item(), float(old[k]), rtol=2e-2, atol=1e-6, err_msg=f"loss {k} (bf16 operands vs fp32 oracle)")
+        np.testing.assert_allclose(v.detach().item(), float(old[k]), rtol=2e-2, atol=1e-6, err_msg=f"loss {k} (bf16 operands vs fp32 oracle)")
     A = aggregation.make_aggregator(a)
     net.zero_grad(set_to_none=True)
     autojac.mtl_backward(losses=[v for k, v in ld.items() if k != "total_loss"], features=[out[f] for f in net.features], aggregator=A,
@@ -118,5 +119,5 @@ def test_bf16_c3_shaped_step_against_the_fp32_oracle(bf16, gpu_device):
             continue
         e = _rel(p.grad, want)
         worst = max(worst, (n, e), key=lambda t: t[1])
-        assert e < 6e-2, f"{n}: rel-L2 {e:.2e} (bf16 operands vs fp32 oracle)"
+        assert e < 3e-2, f"{n}: rel-L2 {e:.2e} (bf16 operands vs fp32 oracle)"
     print(f"[bf16 C3-shaped vq_vae step, B={B}] losses within 2e-2; worst per-parameter gradient rel-L2 {worst[1]:.2e} ({worst[0]})")
