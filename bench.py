@@ -490,7 +490,9 @@ def main():
         traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.config}.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("kernels", {}).get(dom, {}).get("hbm_bytes_per_launch")
+            kern = json.load(open(tpath)).get("kernels", {})
+            parts = [kern.get(k.strip(), {}).get("hbm_bytes_per_launch") for k in dom.split(" + ")]  # (a call of two main launches: both)
+            traffic = sum(parts) if all(v is not None for v in parts) else None
             if traffic is not None:
                 traffic_source = f"profiles/pmc_traffic_{args.config}.json (rocprofv3 --pmc passes of tools/pmc_traffic.py, not this run)"
         alg_bytes = sum(r["alg_bytes"] for r in rows if r["kernel"] == dom) / d["n"]

@@ -30,3 +30,8 @@ PY
     rm -rf /tmp/pf_$c /tmp/pw_$c
   fi
 done
+# the opt-in bf16 leg (never the headline): one bench line per config named in BF16_CFGS, e.g. BF16_CFGS="C3 C5"
+for c in $BF16_CFGS; do
+  python3 $R/bench.py --config $c --dtype bf16 --steps 20 --warmup 5 --cpu-seconds 8 --elbo-check-steps 2 --min-gpu-seconds 3 > $OUT/${c}_bf16_bench.json 2> $OUT/${c}_bf16_bench.err || { tail -5 $OUT/${c}_bf16_bench.err; exit 1; }
+  python3 -c "import json; d=json.load(open('$OUT/${c}_bf16_bench.json')); print('$c bf16 ms/step', round(d['ms_per_step'],4), d['dtype'], (d['roofline'] or {}).get('kernel'), (d['roofline'] or {}).get('frac'))"
+done
