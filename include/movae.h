@@ -164,6 +164,16 @@ int movae_recon_loss_bwd(const float* recons, const float* inputs, const float* 
 /* kl: utils/objectives.py:141-144, out[0] = scale * mean_b(-0.5 sum_d(1 + lv - mu^2 - e^lv)) */
 int movae_kl_fwd(const float* mu, const float* log_var, float* out, int b, int d, float scale,
                  void* ws, size_t ws_bytes, movae_stream_t stream);
+/* The scalar arithmetic of a loss_function (models/vq_vae.py:381-391, vq_vae2.py:313-334, betatc_vae.py:298-324) in ONE launch:
+ * `nterms` device scalars, out[k] = f_k * w_k * (sum of the terms whose coef[k][t] != 0 -- a row's non-zero coefficients must all
+ * equal w_k), k < nout <= 7, and out[nout] = out[0] + ... in order.  f_k = 1 except for k == anneal_row (>= 0) with iter_dev
+ * given: BetaTC's annealing factor min(iter / anneal_steps, 1), the device counter iter_dev being advanced first when training
+ * (models/betatc_vae.py:13,298-302); anneal_out (nullable) keeps the factor for the backward.  terms / g: HOST arrays of device
+ * pointers (g has nout + 1 entries, NULL = absent cotangent); gterms: device [nterms]. */
+int movae_combine_losses_fwd(int nterms, const float* const* terms, int nout, const float* coef, float* iter_dev, float anneal_steps,
+                             int anneal_row, int training, float* out, float* anneal_out, movae_stream_t stream);
+int movae_combine_losses_bwd(int nterms, int nout, const float* const* g, const float* coef, const float* anneal_dev, int anneal_row,
+                             float* gterms, movae_stream_t stream);
 /* VAE.loss_function (models/vae.py:211-228) in three launches: out[3] = (reconstruction_loss, kld_loss, total_loss = their fp32 sum);
  * the same arithmetic as movae_recon_loss_fwd + movae_kl_fwd + a tensor add.  ws >= the two reductions' workspaces together. */
 int movae_vae_losses_fwd(const float* recons, const float* inputs, size_t n, int kind, float rec_scale,
@@ -217,6 +227,9 @@ int movae_edge_match_bwd(const float* recons, const float* inputs, const float* 
  * sse[0] = sum (q - x)^2 (commitment and embedding losses are both sse/numel).  x,q: [rows][d], e: [k][d]. */
 int movae_vq_nearest_fwd(const float* x, const float* e, float* q, int64_t* idx, float* sse, int32_t* used_count,
                          int rows, int k, int d, void* ws, size_t ws_bytes, movae_stream_t stream);
+/* the same, and the two loss terms of models/vq_vae.py:51-52 written by the finalize kernel: mse2[0] = mse2[1] = sse / (rows * d) */
+int movae_vq_nearest_fwd_mse(const float* x, const float* e, float* q, int64_t* idx, float* sse, int32_t* used_count, float* mse2,
+                             int rows, int k, int d, void* ws, size_t ws_bytes, movae_stream_t stream);
 /* dx = dq + gc * 2 (x - q)/numel ; de[k] = ge * 2/numel * sum_{idx[r]==k} (q[r] - x[r])   (gc, ge: device scalars, may be
  * NULL = 0; dx / de may be NULL).  The codebook gradient is a sorted segmented sum (no float atomics, bit-reproducible);
  * `ws` must hold movae_vq_bwd_ws_bytes(rows, k, d) bytes when de and ge are given. */

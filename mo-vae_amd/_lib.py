@@ -67,6 +67,8 @@ SIGNATURES = {
     "movae_recon_loss_fwd": ([_p, _p, _p, _z, _i, _f, _p, _z, _p], _i),
     "movae_recon_loss_bwd": ([_p, _p, _p, _p, _z, _i, _f, _p], _i),
     "movae_kl_fwd": ([_p, _p, _p, _i, _i, _f, _p, _z, _p], _i),
+    "movae_combine_losses_fwd": ([_i, _p, _i, _p, _p, _f, _i, _i, _p, _p, _p], _i),
+    "movae_combine_losses_bwd": ([_i, _i, _p, _p, _p, _i, _p, _p], _i),
     "movae_vae_losses_fwd": ([_p, _p, _z, _i, _f, _p, _p, _i, _i, _f, _p, _p, _z, _p], _i),
     "movae_kl_bwd": ([_p, _p, _p, _p, _p, _i, _i, _f, _p], _i),
     "movae_tc_decomp_fwd": ([_p] * 7 + [_i, _i, _p, _z, _p], _i),
@@ -77,6 +79,7 @@ SIGNATURES = {
     "movae_edge_match_fwd": ([_p, _p, _p, _i, _i, _i, _i, _f, _i, _p, _p, _z, _p], _i),
     "movae_edge_match_bwd": ([_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p, _p], _i),
     "movae_vq_nearest_fwd": ([_p] * 6 + [_i, _i, _i, _p, _z, _p], _i),
+    "movae_vq_nearest_fwd_mse": ([_p] * 7 + [_i, _i, _i, _p, _z, _p], _i),
     "movae_vq_bwd_ws_bytes": ([_i, _i, _i], _z),
     "movae_vq_bwd": ([_p] * 8 + [_i, _i, _i, _p, _z, _p], _i),
     "movae_gram_ws_bytes": ([_i, _z], _z),

@@ -174,16 +174,25 @@ def _group(t, g):
     return None if t is None else t[g]
 
 
+def _dense(t):
+    """Does `t` cover its numel() elements of memory exactly once (contiguous up to a permutation of its axes)?"""
+    if t.is_contiguous():
+        return True
+    order = sorted(range(t.dim()), key=lambda i: (-t.stride(i), -t.shape[i]))
+    return t.permute(order).is_contiguous()
+
+
 def _restack(lst):
     """Per-group results of a torch-native view node are usually G equal slices of one stacked buffer: hand them on as the
-    [G, ...] view they are (no copy), so that later accumulations / kernels see one tensor instead of a list."""
+    [G, ...] view they are (no copy), so that later accumulations / kernels see one tensor instead of a list.  The slices may be
+    permuted views (a logical-NCHW view of an NHWC buffer): dense is enough."""
     t0 = lst[0]
-    if not isinstance(t0, torch.Tensor) or not t0.is_contiguous() or t0.numel() == 0:
+    if not isinstance(t0, torch.Tensor) or t0.numel() == 0 or not _dense(t0):
         return lst
     nbytes = t0.numel() * t0.element_size()
     base = t0.untyped_storage().data_ptr()
     for g, t in enumerate(lst):
-        if (not isinstance(t, torch.Tensor) or t.shape != t0.shape or t.dtype != t0.dtype or not t.is_contiguous() or
+        if (not isinstance(t, torch.Tensor) or t.shape != t0.shape or t.dtype != t0.dtype or t.stride() != t0.stride() or
                 t.untyped_storage().data_ptr() != base or t.data_ptr() != t0.data_ptr() + g * nbytes):
             return lst
     return t0.as_strided((len(lst),) + tuple(t0.shape), (t0.numel(),) + tuple(t0.stride()), t0.storage_offset())
@@ -362,8 +371,8 @@ def mtl_backward_begin(losses, features, aggregator, tasks_params=None, shared_p
     st.task_params = []
     # the K cotangents of every feature are born stacked: [K, ...] buffers whose slice i the op that produces d(loss i)/d(feature)
     # writes directly (ops.COT_SINK) -- no torch.stack launch in front of the batched pull-back
-    cot = [torch.empty((len(losses),) + tuple(f.shape), dtype=f.dtype, device=f.device) if f.is_contiguous() else None
-           for f in st.feat_diff]
+    cot = [torch.empty_strided((len(losses),) + tuple(f.shape), (f.numel(),) + tuple(f.stride()), dtype=f.dtype, device=f.device)
+           if _dense(f) else None for f in st.feat_diff]  # (slice i has the feature's own strides: NHWC memory under an NCHW view)
     for i, (loss, tp) in enumerate(zip(losses, tasks_params)):
         tp = list(tp)
         # the seed cotangent is a persistent ones tensor: autograd would launch a fill per loss for its implicit ones_like

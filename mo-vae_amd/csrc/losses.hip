@@ -393,6 +393,106 @@ int movae_vae_losses_fwd(const float* recons, const float* inputs, size_t n, int
     return MOVAE_OK;
 }
 
+// ---- loss_function arithmetic in one launch --------------------------------------------------------------------------------------
+// The models' loss_function methods weight and add scalar terms (models/vq_vae.py:381-391, vq_vae2.py:313-334,
+// betatc_vae.py:298-324): as tensor arithmetic that is one launch per `*` and `+`, forward and backward.  Here: T scalar terms,
+// K outputs out[k] = f_k * sum_t coef[k][t] * term[t] (f_k = the annealing factor for k == anneal_row, else 1), out[K] = their sum.
+// BetaTC's annealing counter (a device float) is advanced and clamped in the same kernel.
+struct CLTerms {
+    const float* p[8];
+};
+struct CLCoef {
+    float c[64];  // [K][T] row-major, K, T <= 8
+};
+__global__ void combine_losses_k(CLTerms terms, CLCoef coef, int T, int K, float* __restrict__ iter_dev, float anneal_steps,
+                                 int anneal_row, int training, float* __restrict__ out, float* __restrict__ anneal_out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float anneal = 1.f;
+    if (anneal_row >= 0 && iter_dev) {
+        float it = iter_dev[0];
+        if (training) {
+            it += 1.f;  // models/betatc_vae.py:299: num_iter += 1 per training call
+            iter_dev[0] = it;
+            anneal = fminf(it / anneal_steps, 1.f);
+        }
+    }
+    if (anneal_out) anneal_out[0] = anneal;
+    float tv[8];
+    for (int t = 0; t < T; ++t) tv[t] = terms.p[t][0];
+    float total = 0.f;
+    for (int k = 0; k < K; ++k) {
+        // the reference's order: the row's terms are added first (vq_vae2.py: top + bottom), then weight (* annealing factor) * sum
+        float v = 0.f;
+        bool first = true;
+        float w = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const float c = coef.c[k * T + t];
+            if (c == 0.f) continue;
+            v = first ? tv[t] : v + tv[t];
+            w = c;
+            first = false;
+        }
+        v = (k == anneal_row ? w * anneal : w) * v;  // betatc_vae.py:321: kld_weight * 1 * anneal * kld
+        out[k] = v;
+        total = k == 0 ? v : total + v;
+    }
+    out[K] = total;
+}
+
+// gterms[t] = sum_k (g[k] + g[K]) * f_k * coef[k][t]   (absent cotangents: null pointers)
+__global__ void combine_losses_bwd_k(CLTerms g, CLCoef coef, int T, int K, const float* __restrict__ anneal_dev, int anneal_row,
+                                     float* __restrict__ gterms) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float gt = g.p[K] ? g.p[K][0] : 0.f;
+    for (int t = 0; t < T; ++t) {
+        float acc = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const float c = coef.c[k * T + t];
+            if (c == 0.f) continue;
+            float gk = (g.p[k] ? g.p[k][0] : 0.f) + gt;
+            if (k == anneal_row && anneal_dev) gk *= anneal_dev[0];
+            acc += gk * c;
+        }
+        gterms[t] = acc;
+    }
+}
+
+int movae_combine_losses_fwd(int nterms, const float* const* terms, int nout, const float* coef, float* iter_dev, float anneal_steps,
+                             int anneal_row, int training, float* out, float* anneal_out, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(terms && coef && out && nterms >= 1 && nterms <= 8 && nout >= 1 && nout <= 8, "movae_combine_losses_fwd: bad argument");
+    CLTerms tp{};
+    CLCoef cc{};
+    for (int t = 0; t < nterms; ++t) {
+        MOVAE_CHECK_ARG(terms[t], "movae_combine_losses_fwd: null term");
+        tp.p[t] = terms[t];
+    }
+    for (int i = 0; i < nout * nterms; ++i) cc.c[i] = coef[i];
+    for (int k = 0; k < nout; ++k) {  // a row's non-zero coefficients must be equal: out[k] = w_k * (sum of its terms)
+        float w = 0.f;
+        for (int t = 0; t < nterms; ++t) {
+            const float c = coef[k * nterms + t];
+            MOVAE_CHECK_ARG(c == 0.f || w == 0.f || c == w, "movae_combine_losses_fwd: row %d mixes different weights", k);
+            if (c != 0.f) w = c;
+        }
+    }
+    hipLaunchKernelGGL(combine_losses_k, dim3(1), dim3(64), 0, (hipStream_t)stream, tp, cc, nterms, nout, iter_dev, anneal_steps,
+                       anneal_row, training, out, anneal_out);
+    MOVAE_CHECK_LAUNCH("combine_losses");
+    return MOVAE_OK;
+}
+
+int movae_combine_losses_bwd(int nterms, int nout, const float* const* g, const float* coef, const float* anneal_dev, int anneal_row,
+                             float* gterms, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(g && coef && gterms && nterms >= 1 && nterms <= 8 && nout >= 1 && nout <= 7, "movae_combine_losses_bwd: bad argument");
+    CLTerms gp{};
+    CLCoef cc{};
+    for (int k = 0; k <= nout; ++k) gp.p[k] = g[k];
+    for (int i = 0; i < nout * nterms; ++i) cc.c[i] = coef[i];
+    hipLaunchKernelGGL(combine_losses_bwd_k, dim3(1), dim3(64), 0, (hipStream_t)stream, gp, cc, nterms, nout, anneal_dev, anneal_row, gterms);
+    MOVAE_CHECK_LAUNCH("combine_losses_bwd");
+    return MOVAE_OK;
+}
+
 int movae_kl_bwd(const float* mu, const float* log_var, const float* gscale_dev, float* dmu, float* dlog_var, int b, int d,
                  float scale, movae_stream_t stream) {
     MOVAE_CHECK_ARG(mu && log_var && dmu && dlog_var && b > 0 && d > 0, "movae_kl_bwd: bad argument");

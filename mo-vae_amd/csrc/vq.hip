@@ -172,7 +172,8 @@ __global__ __launch_bounds__(256) void vq_nearest_generic(const float* __restric
 }
 
 __global__ __launch_bounds__(256) void vq_finalize(const double* __restrict__ part, int nblk, const int* __restrict__ used,
-                                                   int K, float* __restrict__ sse, int* __restrict__ used_count) {
+                                                   int K, float* __restrict__ sse, int* __restrict__ used_count,
+                                                   float* __restrict__ mse2, float numel) {
     __shared__ double shd[4];
     double s = 0.0, u = 0.0;
     for (int i = threadIdx.x; i < nblk; i += 256) s += part[i];
@@ -181,6 +182,7 @@ __global__ __launch_bounds__(256) void vq_finalize(const double* __restrict__ pa
     u = block_sum_256(u, shd);
     if (threadIdx.x == 0) {
         sse[0] = (float)s;
+        if (mse2) mse2[0] = mse2[1] = (float)s / numel;  // commitment and embedding terms: mse(q, x), the fp32 division torch would do
         if (used_count) used_count[0] = (int)(u + 0.5);
     }
 }
@@ -366,8 +368,8 @@ static int segmented_code_sum(const float* x, const float* q, const int64_t* idx
 
 extern "C" {
 
-int movae_vq_nearest_fwd(const float* x, const float* e, float* q, int64_t* idx, float* sse, int32_t* used_count, int rows,
-                         int k, int d, void* ws, size_t ws_bytes, movae_stream_t stream) {
+static int vq_nearest_impl(const float* x, const float* e, float* q, int64_t* idx, float* sse, int32_t* used_count, float* mse2, int rows,
+                           int k, int d, void* ws, size_t ws_bytes, movae_stream_t stream) {
     MOVAE_WS_SCRATCH(ws, ws_bytes);
     MOVAE_CHECK_ARG(x && e && q && idx && sse, "movae_vq_nearest_fwd: null pointer");
     MOVAE_CHECK_ARG(rows > 0 && k > 0 && d > 0, "movae_vq_nearest_fwd: bad shape rows=%d k=%d d=%d", rows, k, d);
@@ -392,9 +394,22 @@ int movae_vq_nearest_fwd(const float* x, const float* e, float* q, int64_t* idx,
             hipLaunchKernelGGL(vq_nearest_generic, dim3(nblk), dim3(256), 0, st, x, e, q, idx, part, used, rows, k, d);
     }
     MOVAE_CHECK_LAUNCH("vq_nearest");
-    hipLaunchKernelGGL(vq_finalize, dim3(1), dim3(256), 0, st, part, nblk, used, k, sse, used_count);
+    hipLaunchKernelGGL(vq_finalize, dim3(1), dim3(256), 0, st, part, nblk, used, k, sse, used_count, mse2, (float)rows * (float)d);
     MOVAE_CHECK_LAUNCH("vq_finalize");
     return MOVAE_OK;
+}
+
+int movae_vq_nearest_fwd(const float* x, const float* e, float* q, int64_t* idx, float* sse, int32_t* used_count, int rows,
+                         int k, int d, void* ws, size_t ws_bytes, movae_stream_t stream) {
+    return vq_nearest_impl(x, e, q, idx, sse, used_count, nullptr, rows, k, d, ws, ws_bytes, stream);
+}
+
+// ... and the two loss terms of models/vq_vae.py:51-52 from the same finalize kernel: mse2[0] = mse2[1] = sse / (rows * d)
+// (commitment = mse(q.detach(), x), embedding = mse(q, x.detach()): one value, two tape nodes) -- no division / clone launches
+int movae_vq_nearest_fwd_mse(const float* x, const float* e, float* q, int64_t* idx, float* sse, int32_t* used_count, float* mse2,
+                             int rows, int k, int d, void* ws, size_t ws_bytes, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(mse2, "movae_vq_nearest_fwd_mse: null pointer");
+    return vq_nearest_impl(x, e, q, idx, sse, used_count, mse2, rows, k, d, ws, ws_bytes, stream);
 }
 
 size_t movae_vq_bwd_ws_bytes(int rows, int k, int d) {

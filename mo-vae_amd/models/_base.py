@@ -31,6 +31,31 @@ def resolve_lambda_weights(owner, objectives, lambda_weights, defaults, list_ord
     raise TypeError(f"lambda_weights must be dict or list, got {type(lambda_weights)}")
 
 
+class LazyDict(dict):
+    """A forward() result whose function-valued entries are computed on first read.  VQ-VAE-2's `commitment_loss` /
+    `embedding_loss` are sums of the two codebooks' terms (models/vq_vae2.py:291-292): loss_function consumes the four terms
+    directly, so in a training step nobody reads the sums and their launches are never made; any other reader (`out[key]`,
+    .get, .items(), .values()) sees ordinary tensors."""
+
+    def _resolve(self, key, v):
+        if callable(v) and not isinstance(v, torch.Tensor) and getattr(v, "__name__", "") == "<lambda>":
+            v = v()
+            dict.__setitem__(self, key, v)
+        return v
+
+    def __getitem__(self, key):
+        return self._resolve(key, dict.__getitem__(self, key))
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+
 class LazyScalar:
     """A number that lives on the device until somebody needs it on the host.
 

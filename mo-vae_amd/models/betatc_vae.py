@@ -1,4 +1,6 @@
 """Beta-TC-VAE on the HIP kernels -- drop-in for the reference's models/betatc_vae.py:12-350."""
+import os
+
 import torch
 
 from .. import nn as mnn
@@ -90,6 +92,18 @@ class BetaTCVAE(HotPathModel):
         z = args["z"]
         rec = self.objectives["reconstruction_loss"](inputs, args["recons"], lw["reconstruction_loss"])
         terms = ops.tc_decomposition(z, args["mu"], args["log_var"], self._log_importance_weights(z.shape[0], z.device))
+        if os.environ.get("MOVAE_FUSE_LOSSES", "1") != "0" and rec.is_cuda:
+            # weights, annealing and the total in one launch (ops.CombineLosses) instead of eight; the annealing counter is
+            # advanced inside the kernel in graph mode (prepare_for_graph), on the host otherwise
+            anneal, host = None, 1.0
+            if self.training and self._iter_dev is not None:
+                anneal = (3, self._iter_dev, float(self.anneal_steps), True)
+            elif self.training:
+                self.num_iter += 1
+                host = min(0 + 1 * self.num_iter / self.anneal_steps, 1)
+            coef = [[1.0, 0, 0, 0], [0, lw["mi_loss"], 0, 0], [0, 0, lw["tc_loss"] * 1, 0], [0, 0, 0, lw["kld"] * 1 * host]]
+            rec, mi, tc, kld, total = ops.combine_losses([rec, terms], coef, anneal)
+            return {"reconstruction_loss": rec, "mi_loss": mi, "tc_loss": tc, "kld": kld, "total_loss": total}
         if self.training and self._iter_dev is not None:
             # graph mode (prepare_for_graph): the iteration counter lives on the device, so a replayed capture anneals
             self._iter_dev.add_(1.0)

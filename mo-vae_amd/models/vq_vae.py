@@ -1,5 +1,7 @@
 """VQ-VAE on the HIP kernels -- drop-in for the reference's models/vq_vae.py (VectorQuantizer
 :11-124, ResidualLayer :127-145, VQVAE :148-470)."""
+import os
+
 import torch
 
 from .. import nn as mnn
@@ -131,6 +133,14 @@ class VQVAE(HotPathModel):
 
     def loss_function(self, inputs, args: dict) -> dict:
         lw, ld = self.lambda_weights, {}
+        keys = list(self.objectives)
+        if keys == ["reconstruction_loss", "embedding_loss", "commitment_loss"] and os.environ.get("MOVAE_FUSE_LOSSES", "1") != "0" \
+                and args["recons"].is_cuda:
+            # the two weights and the total in one launch (ops.CombineLosses) instead of four
+            rec = self.objectives["reconstruction_loss"](inputs, args["recons"], lw["reconstruction_loss"])
+            coef = [[1.0, 0, 0], [0, lw["embedding_loss"], 0], [0, 0, lw["commitment_loss"]]]
+            rec, emb, com, total = ops.combine_losses([rec, args["embedding_loss"], args["commitment_loss"]], coef)
+            return {"reconstruction_loss": rec, "embedding_loss": emb, "commitment_loss": com, "total_loss": total}
         for key, fn in self.objectives.items():  # order: reconstruction, embedding, commitment (models/vq_vae.py:381-389)
             if key == "embedding_loss":
                 ld[key] = lw[key] * args["embedding_loss"]

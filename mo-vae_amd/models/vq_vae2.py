@@ -1,11 +1,13 @@
 """Hierarchical VQ-VAE-2 on the HIP kernels -- drop-in for the reference's models/vq_vae2.py
 (ResBlock :12-28, Encoder :31-58, Decoder :61-103, VQVAE2 :106-390)."""
+import os
+
 import torch
 
 from .. import nn as mnn
 from .. import objectives as O
 from .. import ops
-from ._base import LazyScalar, HotPathModel, nchw_view, resolve_lambda_weights
+from ._base import HotPathModel, LazyDict, LazyScalar, nchw_view, resolve_lambda_weights
 from .vq_vae import VectorQuantizer
 
 N_RES_CHANNEL = 32  # hard-coded at models/vq_vae2.py:190-212
@@ -131,9 +133,11 @@ class VQVAE2(HotPathModel):
         K = self.num_embeddings
         used_t, used_b = self._used
         usage = LazyScalar([used_t, used_b], 100.0 / K / 2.0)  # mean of the two codebooks' usage, read lazily
-        out = {"recons": recons, "encoding_top": enc_t, "encoding_bottom": enc_b, "quantized_top": quant_t,
-               "quantized_bottom": quant_b, "commitment_loss": c_t + c_b, "embedding_loss": e_t + e_b,
-               "codebook_usage_percentage": usage, "encoding_inds_top": i_t, "encoding_inds_bottom": i_b}
+        # the two sums are formed only if somebody reads them: loss_function takes the four terms (one launch for all of it)
+        out = LazyDict({"recons": recons, "encoding_top": enc_t, "encoding_bottom": enc_b, "quantized_top": quant_t,
+                        "quantized_bottom": quant_b, "commitment_loss": lambda: c_t + c_b, "embedding_loss": lambda: e_t + e_b,
+                        "codebook_usage_percentage": usage, "encoding_inds_top": i_t, "encoding_inds_bottom": i_b,
+                        "_vq_terms": (c_t, c_b, e_t, e_b)})
         return out["recons"] if self._summary_mode else out
 
     def get_code_indices(self, x):
@@ -147,6 +151,13 @@ class VQVAE2(HotPathModel):
     def loss_function(self, inputs, args: dict) -> dict:
         lw = self.lambda_weights
         rec = self.recon_obj(inputs, args["recons"], lw["reconstruction_loss"])
+        terms = args.get("_vq_terms") if os.environ.get("MOVAE_FUSE_LOSSES", "1") != "0" and rec.is_cuda else None
+        if terms is not None:
+            # top + bottom, the weights and the total in one launch (ops.CombineLosses); `terms` = (c_t, c_b, e_t, e_b)
+            wc, we = lw["commitment_loss"], lw["embedding_loss"]
+            coef = [[1.0, 0, 0, 0, 0], [0, wc, wc, 0, 0], [0, 0, 0, we, we]]
+            rec, com, emb, total = ops.combine_losses([rec, *terms], coef)
+            return {"reconstruction_loss": rec, "commitment_loss": com, "embedding_loss": emb, "total_loss": total}
         com = lw["commitment_loss"] * args["commitment_loss"]
         emb = lw["embedding_loss"] * args["embedding_loss"]
         return {"reconstruction_loss": rec, "commitment_loss": com, "embedding_loss": emb, "total_loss": rec + com + emb}

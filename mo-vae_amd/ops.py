@@ -75,9 +75,15 @@ COT_SINK = {}
 
 
 def _cot(feature_ptr, like):
+    """Destination for the gradient w.r.t. the tensor `like` (contiguous) whose memory the feature at `feature_ptr` views: the
+    registered sink slice, seen with `like`'s shape (the feature may be a permuted view of the same memory -- logical NCHW over
+    an NHWC buffer; the slice was allocated with the feature's strides, i.e. in that memory order), else a fresh buffer."""
     dst = COT_SINK.pop(feature_ptr, None) if COT_SINK else None
-    if dst is not None and dst.shape == like.shape and dst.dtype == like.dtype and dst.is_contiguous():
-        return dst
+    if dst is not None and dst.numel() == like.numel() and dst.dtype == like.dtype and like.is_contiguous():
+        if dst.shape == like.shape and dst.is_contiguous():
+            return dst
+        if sorted(zip(dst.stride(), dst.shape), reverse=True) == sorted(zip(like.stride(), like.shape), reverse=True):  # same memory order
+            return dst.as_strided(like.shape, like.stride())
     return torch.empty_like(like)
 
 
@@ -1440,6 +1446,59 @@ def vae_losses(recons, inputs, kind, scale_r, mu, log_var, scale_k):
     return VAELosses.apply(recons, inputs, kind, scale_r, mu, log_var, scale_k)
 
 
+class CombineLosses(Function):
+    """The scalar arithmetic of a loss_function (models/vq_vae.py:381-391, vq_vae2.py:313-334, betatc_vae.py:298-324) in one
+    launch forward and one backward: `inputs` are device tensors of 1..n fp32 scalars each (T scalars in all, in order), `coef`
+    a K x T list of rows, out[k] = f_k * w_k * (sum of the row's terms) and out[K] = out[0] + out[1] + ...  Returns the K + 1
+    scalars.  `anneal`: None or (row, iter_dev, steps, training) -- BetaTC's annealing counter on the device.  The backward
+    returns a cotangent only for the inputs a present cotangent reaches (the others stay None, so a per-loss backward of
+    mtl_backward does not walk the other losses' subgraphs)."""
+
+    @staticmethod
+    def forward(ctx, coef, anneal, *inputs):
+        ctx.set_materialize_grads(False)
+        L.require_gpu(inputs[0])
+        inputs = [_c(t) for t in inputs]
+        sizes = [t.numel() for t in inputs]
+        T, K = sum(sizes), len(coef)
+        assert all(len(r) == T for r in coef) and all(t.dtype == torch.float32 for t in inputs), (T, [len(r) for r in coef])
+        ptrs = (C.c_void_p * T)(*[t.data_ptr() + 4 * j for t, n in zip(inputs, sizes) for j in range(n)])
+        flat = (C.c_float * (K * T))(*[float(c) for r in coef for c in r])
+        out = torch.empty(K + 1, dtype=torch.float32, device=inputs[0].device)
+        row, it_dev, steps, training = anneal if anneal is not None else (-1, None, 1.0, False)
+        fac = torch.empty(1, dtype=torch.float32, device=out.device) if it_dev is not None else None
+        _call("movae_combine_losses_fwd", T, C.addressof(ptrs), K, C.addressof(flat), it_dev.data_ptr() if it_dev is not None else 0,
+              float(steps), int(row), int(bool(training)), out.data_ptr(), fac.data_ptr() if fac is not None else 0, _st(out))
+        ctx.coef, ctx.sizes, ctx.row, ctx.fac, ctx.flat = coef, sizes, int(row), fac, flat
+        ctx.shapes = [t.shape for t in inputs]
+        return tuple(out[k] for k in range(K + 1))
+
+    @staticmethod
+    def backward(ctx, *g):
+        K, T = len(ctx.coef), sum(ctx.sizes)
+        if all(x is None for x in g):
+            return (None,) * (2 + len(ctx.sizes))
+        g = [None if x is None else _c(x) for x in g]
+        dev = next(x for x in g if x is not None).device
+        gp = (C.c_void_p * (K + 1))(*[0 if x is None else x.data_ptr() for x in g])
+        gterms = torch.empty(T, dtype=torch.float32, device=dev)
+        _call("movae_combine_losses_bwd", T, K, C.addressof(gp), C.addressof(ctx.flat),
+              ctx.fac.data_ptr() if ctx.fac is not None else 0, ctx.row, gterms.data_ptr(), _st(gterms))
+        reached = [any(ctx.coef[k][t] != 0 and (g[k] is not None or g[K] is not None) for k in range(K)) for t in range(T)]
+        grads, off = [], 0
+        for i, n in enumerate(ctx.sizes):
+            if ctx.needs_input_grad[2 + i] and any(reached[off: off + n]):
+                grads.append(gterms[off: off + n].view(ctx.shapes[i]))
+            else:
+                grads.append(None)
+            off += n
+        return (None, None, *grads)
+
+
+def combine_losses(inputs, coef, anneal=None):
+    return CombineLosses.apply(coef, anneal, *inputs)
+
+
 class TCDecomposition(Function):
     """-> tensor [3] = (mi, tc, kld) of models/betatc_vae.py:294-296 (unweighted)."""
 
@@ -1492,12 +1551,14 @@ class VectorQuantize(Function):
         idx = torch.empty(rows, dtype=torch.int64, device=x.device)
         sse = torch.empty((), dtype=x.dtype, device=x.device)
         used = torch.empty((), dtype=torch.int32, device=x.device)
+        mse2 = torch.empty(2, dtype=x.dtype, device=x.device)
         wsp, wsb = _ws(x)
-        _call("movae_vq_nearest_fwd", x.data_ptr(), e.data_ptr(), q.data_ptr(), idx.data_ptr(), sse.data_ptr(), used.data_ptr(),
-              rows, k, d, wsp, wsb, _st(x))
-        mse = sse / float(x.numel())
-        commitment, embedding = mse, mse.clone()
+        # commitment = mse(q.detach(), x) and embedding = mse(q, x.detach()): one value, written twice by the finalize kernel
+        _call("movae_vq_nearest_fwd_mse", x.data_ptr(), e.data_ptr(), q.data_ptr(), idx.data_ptr(), sse.data_ptr(), used.data_ptr(),
+              mse2.data_ptr(), rows, k, d, wsp, wsb, _st(x))
+        commitment, embedding = mse2[0], mse2[1]
         ctx.save_for_backward(x, q, idx)
+        ctx.x_ptr = x.data_ptr()
         ctx.kd = (k, d)
         ctx.mark_non_differentiable(idx, used)
         ctx.set_materialize_grads(False)  # a loss that does not reach an output hands None (not zeros): that part is skipped
@@ -1513,7 +1574,7 @@ class VectorQuantize(Function):
         # a cotangent that reaches neither the straight-through output nor the commitment term (the embedding loss alone) has NO
         # gradient w.r.t. x: None, not a tensor of zeros -- mtl_backward then skips that loss's pull-back through the encoder
         # (a zero Jacobian row costs nothing); likewise no codebook gradient without an embedding-loss cotangent
-        dx = torch.empty_like(x) if (need_x and (dq is not None or gc is not None)) else None
+        dx = _cot(ctx.x_ptr, x) if (need_x and (dq is not None or gc is not None)) else None  # (x is a feature: born stacked)
         de = torch.empty((k, d), dtype=x.dtype, device=x.device) if (need_e and ge is not None) else None
         if dx is None and de is None:
             return None, None

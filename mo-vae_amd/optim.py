@@ -18,6 +18,12 @@ def _dense(t):
     return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
 
 
+def _layout_differs(a, p):
+    """Do a and p (same shape) lay their elements out differently?  Strides of size-1 dimensions carry no layout: a 1x1
+    convolution's weight [o, i, 1, 1] is the same memory contiguous (strides i, 1, 1, 1) and channels_last (i, 1, i, i)."""
+    return a.shape != p.shape or any(n > 1 and x != y for n, x, y in zip(p.shape, a.stride(), p.stride()))
+
+
 class FusedAdam(torch.optim.Adam):
     """torch.optim.Adam(params, lr, betas, eps, weight_decay) with a one-launch step.
 
@@ -73,7 +79,7 @@ class FusedAdam(torch.optim.Adam):
                     raise RuntimeError("Adam does not support sparse gradients")
                 if p.dtype != torch.float32 or not _dense(p):
                     raise NotImplementedError("FusedAdam: parameters must be dense fp32 tensors")
-                if g.stride() != p.stride() or g.dtype != p.dtype:
+                if g.dtype != p.dtype or _layout_differs(g, p):
                     g = torch.empty_like(p).copy_(g)
                 st = self.state[p]
                 if len(st) == 0:
@@ -85,7 +91,7 @@ class FusedAdam(torch.optim.Adam):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 m, v = st["exp_avg"], st["exp_avg_sq"]
-                if m.stride() != p.stride() or v.stride() != p.stride():  # state loaded from a differently laid out checkpoint
+                if _layout_differs(m, p) or _layout_differs(v, p):  # state loaded from a differently laid out checkpoint
                     m = st["exp_avg"] = torch.empty_like(p).copy_(m)
                     v = st["exp_avg_sq"] = torch.empty_like(p).copy_(v)
                 if self._device_step:

@@ -66,6 +66,16 @@ def print_gd_similarity(_, inputs, weights):
     _hook_values["similarity"] = aggregation.gd_similarity(inputs[0], weights)
 
 
+def _stacked(losses):
+    """torch.stack of the detached component losses -- as a view when they already lie next to each other in one buffer (the
+    fused loss kernels write them that way: ops.VAELosses / ops.CombineLosses), so no launch is spent on it."""
+    first = losses[0]
+    if all(c.dim() == 0 and c.dtype == first.dtype and c.untyped_storage().data_ptr() == first.untyped_storage().data_ptr()
+           and c.storage_offset() == first.storage_offset() + i for i, c in enumerate(losses)):
+        return first.detach().as_strided((len(losses),), (1,))
+    return torch.stack([c.detach() for c in losses])
+
+
 def forward_backward_begin(net, images, optimizer, aggregator):
     """zero_grad, forward, losses and the backward down to the features (main.py:157-196, first half of torchjd's
     mtl_backward).  Returns (loss_dict, outputs, pending): `pending` is None when the whole backward is already done
@@ -81,7 +91,7 @@ def forward_backward_begin(net, images, optimizer, aggregator):
         features = [outputs[f] for f in net.features] if net.features is not None else None
         component_losses = [v for k, v in loss_dict.items() if k != "total_loss"]  # main.py:184
         if isinstance(aggregator, (MGDA, COMFORT)):  # main.py:185
-            aggregator.set_losses(torch.stack([c.detach() for c in component_losses]))
+            aggregator.set_losses(_stacked(component_losses))
         if features is None:
             autojac.backward(component_losses, aggregator=aggregator)
             return loss_dict, outputs, None

@@ -260,6 +260,54 @@ def test_shared_task_side_weight_is_not_double_counted(gpu_device):
         np.testing.assert_allclose(p.grad.cpu().numpy(), w.cpu().numpy(), rtol=1e-4, atol=1e-6 * float(w.abs().max()))
 
 
+@pytest.mark.parametrize("tag", ["vq_vae_tiny", "vq_vae2_tiny", "betatc_vae_tiny"])
+def test_fused_loss_arithmetic_equals_tensor_arithmetic(tag, gpu_device, monkeypatch):
+    """ops.CombineLosses (weights, top + bottom, annealing and the total in one launch) against the loss_function written as
+    tensor arithmetic like the reference's (MOVAE_FUSE_LOSSES=0): the same loss values bit for bit, the same per-loss and
+    total-loss parameter gradients, and a per-loss backward that does not reach the other losses' subgraphs."""
+    import movae_amd  # noqa: F401
+    from movae_amd.models.betatc_vae import BetaTCVAE
+    from movae_amd.train import _stacked
+
+    fx = load_golden(tag)
+    res = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("MOVAE_FUSE_LOSSES", fuse)
+        net, m = build(fx)
+        net = net.to(gpu_device).train()
+        if "eps.0" in fx.files:
+            net.eps_override = T(fx["eps.0"]).to(gpu_device)
+        x = T(fx["x"]).to(gpu_device)
+        for _ in range(2):  # BetaTC: the second call anneals with num_iter = 2
+            out = net(x)
+            ld = net.loss_function(x, args=out)
+        keys = [k for k in ld if k != "total_loss"]
+        params = [p for p in net.parameters() if p.requires_grad]
+        grads = {}
+        for k in keys + ["total_loss"]:
+            gs = torch.autograd.grad(ld[k], params, retain_graph=True, allow_unused=True)
+            grads[k] = [None if g is None else g.detach().cpu().numpy() for g in gs]
+        res[fuse] = ({k: float(v.detach()) for k, v in ld.items()}, grads, [n for n, _ in net.named_parameters()])
+        if fuse == "1":
+            st = _stacked([ld[k] for k in keys])
+            assert st.data_ptr() == ld[keys[0]].data_ptr() and st.shape == (len(keys),), "the component losses should be one buffer"
+            assert torch.equal(st, torch.stack([ld[k].detach() for k in keys]))
+            if tag == "vq_vae2_tiny":  # the lazily formed sums are ordinary tensors for any other reader
+                assert callable(dict.__getitem__(out, "commitment_loss")) and not isinstance(dict.__getitem__(out, "commitment_loss"), torch.Tensor)
+                c = out["commitment_loss"]
+                assert isinstance(c, torch.Tensor) and float(c.detach()) == float((out["_vq_terms"][0] + out["_vq_terms"][1]).detach())
+                assert isinstance(dict(out.items())["embedding_loss"], torch.Tensor)
+    BetaTCVAE.num_iter = 0
+    (lf, gf, names), (lu, gu, _) = res["1"], res["0"]
+    assert list(lf) == list(lu)
+    for k in lf:
+        assert lf[k] == lu[k], f"{k}: fused {lf[k]!r} != tensor arithmetic {lu[k]!r}"
+        for n, a, b in zip(names, gf[k], gu[k]):
+            assert (a is None) == (b is None), f"{k}: {n} reached by one form only"
+            if a is not None:
+                np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-9 * max(1.0, float(np.abs(b).max())), err_msg=f"{k} {n}")
+
+
 def _full_case(tag):
     fx = load_golden("full_configs")
     m = {}

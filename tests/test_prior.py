@@ -39,14 +39,14 @@ def test_oracle_prior_matches_reference_vectors(tag):
     for k, v in out.items():
         np.testing.assert_allclose(v.detach().numpy(), fx[f"{tag}.{k}"], rtol=1e-5, atol=1e-6, err_msg=k)
     for k, v in ld.items():
-        np.testing.assert_allclose(float(v), fx[f"{tag}.loss.{k}"], rtol=1e-6, err_msg=k)
+        np.testing.assert_allclose(float(v.detach()), fx[f"{tag}.loss.{k}"], rtol=1e-6, err_msg=k)
     for n, v in g.items():
         np.testing.assert_allclose(v.numpy(), fx[f"{tag}.g.{n}"], rtol=1e-4, atol=1e-7, err_msg="grad " + n)
     tr2 = OP.PriorTrainer(cfg, seed, lr=lr)
     tr2.step(zt, zb)
     ld2, _ = OP.losses(tr2.sd, cfg, zt, zb)  # the second forward re-masks the weights, as the fixture's did
     for k, v in ld2.items():
-        np.testing.assert_allclose(float(v), fx[f"{tag}.loss2.{k}"], rtol=2e-6, err_msg="loss2 " + k)
+        np.testing.assert_allclose(float(v.detach()), fx[f"{tag}.loss2.{k}"], rtol=2e-6, err_msg="loss2 " + k)
     for k in keys:
         np.testing.assert_allclose(tr2.sd[k].detach().numpy(), fx[f"{tag}.sd1.{k}"], rtol=1e-5, atol=2e-7, err_msg="sd1 " + k)
 
