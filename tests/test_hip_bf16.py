@@ -106,7 +106,7 @@ def test_bf16_c3_shaped_step_against_the_fp32_oracle(bf16, gpu_device):
     ld = net.loss_function(xg, args=out)
     assert list(ld.keys()) == list(old.keys())
     for k, v in ld.items():
-        np.testing.assert_allclose(v.detach().item(), float(old[k]), rtol=2e-2, atol=1e-6, err_msg=f"loss {k} (bf16 operands vs fp32 oracle)")
+        np.testing.assert_allclose(v.detach().item(), float(old[k].detach()), rtol=2e-2, atol=1e-6, err_msg=f"loss {k} (bf16 operands vs fp32 oracle)")
     A = aggregation.make_aggregator(a)
     net.zero_grad(set_to_none=True)
     autojac.mtl_backward(losses=[v for k, v in ld.items() if k != "total_loss"], features=[out[f] for f in net.features], aggregator=A,

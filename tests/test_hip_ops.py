@@ -768,8 +768,8 @@ def test_to_nhwc_remembers_only_unmodified_constant_inputs(M):
 
 
 def test_restack_rebuilds_stacked_views_only(M):
-    """autojac._restack: G equal, adjacent, contiguous slices of one buffer come back as the [G, ...] view of that buffer
-    (no copy); anything else stays a list."""
+    """autojac._restack: G equal, adjacent, dense slices of one buffer (contiguous, or a permutation of it such as the NCHW
+    view of an NHWC feature) come back as the [G, ...] view of that buffer (no copy); anything else stays a list."""
     from movae_amd import autojac
 
     buf = torch.arange(2 * 3 * 4, dtype=torch.float32).cuda().reshape(2, 3, 4)
@@ -778,7 +778,9 @@ def test_restack_rebuilds_stacked_views_only(M):
     assert isinstance(autojac._restack([buf[1], buf[0]]), list)                  # wrong order
     assert isinstance(autojac._restack([buf[0], buf[0].clone()]), list)         # different storage
     assert isinstance(autojac._restack([buf[0, :2], buf[1, :2]]), list)          # not adjacent
-    assert isinstance(autojac._restack([buf[0].t(), buf[1].t()]), list)          # not contiguous
+    r = autojac._restack([buf[0].t(), buf[1].t()])                               # dense, permuted: the stacked view keeps the strides
+    assert isinstance(r, torch.Tensor) and r.data_ptr() == buf.data_ptr() and torch.equal(r, torch.stack([buf[0].t(), buf[1].t()]))
+    assert isinstance(autojac._restack([buf[0, :, ::2], buf[1, :, ::2]]), list)  # not dense
 
 
 def test_invalid_arguments_raise(M):

@@ -256,7 +256,7 @@ def test_full_size_sum_gradients_elementwise(tag, gpu_device, monkeypatch):
     ld = net.loss_function(xg, args=out)
     assert list(ld.keys()) == list(old.keys())
     for k, v in ld.items():
-        np.testing.assert_allclose(v.item(), float(old[k]), rtol=5e-4, atol=1e-5 + 2e-6 * abs(float(old["total_loss"])), err_msg=k)
+        np.testing.assert_allclose(v.item(), float(old[k].detach()), rtol=5e-4, atol=1e-5 + 2e-6 * abs(float(old["total_loss"].detach())), err_msg=k)
     ld["total_loss"].backward()
     if tag in ("C3", "C4"):  # VQ: a float64 run quantises near-tied rows differently, so the fp32 oracle is the reference
         rtol, atol_rel = SUM_TOL[tag]
