@@ -312,6 +312,22 @@ int movae_scale_by_clip(float* g, size_t n, const float* sumsq_dev, float max_no
 #define MOVAE_DTYPE_BF16 1
 int movae_set_compute_dtype(int dtype);
 
+/* A weight gradient's split-K reduce need not be a launch of its own on the backward's dependency chain: nobody reads the weight
+ * gradient before the aggregation / the optimizer.  movae_reduce_defer(1) arms the NEXT movae_conv*_wgrad* / *_dgrad_wgrad* call
+ * (one call): its reduce is parked instead of launched, and the next implicit-GEMM launch on the same stream carries it as extra
+ * blocks behind its own (same arithmetic, same order).  The caller guarantees (mo-vae_amd/ops.py does) that until then (a) nothing
+ * reads the call's dw / dbias destinations and (b) nothing writes the scratch arena `ws` the call was given.  A second armed call,
+ * a following call's bias column sums, or movae_reduce_flush() launch a still-parked reduce stand-alone.  Returns the previous
+ * arming.  movae_reduce_defer_stats: out3 = {parked, carried by a later launch, launched stand-alone after all}; returns 1 while a
+ * reduce is parked. */
+int movae_reduce_defer(int on);
+int movae_reduce_flush(void);
+int movae_reduce_defer_stats(long long* out3, int reset);
+/* Only reduces whose slabs hold at most this many bytes are parked (a parked reduce runs with its carrier's occupancy: right for a
+ * launch-bound reduce, wrong for a bandwidth-bound one).  Default 2 MiB (MOVAE_DEFER_MAX_BYTES); bytes < 0 only reads.  Returns the
+ * previous value. */
+long long movae_reduce_defer_max_bytes(long long bytes);
+
 /* ---- measurement hook (bench.py's roofline leg only; no reference counterpart) ------------------------
  * on != 0: the conv family launches ONLY its main MFMA kernel (split-K reduce / bias column-sum launches are
  * skipped, so outputs are incomplete) so that one kernel can be timed between HIP events.  Process-wide;

@@ -127,6 +127,10 @@ SIGNATURES = {
     "movae_cross_entropy_bwd": ([_p, _p, _p, _p, _p, _z, _i, _p], _i),
     "movae_bench_main_kernel_only": ([_i], _i),
     "movae_bench_last_kernel": ([], C.c_char_p),
+    "movae_reduce_defer": ([_i], _i),
+    "movae_reduce_flush": ([], _i),
+    "movae_reduce_defer_stats": ([_p, _i], _i),
+    "movae_reduce_defer_max_bytes": ([C.c_longlong], C.c_longlong),
     "movae_bench_force_split": ([_i], _i),
     "movae_bench_force_kgemm": ([_i], _i),
     "movae_set_compute_dtype": ([_i], _i),
@@ -194,12 +198,46 @@ def set_compute_dtype(name):
 
 TRACE = None  # optional callable(name, args) invoked for every C-ABI launch (bench.py's recorder)
 
+#: Deferred weight-gradient reduces (include/movae.h: movae_reduce_defer; ops.deferred_reduces is the switch).  While a reduce may
+#: be parked, the calls listed here go ahead -- the backward's own ops: they neither read a convolution's weight / bias gradient nor
+#: write the parked call's scratch arena (armed calls get arenas 2 / 3 in turn, everything else arena 0), and the implicit-GEMM
+#: ones among them carry the parked reduce along.  Any other call -- the aggregation, the optimizer, a forward op -- first makes
+#: the library launch it stand-alone (movae_reduce_flush).
+DEFER_ON = [False]
+DEFER_PASS = frozenset(
+    [f"movae_conv{t}2d_{k}" for t in ("", "T") for k in ("dgrad", "dgrad_f", "wgrad_grouped", "wgrad_grouped_f", "dgrad_wgrad_grouped",
+                                                       "dgrad_wgrad_grouped_f")] +
+    ["movae_bn_bwd_finalize", "movae_bn_bwd_apply", "movae_bn_bwd_finalize_apply", "movae_bn_act_bwd", "movae_bn_act_bwd_grouped",
+     "movae_act_bwd", "movae_act_bwd_bias_grouped", "movae_colsum", "movae_add", "movae_axpby", "movae_copy_channels", "movae_mul",
+     "movae_nchw_to_nhwc", "movae_nhwc_to_nchw", "movae_reparam_bwd", "movae_kl_bwd", "movae_recon_loss_bwd", "movae_tc_decomp_bwd",
+     "movae_combine_losses_bwd", "movae_vq_bwd", "movae_linear_pair_bwd", "movae_edge_weighted_mse_bwd", "movae_edge_match_bwd",
+     "movae_gated_residual_bwd"])
+_defer_arena = [0]
+
+
+def defer_arm(device):
+    """Arm the next weight-gradient call (ops.Conv.backward*): -> (ws pointer, ws bytes) of the arena its slabs may keep until a
+    later launch has carried the reduce.  Not traced: bench.py's replay of recorded calls launches every reduce stand-alone."""
+    _defer_arena[0] ^= 1
+    w = workspace(device, slot=2 + _defer_arena[0])
+    load().movae_reduce_defer(1)
+    return w.data_ptr(), w.numel()
+
+
+def defer_flush():
+    """Launch a still-parked reduce now (before anything outside this library reads a weight gradient)."""
+    if _lib is not None:
+        check(load().movae_reduce_flush(), "movae_reduce_flush")
+
 
 def call(name, *args):
     """Invoke one C-ABI entry point, raising RuntimeError with the library's message on failure."""
     if TRACE is not None:
         TRACE(name, args)
-    check(getattr(load(), name)(*args), name)
+    lib = load()
+    if DEFER_ON[0] and name not in DEFER_PASS:
+        check(lib.movae_reduce_flush(), "movae_reduce_flush")
+    check(getattr(lib, name)(*args), name)
 
 
 class Unsupported(RuntimeError):

@@ -85,6 +85,7 @@ def _accumulate(p, g, taken=()):
                            "does not support shared weights")
     else:
         ops.join_wgrad()  # both operands may still be in flight on the weight-gradient side stream
+        ops.flush_deferred()  # ... or wait in a parked split-K reduce (ops.deferred_reduces)
         p.grad = p.grad + g
 
 
@@ -384,9 +385,30 @@ def mtl_backward_begin(losses, features, aggregator, tasks_params=None, shared_p
             ops.GRAD_ACCUM.update({p.data_ptr(): p.grad for p in tp if p.grad is not None})
         ops.COT_SINK.clear()
         ops.COT_SINK.update({f.data_ptr(): c[i] for f, c in zip(st.feat_diff, cot) if c is not None})
+        # a task-side parameter no earlier loss reached gets its gradient written into a buffer kept across steps (no allocation;
+        # and a destination the kernels know nobody reads before the optimizer: its split-K reduce may ride on a later launch)
+        ops.GRAD_SINK.clear()
+        owned = {}
+        if ops.L.DEFER is None:
+            for p in tp:
+                if p.grad is None:
+                    buf = ops.GRAD_SINK[p.data_ptr()] = _task_grad_buffer(p)
+                    owned[buf.data_ptr()] = p
+        n_w, n_z = len(ops.SINK_LOG), len(ops.SINK_ZERO_LOG)
         try:
-            got = torch.autograd.grad(loss, tp + st.feat_diff, grad_outputs=seed, retain_graph=True, allow_unused=True)
+            with ops.deferred_reduces():
+                got = torch.autograd.grad(loss, tp + st.feat_diff, grad_outputs=seed, retain_graph=True, allow_unused=True)
         finally:
+            # a buffer handed out as an untouched all-zero gradient (ops._sink_zeros) must BE zero: it is, unless an earlier
+            # step wrote it (a BatchNorm switched between eval and training mode) -- re-zeroed then, once
+            for ptr in ops.SINK_LOG[n_w:]:
+                if ptr in owned:
+                    owned[ptr]._movae_grad_written = True
+            for ptr in ops.SINK_ZERO_LOG[n_z:]:
+                if ptr in owned and getattr(owned[ptr], "_movae_grad_written", False):
+                    owned[ptr]._movae_grad_buf.zero_()
+                    owned[ptr]._movae_grad_written = False
+            ops.GRAD_SINK.clear()
             ops.COT_SINK.clear()
             ops.GRAD_ACCUM.clear()
             taken = frozenset(ops.GRAD_ACCUM_TAKEN)
@@ -399,7 +421,21 @@ def mtl_backward_begin(losses, features, aggregator, tasks_params=None, shared_p
     return st
 
 
+def _task_grad_buffer(p):
+    """Flat fp32 buffer of p's size, one per parameter for life (the memory image of the gradient: ops._sink views it)."""
+    buf = getattr(p, "_movae_grad_buf", None)
+    if buf is None or buf.numel() != p.numel() or buf.device != p.device:
+        buf = torch.zeros(p.numel(), dtype=p.dtype, device=p.device)  # (zero: ops._sink_zeros hands a sink out untouched)
+        p._movae_grad_buf, p._movae_grad_written = buf, False
+    return buf
+
+
 def mtl_backward_finish(st):
+    with ops.deferred_reduces():
+        return _mtl_backward_finish(st)
+
+
+def _mtl_backward_finish(st):
     """Second half: the K feature cotangents are pulled back through the shared trunk (batched), the Jacobian is
     aggregated and the result lands in the shared parameters' .grad."""
     jb, feat_diff, feat_grads, shared_params = st.jb, st.feat_diff, st.feat_grads, st.shared_params

@@ -612,21 +612,21 @@ struct RGroups {
     float* out2[8];
     long slab_gs;
 };
-__global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ slab, RGroups rg, long total,
-                                                     int S, int N, const float* __restrict__ bias, int act, float slope,
-                                                     int accumulate, long n1, ActMul am) {
-    slab += blockIdx.y * rg.slab_gs;
-    float* __restrict__ out = rg.out[blockIdx.y];
-    float* __restrict__ out2 = rg.out2[blockIdx.y];
+__device__ __forceinline__ void splitk_reduce_body(const float* __restrict__ slab, const RGroups& rg, long total, int S, int N,
+                                                   const float* __restrict__ bias, int act, float slope, int accumulate, long n1,
+                                                   const ActMul& am, int bx, int by, float* lds) {
+    slab += by * rg.slab_gs;
+    float* __restrict__ out = rg.out[by];
+    float* __restrict__ out2 = rg.out2[by];
     const int il = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const long i = (long)blockIdx.x * 16 + il;
+    const long i = (long)bx * 16 + il;
     float v = 0.f;
     if (i < total)
         for (int z = sl; z < S; z += 16) v += slab[(long)z * total + i];
     // lanes of one wave hold sl in {4w..4w+3}; fold those with shuffles, then the 4 waves through LDS
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
-    __shared__ float sh[4][16];
+    float(*sh)[16] = reinterpret_cast<float(*)[16]>(lds);
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) < 16) sh[w][il] = v;
     __syncthreads();
@@ -638,16 +638,22 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ s
         *o = accumulate ? *o + v : v;
     }
 }
+__global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ slab, RGroups rg, long total,
+                                                     int S, int N, const float* __restrict__ bias, int act, float slope,
+                                                     int accumulate, long n1, ActMul am) {
+    __shared__ __attribute__((aligned(16))) float lds[64];
+    splitk_reduce_body(slab, rg, total, S, N, bias, act, slope, accumulate, n1, am, blockIdx.x, blockIdx.y, lds);
+}
 
 // many slabs (S >= 64) over few outputs: 64 split-lanes x 4 float4 columns per block, 4 independent 16-byte loads in
 // flight per lane; the 16 split-lanes of a wave fold with shuffles, the 4 waves through LDS.  Deterministic.
-__global__ __launch_bounds__(256) void splitk_reduce_wide(const float* __restrict__ slab, RGroups rg, long total, int S, int N,
-        const float* __restrict__ bias, int act, float slope, int accumulate, long n1, ActMul am) {
-    slab += blockIdx.y * rg.slab_gs;
-    float* __restrict__ out = rg.out[blockIdx.y];
-    float* __restrict__ out2 = rg.out2[blockIdx.y];
+__device__ __forceinline__ void splitk_reduce_wide_body(const float* __restrict__ slab, const RGroups& rg, long total, int S, int N,
+        const float* __restrict__ bias, int act, float slope, int accumulate, long n1, const ActMul& am, int bx, int by, float* lds) {
+    slab += by * rg.slab_gs;
+    float* __restrict__ out = rg.out[by];
+    float* __restrict__ out2 = rg.out2[by];
     const int il = threadIdx.x & 3, sl = threadIdx.x >> 2;
-    const long i = ((long)blockIdx.x * 4 + il) * 4;
+    const long i = ((long)bx * 4 + il) * 4;
     f32x4 acc[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -672,7 +678,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_wide(const float* __restric
         s += __shfl_xor(s, 32, 64);
         v[j] = s;
     }
-    __shared__ f32x4 sh[4][4];
+    f32x4(*sh)[4] = reinterpret_cast<f32x4(*)[4]>(lds);
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) < 4) sh[w][il] = v;
     __syncthreads();
@@ -689,16 +695,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_wide(const float* __restric
         *reinterpret_cast<f32x4*>(dst) = o;
     }
 }
+__global__ __launch_bounds__(256) void splitk_reduce_wide(const float* __restrict__ slab, RGroups rg, long total, int S, int N,
+        const float* __restrict__ bias, int act, float slope, int accumulate, long n1, ActMul am) {
+    __shared__ __attribute__((aligned(16))) float lds[64];
+    splitk_reduce_wide_body(slab, rg, total, S, N, bias, act, slope, accumulate, n1, am, blockIdx.x, blockIdx.y, lds);
+}
 
 // 8 <= S < 64 slabs over MANY outputs (>= 2^19): a thread owns four consecutive outputs and walks the slabs with four 16-byte loads
 // in flight -- the 16-split-lane kernel above reads 4-byte pieces in 64-byte runs, which is what a few hundred outputs per CU need
 // to fill the chip but half the achievable rate on the 2-10 MB results of the C3-C5 weight gradients (14.4 us for 33 MB of slabs).
-__global__ __launch_bounds__(256) void splitk_reduce_vec(const float* __restrict__ slab, RGroups rg, long total, int S, int N,
-        const float* __restrict__ bias, int act, float slope, int accumulate, long n1, ActMul am) {
-    slab += blockIdx.y * rg.slab_gs;
-    float* __restrict__ out = rg.out[blockIdx.y];
-    float* __restrict__ out2 = rg.out2[blockIdx.y];
-    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+__device__ __forceinline__ void splitk_reduce_vec_body(const float* __restrict__ slab, const RGroups& rg, long total, int S, int N,
+        const float* __restrict__ bias, int act, float slope, int accumulate, long n1, const ActMul& am, int bx, int by) {
+    slab += by * rg.slab_gs;
+    float* __restrict__ out = rg.out[by];
+    float* __restrict__ out2 = rg.out2[by];
+    const long i = ((long)bx * 256 + threadIdx.x) * 4;
     if (i >= total) return;
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
     int z = 0;
@@ -720,15 +731,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec(const float* __restrict
     }
     *reinterpret_cast<f32x4*>(dst) = o;
 }
+__global__ __launch_bounds__(256) void splitk_reduce_vec(const float* __restrict__ slab, RGroups rg, long total, int S, int N,
+        const float* __restrict__ bias, int act, float slope, int accumulate, long n1, ActMul am) {
+    splitk_reduce_vec_body(slab, rg, total, S, N, bias, act, slope, accumulate, n1, am, blockIdx.x, blockIdx.y);
+}
 
 // few slabs over many outputs: one thread per output, grid-stride
-__global__ __launch_bounds__(256) void splitk_reduce_flat(const float* __restrict__ slab, RGroups rg, long total, int S, int N,
-        const float* __restrict__ bias, int act, float slope, int accumulate, long n1, ActMul am) {
-    slab += blockIdx.y * rg.slab_gs;
-    float* __restrict__ out = rg.out[blockIdx.y];
-    float* __restrict__ out2 = rg.out2[blockIdx.y];
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+__device__ __forceinline__ void splitk_reduce_flat_body(const float* __restrict__ slab, const RGroups& rg, long total, int S, int N,
+        const float* __restrict__ bias, int act, float slope, int accumulate, long n1, const ActMul& am, int bx, int by, int nbx) {
+    slab += by * rg.slab_gs;
+    float* __restrict__ out = rg.out[by];
+    float* __restrict__ out2 = rg.out2[by];
+    const long stride = (long)nbx * 256;
+    for (long i = (long)bx * 256 + threadIdx.x; i < total; i += stride) {
         float v = 0.f;
         for (int z = 0; z < S; ++z) v += slab[(long)z * total + i];
         if (bias) v += bias[i % N];
@@ -736,6 +751,32 @@ __global__ __launch_bounds__(256) void splitk_reduce_flat(const float* __restric
         float* o = i < n1 ? out + i : out2 + (i - n1);
         *o = accumulate ? *o + v : v;
     }
+}
+__global__ __launch_bounds__(256) void splitk_reduce_flat(const float* __restrict__ slab, RGroups rg, long total, int S, int N,
+        const float* __restrict__ bias, int act, float slope, int accumulate, long n1, ActMul am) {
+    splitk_reduce_flat_body(slab, rg, total, S, N, bias, act, slope, accumulate, n1, am, blockIdx.x, blockIdx.y, gridDim.x);
+}
+
+// ---- a weight-gradient reduce riding on a LATER launch ---------------------------------------------------
+// Nobody reads a weight gradient before the aggregation / the optimizer, so the reduce of layer i's slabs need not be a launch of
+// its own on the backward's dependency chain: it is parked (host side: g_defer) and the next implicit-GEMM launch -- layer i-1's
+// input gradient / pair -- carries it as extra blocks behind its own.  Same arithmetic, same order as the stand-alone kernels.
+struct RSide {
+    const float* slab;
+    RGroups rg;
+    long total, n1;
+    int S, N, accumulate;
+    int kind;  // 0 wide, 1 vec, 2 plain (16 split lanes), 3 flat
+    int nbx;   // blocks per group (the stand-alone launch's grid x); blocks in all: nbx * groups
+    int nblk;  // 0: nothing rides on this launch
+};
+__device__ __forceinline__ void side_reduce(const RSide& r, int bid, float* lds) {
+    const int bx = bid % r.nbx, by = bid / r.nbx;
+    const ActMul none{nullptr, 0, 0.f, 0, 0, nullptr};
+    if (r.kind == 0) splitk_reduce_wide_body(r.slab, r.rg, r.total, r.S, r.N, nullptr, 0, 0.f, r.accumulate, r.n1, none, bx, by, lds);
+    else if (r.kind == 1) splitk_reduce_vec_body(r.slab, r.rg, r.total, r.S, r.N, nullptr, 0, 0.f, r.accumulate, r.n1, none, bx, by);
+    else if (r.kind == 2) splitk_reduce_body(r.slab, r.rg, r.total, r.S, r.N, nullptr, 0, 0.f, r.accumulate, r.n1, none, bx, by, lds);
+    else splitk_reduce_flat_body(r.slab, r.rg, r.total, r.S, r.N, nullptr, 0, 0.f, r.accumulate, r.n1, none, bx, by, r.nbx);
 }
 
 // BWD form with per-class split factors: pixel (ho, wo) belongs to output-parity class (ho % s) * s + (wo % s) and only the
@@ -846,29 +887,107 @@ inline long reduce_vec_min() {  // outputs from which the 16-byte reduce serves 
     return v;
 }
 
+// ---- host side of the parked reduce ------------------------------------------------------------------------------------------
+// movae_reduce_defer(1) (ops.py: the destination is a gradient sink nobody reads before the aggregation, and the call's scratch
+// arena is not touched by the calls that follow) arms the NEXT weight-gradient call: its split-K reduce is parked instead of
+// launched.  The next implicit-GEMM launch on the same stream takes it along (defer_take -> extra blocks); movae_reduce_flush(),
+// any second parked reduce, or a call that cannot carry it launch it stand-alone.  At most one is parked.
+struct DeferredReduce {
+    bool armed = false, pending = false;
+    unsigned serial = 0;  // counts parked reduces (DeferScope: was the one parked at entry carried?)
+    RSide r{};
+    hipStream_t st = nullptr;
+};
+// PROCESS-wide, not thread_local like the per-call plans (g_pending, g_kpend): the reduce is parked by one library call and taken
+// by a later one, and torch runs a backward's nodes on its autograd thread while the caller that flushes sits on another.  The
+// calls themselves are sequential (one stream, one step); the arming flag travels with the thread that makes the armed call.
+static DeferredReduce g_defer;
+static long g_defer_stats[3] = {0, 0, 0};  // parked, carried by a later launch, launched stand-alone after all
+
+struct DeferArmScope {  // a weight-gradient entry point: remembers what was parked at entry, disarms at exit
+    unsigned serial = g_defer.serial;
+    ~DeferArmScope() { g_defer.armed = false; }
+};
+
+inline int reduce_launch(const RSide& r, const float* bias, int act, float slope, const ActMul& am, hipStream_t st) {
+    const dim3 grid((unsigned)r.nbx, (unsigned)(r.nblk / r.nbx));
+    if (r.kind == 0)
+        hipLaunchKernelGGL(splitk_reduce_wide, grid, dim3(256), 0, st, r.slab, r.rg, r.total, r.S, r.N, bias, act, slope, r.accumulate, r.n1, am);
+    else if (r.kind == 1)
+        hipLaunchKernelGGL(splitk_reduce_vec, grid, dim3(256), 0, st, r.slab, r.rg, r.total, r.S, r.N, bias, act, slope, r.accumulate, r.n1, am);
+    else if (r.kind == 2)
+        hipLaunchKernelGGL(splitk_reduce, grid, dim3(256), 0, st, r.slab, r.rg, r.total, r.S, r.N, bias, act, slope, r.accumulate, r.n1, am);
+    else
+        hipLaunchKernelGGL(splitk_reduce_flat, grid, dim3(256), 0, st, r.slab, r.rg, r.total, r.S, r.N, bias, act, slope, r.accumulate, r.n1, am);
+    MOVAE_CHECK_LAUNCH("splitk_reduce");
+    return MOVAE_OK;
+}
+
+inline int defer_flush() {
+    if (!g_defer.pending) return MOVAE_OK;
+    g_defer.pending = false;
+    ++g_defer_stats[2];
+    return reduce_launch(g_defer.r, nullptr, 0, 0.f, ActMul{nullptr, 0, 0.f, 0, 0, nullptr}, g_defer.st);
+}
+
+// the parked reduce, if this launch (on stream st) can carry it; r.nblk == 0 otherwise
+inline RSide defer_take(hipStream_t st) {
+    RSide none{};
+    if (!g_defer.pending || g_defer.st != st || g_bench_main_only) return none;
+    g_defer.pending = false;
+    ++g_defer_stats[1];
+    return g_defer.r;
+}
+
+// a 3-D launch takes the parked reduce as whole extra z layers in FRONT of its own (*sz = those layers, g.z grows): blocks are
+// dispatched in index order, so the reduce's short blocks run beside the launch's first wave instead of after its last one.
+// The hardware's z limit can refuse (a reduce of many blocks in front of a one-tile layer): the reduce stays parked then
+inline RSide defer_take_3d(hipStream_t st, dim3* g, int* sz) {
+    *sz = 0;
+    RSide none{};
+    if (!g_defer.pending || g_defer.st != st || g_bench_main_only) return none;
+    const long layers = ((long)g_defer.r.nblk + (long)g->x * g->y - 1) / ((long)g->x * g->y);
+    if ((long)g->z + layers > 65535) return none;
+    g->z += (unsigned)layers;
+    *sz = (int)layers;
+    return defer_take(st);
+}
+
+// a parked reduce is a few blocks' work in a launch built for something else (its occupancy, not the reduce's): only reduces that
+// are launch-bound on their own are parked -- slabs of at most this many bytes (33 MB of slabs behind a 185 us kernel cost it 49 us)
+static size_t g_defer_max_bytes = getenv("MOVAE_DEFER_MAX_BYTES") ? (size_t)atol(getenv("MOVAE_DEFER_MAX_BYTES")) : (size_t)(2u << 20);
+inline size_t defer_max_bytes() { return g_defer_max_bytes; }
+
 inline int launch_reduce_groups(const float* slab, const RGroups& rg, int G, long n1, long n2, int S, int N, const float* bias, int act,
-                                float slope, int accumulate, hipStream_t st, ActMul am = ActMul{nullptr, 0, 0.f, 0, 0, nullptr}) {
+                                float slope, int accumulate, hipStream_t st, ActMul am = ActMul{nullptr, 0, 0.f, 0, 0, nullptr},
+                                bool deferrable = false) {
     if (g_bench_main_only) return MOVAE_OK;
     const long total = n1 + n2;  // floats per slab: n1 outputs for `out`, then n2 for `out2`
     uintptr_t al = reinterpret_cast<uintptr_t>(slab) | (uintptr_t)(rg.slab_gs * 4);
     for (int i = 0; i < G; ++i) al |= reinterpret_cast<uintptr_t>(rg.out[i]) | reinterpret_cast<uintptr_t>(rg.out2[i]);
     const bool al16 = (al & 15) == 0;
+    RSide r{slab, rg, total, n1, S, N, accumulate, 0, 0, 0};
     if (S >= 64 && total % 4 == 0 && n1 % 4 == 0 && total <= (1L << 20) && al16) {
-        hipLaunchKernelGGL(splitk_reduce_wide, dim3(ceil_div(total, 16), G), dim3(256), 0, st, slab, rg, total, S, N, bias, act, slope,
-                           accumulate, n1, am);
+        r.kind = 0, r.nbx = (int)ceil_div(total, 16);
     } else if (S >= 8 && total >= reduce_vec_min() && total % 4 == 0 && n1 % 4 == 0 && al16) {
-        hipLaunchKernelGGL(splitk_reduce_vec, dim3((unsigned)ceil_div(total / 4, 256), G), dim3(256), 0, st, slab, rg, total, S, N, bias, act,
-                           slope, accumulate, n1, am);
+        r.kind = 1, r.nbx = (int)ceil_div(total / 4, 256);
     } else if (S >= 8 && total <= (1L << 20)) {
-        hipLaunchKernelGGL(splitk_reduce, dim3(ceil_div(total, 16), G), dim3(256), 0, st, slab, rg, total, S, N, bias, act, slope, accumulate,
-                           n1, am);
+        r.kind = 2, r.nbx = (int)ceil_div(total, 16);
     } else {
         long gq = (total + 255) / 256;
         if (gq > 4096) gq = 4096;
-        hipLaunchKernelGGL(splitk_reduce_flat, dim3((int)gq, G), dim3(256), 0, st, slab, rg, total, S, N, bias, act, slope, accumulate, n1, am);
+        r.kind = 3, r.nbx = (int)gq;
     }
-    MOVAE_CHECK_LAUNCH("splitk_reduce");
-    return MOVAE_OK;
+    r.nblk = r.nbx * G;
+    if (deferrable && g_defer.armed && !bias && act == MOVAE_ACT_NONE && !am.y && !am.res &&
+        (size_t)total * S * G * sizeof(float) <= defer_max_bytes()) {
+        if (int rc = defer_flush()) return rc;  // (one slot)
+        g_defer.r = r, g_defer.st = st, g_defer.pending = true;
+        ++g_defer.serial;
+        ++g_defer_stats[0];
+        return MOVAE_OK;
+    }
+    return reduce_launch(r, bias, act, slope, am, st);
 }
 
 inline int launch_reduce(const float* slab, float* out, long n1, int S, int N, const float* bias, int act, float slope,
@@ -1336,6 +1455,27 @@ extern "C" {
 
 const char* movae_bench_last_kernel(void) { return g_last_kernel; }
 
+int movae_reduce_defer(int on) {
+    const int prev = g_defer.armed ? 1 : 0;
+    g_defer.armed = on != 0;
+    return prev;
+}
+
+int movae_reduce_flush(void) { return defer_flush(); }
+
+long long movae_reduce_defer_max_bytes(long long bytes) {
+    const long long prev = (long long)g_defer_max_bytes;
+    if (bytes >= 0) g_defer_max_bytes = (size_t)bytes;
+    return prev;
+}
+
+int movae_reduce_defer_stats(long long* out3, int reset) {
+    if (out3)
+        for (int i = 0; i < 3; ++i) out3[i] = g_defer_stats[i];
+    if (reset) g_defer_stats[0] = g_defer_stats[1] = g_defer_stats[2] = 0;
+    return g_defer.pending ? 1 : 0;
+}
+
 int movae_bench_force_split(int s) {
     const int prev = g_force_split;
     g_force_split = s > 0 ? s : 0;
@@ -1402,6 +1542,7 @@ int movae_conv2d_dgrad_f(const float* dy, const float* w, float* dx, int n, int 
 int movae_conv2d_wgrad_grouped_f(int groups, const float* dy, const float* x, float* const* dw, float* const* dbias, int n, int hi,
                                int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad, int accumulate,
                                void* ws, size_t ws_bytes, movae_stream_t stream, const movae_fuse_t* fuse) {
+    DeferArmScope defer_scope;  // (movae_reduce_defer arms ONE weight-gradient call)
     MOVAE_CHECK_FUSE(fuse, ci);
     FuseScope scope(const_cast<movae_fuse_t*>(fuse), 2);
     void* ws_full = ws;
@@ -1414,6 +1555,8 @@ int movae_conv2d_wgrad_grouped_f(int groups, const float* dy, const float* x, fl
     const long dy_gs = (long)n * ho * wo * co;  // dy is stacked [groups][n][ho][wo][co]; x is shared
     bool bias_done = false;
     if (int rc = launch_wgrad(dy, x, dw, groups, dy_gs, 0, g, accumulate, ws, ws_bytes, (hipStream_t)stream, dbias, &bias_done)) return rc;
+    if (dbias && !bias_done && !g_bench_main_only && g_defer.pending && g_defer.serial != defer_scope.serial)
+        if (int rc = defer_flush()) return rc;  // the column sums below use the arena the parked reduce's slabs lie in
     if (dbias && !bias_done && !g_bench_main_only)
         for (int i = 0; i < groups; ++i)
             if (dbias[i])
@@ -1477,6 +1620,7 @@ int movae_convT2d_dgrad_f(const float* dy, const float* w, float* dx, int n, int
 int movae_convT2d_wgrad_grouped_f(int groups, const float* dy, const float* x, float* const* dw, float* const* dbias, int n, int hi,
                                 int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad, int accumulate,
                                 void* ws, size_t ws_bytes, movae_stream_t stream, const movae_fuse_t* fuse) {
+    DeferArmScope defer_scope;  // (movae_reduce_defer arms ONE weight-gradient call)
     MOVAE_CHECK_FUSE(fuse, ci);
     FuseScope scope(const_cast<movae_fuse_t*>(fuse), 1);
     void* ws_full = ws;
@@ -1488,6 +1632,8 @@ int movae_convT2d_wgrad_grouped_f(int groups, const float* dy, const float* x, f
     WGeom g{n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad};
     const long dy_gs = (long)n * ho * wo * co;  // the small side (x) is shared, the gathered side (dy) is per group
     if (int rc = launch_wgrad(x, dy, dw, groups, 0, dy_gs, g, accumulate, ws, ws_bytes, (hipStream_t)stream)) return rc;
+    if (dbias && !g_bench_main_only && g_defer.pending && g_defer.serial != defer_scope.serial)
+        if (int rc = defer_flush()) return rc;  // the column sums below use the arena the parked reduce's slabs lie in
     if (dbias && !g_bench_main_only)
         for (int i = 0; i < groups; ++i)
             if (dbias[i])

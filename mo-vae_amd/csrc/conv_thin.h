@@ -1451,10 +1451,14 @@ int launch_thin_wgrad_impl(const float* S, const float* Bg, float* const* dW, in
 #undef MOVAE_SW
 #undef MOVAE_MF
                 MOVAE_CHECK_LAUNCH("thin_wgrad_sweep");
-                for (int i = 0; i < G; ++i)
-                    if (int rc = launch_reduce(slab + i * slab_gs, dW[i], (long)M * N, (int)nblk, N, nullptr, 0, 0.f, accumulate, st,
-                                               cs_on ? colsum[i] : nullptr, M))
+                {  // ONE reduce launch for all groups (blockIdx.y = group); it may wait for a later launch to carry it (RSide)
+                    RGroups rg{};
+                    for (int i = 0; i < G; ++i) rg.out[i] = dW[i], rg.out2[i] = cs_on ? colsum[i] : nullptr;
+                    rg.slab_gs = slab_gs;
+                    if (int rc = launch_reduce_groups(slab, rg, G, (long)M * N, cs_on ? M : 0, (int)nblk, N, nullptr, 0, 0.f, accumulate, st,
+                                                      ActMul{nullptr, 0, 0.f, 0, 0, nullptr}, true))
                         return rc;
+                }
                 if (colsum_done) *colsum_done = cs_on;
                 return MOVAE_OK;
             }

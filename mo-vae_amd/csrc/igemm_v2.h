@@ -545,9 +545,14 @@ __device__ __forceinline__ void igemm2_fwd_body(const FwdArgs& a, float* __restr
 }
 
 template <int BM, int BN, bool BF = false>
-__global__ __launch_bounds__(256) void igemm2_fwd(FwdArgs a) {
+__global__ __launch_bounds__(256) void igemm2_fwd(FwdArgs a, RSide sd, int sz) {
     __shared__ __attribute__((aligned(16))) float smem[FwdSmem<BM, BN>::FLOATS];
-    igemm2_fwd_body<BM, BN, BF>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+    if ((int)blockIdx.z < sz) {  // a parked weight-gradient reduce rides in FRONT of this launch's own blocks (conv_igemm.hip: RSide)
+        const int bid = ((int)blockIdx.z * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
+        if (bid < sd.nblk) side_reduce(sd, bid, smem);
+        return;
+    }
+    igemm2_fwd_body<BM, BN, BF>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z - sz);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -983,9 +988,14 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
 }
 
 template <int BM, int BN, bool BF = false>
-__global__ __launch_bounds__(256) void igemm2_bwd(BwdArgs a) {
+__global__ __launch_bounds__(256) void igemm2_bwd(BwdArgs a, RSide sd, int sz) {
     __shared__ __attribute__((aligned(16))) float smem[BwdSmem<BM, BN>::FLOATS];
-    igemm2_bwd_body<BM, BN, BF>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+    if ((int)blockIdx.z < sz) {  // a parked weight-gradient reduce rides in FRONT of this launch's own blocks (conv_igemm.hip: RSide)
+        const int bid = ((int)blockIdx.z * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
+        if (bid < sd.nblk) side_reduce(sd, bid, smem);
+        return;
+    }
+    igemm2_bwd_body<BM, BN, BF>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z - sz);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1285,9 +1295,14 @@ __device__ __forceinline__ void igemm2_wgrad_body(const WgArgs& a, float* __rest
 }
 
 template <int BM, int BN, bool BF = false>
-__global__ __launch_bounds__(256) void igemm2_wgrad(WgArgs a) {
+__global__ __launch_bounds__(256) void igemm2_wgrad(WgArgs a, RSide sd, int sz) {
     __shared__ __attribute__((aligned(16))) float smem[WgSmem<BM, BN>::FLOATS];
-    igemm2_wgrad_body<BM, BN, BF>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+    if ((int)blockIdx.z < sz) {  // a parked weight-gradient reduce rides in FRONT of this launch's own blocks (conv_igemm.hip: RSide)
+        const int bid = ((int)blockIdx.z * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
+        if (bid < sd.nblk) side_reduce(sd, bid, smem);
+        return;
+    }
+    igemm2_wgrad_body<BM, BN, BF>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z - sz);
 }
 
 // ---- one launch, two problems: the input gradient (FWD or BWD gather form) and the weight gradient of one layer ----------
@@ -1297,11 +1312,16 @@ __global__ __launch_bounds__(256) void igemm2_wgrad(WgArgs a) {
 // of the two bodies' needs.
 template <int FORM, int ABM, int ABN, int WBM, int WBN>
 __global__ __launch_bounds__(256) void igemm2_pair(FwdArgs fa, BwdArgs ba, WgArgs wa, int nd, int dgx, int dgy, int wgx, int wgy,
-                                                   int nw, int inter) {
+                                                   int nw, int inter, RSide sd) {
     constexpr int DF = FORM == 0 ? FwdSmem<ABM, ABN>::FLOATS : BwdSmem<ABM, ABN>::FLOATS;
     constexpr int WF = WgSmem<WBM, WBN>::FLOATS;
     __shared__ __attribute__((aligned(16))) float smem[DF > WF ? DF : WF];
     int b = blockIdx.x;
+    if (b < sd.nblk) {  // ... and, in front of the two, the previous layer's parked weight-gradient reduce (conv_igemm.hip: RSide)
+        side_reduce(sd, b, smem);
+        return;
+    }
+    b -= sd.nblk;
     if (inter == 2) {  // weight-gradient blocks first
         b = b < nw ? nd + b : b - nw;
     } else if (inter) {  // alternate the two problems' blocks while both last (the dispatcher hands out blocks in index order)
@@ -1400,13 +1420,15 @@ inline int flush_pending(hipStream_t st) {  // launch the stashed dgrad on its o
     PendingDgrad& p = g_pending;
     if (!p.active) return MOVAE_OK;
     p.active = false;
-    const dim3 grid(p.gx, p.gy, p.gz);
+    dim3 grid(p.gx, p.gy, p.gz);
+    int sz;
+    const RSide sd = defer_take_3d(st, &grid, &sz);
     if (p.form == 0) {
-        if (p.bm == 64) hipLaunchKernelGGL((igemm2_fwd<64, 64>), grid, dim3(256), 0, st, p.fa);
-        else hipLaunchKernelGGL((igemm2_fwd<128, 32>), grid, dim3(256), 0, st, p.fa);
+        if (p.bm == 64) hipLaunchKernelGGL((igemm2_fwd<64, 64>), grid, dim3(256), 0, st, p.fa, sd, sz);
+        else hipLaunchKernelGGL((igemm2_fwd<128, 32>), grid, dim3(256), 0, st, p.fa, sd, sz);
     } else {
-        if (p.bm == 64) hipLaunchKernelGGL((igemm2_bwd<64, 64>), grid, dim3(256), 0, st, p.ba);
-        else hipLaunchKernelGGL((igemm2_bwd<128, 32>), grid, dim3(256), 0, st, p.ba);
+        if (p.bm == 64) hipLaunchKernelGGL((igemm2_bwd<64, 64>), grid, dim3(256), 0, st, p.ba, sd, sz);
+        else hipLaunchKernelGGL((igemm2_bwd<128, 32>), grid, dim3(256), 0, st, p.ba, sd, sz);
     }
     MOVAE_CHECK_LAUNCH("igemm2 dgrad (unpaired)");
     return finish_pending(st);
@@ -1471,8 +1493,11 @@ int launch_fwd2(const float* X, const float* W, float* Y, const Geom& g, const E
         p.ws_used = S > 1 ? (size_t)M * g.Nn * sizeof(float) * S : 0;
         return MOVAE_OK;
     }
-    if (BM == 128 && BN == 128 && g_compute_bf16) hipLaunchKernelGGL((igemm2_fwd<BM, BN, BM == 128 && BN == 128>), dim3(gx, gy, S), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((igemm2_fwd<BM, BN>), dim3(gx, gy, S), dim3(256), 0, st, a);
+    dim3 grid(gx, gy, S);
+    int sz;
+    const RSide sd = defer_take_3d(st, &grid, &sz);
+    if (BM == 128 && BN == 128 && g_compute_bf16) hipLaunchKernelGGL((igemm2_fwd<BM, BN, BM == 128 && BN == 128>), grid, dim3(256), 0, st, a, sd, sz);
+    else hipLaunchKernelGGL((igemm2_fwd<BM, BN>), grid, dim3(256), 0, st, a, sd, sz);
     MOVAE_CHECK_LAUNCH("igemm2_fwd");
     if (S > 1) {
         if (rbb.y && !g_bench_main_only) {
@@ -1608,8 +1633,11 @@ int launch_bwd2(const float* X, const float* W, float* Y, const Geom& g, const E
         p.ws_used = Sreal > 1 ? (size_t)total * sizeof(float) * Sreal : 0;
         return MOVAE_OK;
     }
-    if (BM == 128 && BN == 128 && g_compute_bf16) hipLaunchKernelGGL((igemm2_bwd<BM, BN, BM == 128 && BN == 128>), dim3(gx, gy, zsum), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((igemm2_bwd<BM, BN>), dim3(gx, gy, zsum), dim3(256), 0, st, a);
+    dim3 grid(gx, gy, zsum);
+    int sz;
+    const RSide sd = defer_take_3d(st, &grid, &sz);
+    if (BM == 128 && BN == 128 && g_compute_bf16) hipLaunchKernelGGL((igemm2_bwd<BM, BN, BM == 128 && BN == 128>), grid, dim3(256), 0, st, a, sd, sz);
+    else hipLaunchKernelGGL((igemm2_bwd<BM, BN>), grid, dim3(256), 0, st, a, sd, sz);
     MOVAE_CHECK_LAUNCH("igemm2_bwd");
     if (Sreal > 1 && !g_bench_main_only) {
         if (rbb.y) {
@@ -1634,8 +1662,9 @@ template <int FORM, int ABM, int ABN, int WBM, int WBN>
 inline void launch_pair(const PendingDgrad& p, const WgArgs& wa, int wgx, int wgy, int wgz, hipStream_t st) {
     const int nd = p.gx * p.gy * p.gz, nw = wgx * wgy * wgz;
     static const int inter = getenv("MOVAE_PAIR_INTERLEAVE") ? atoi(getenv("MOVAE_PAIR_INTERLEAVE")) : 0;
-    hipLaunchKernelGGL((igemm2_pair<FORM, ABM, ABN, WBM, WBN>), dim3(nd + nw), dim3(256), 0, st, p.fa, p.ba, wa, nd, p.gx, p.gy, wgx,
-                       wgy, nw, inter);
+    const RSide sd = defer_take(st);  // the previous layer's parked weight-gradient reduce rides in front of the two problems
+    hipLaunchKernelGGL((igemm2_pair<FORM, ABM, ABN, WBM, WBN>), dim3(nd + nw + sd.nblk), dim3(256), 0, st, p.fa, p.ba, wa, nd, p.gx, p.gy,
+                       wgx, wgy, nw, inter, sd);
 }
 
 template <int BM, int BN>
@@ -1688,15 +1717,20 @@ int launch_wgrad2(const float* Sm, const float* Bg, float* const* dW, int G, lon
         if (int rc = finish_pending(st)) return rc;
     } else {
         if (int rc = flush_pending(st)) return rc;
-        if (BM == 128 && BN == 128 && g_compute_bf16) hipLaunchKernelGGL((igemm2_wgrad<BM, BN, BM == 128 && BN == 128>), dim3(gx, gy, Sp * G), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((igemm2_wgrad<BM, BN>), dim3(gx, gy, Sp * G), dim3(256), 0, st, a);
+        dim3 grid(gx, gy, Sp * G);
+        int sz;
+        const RSide sd = defer_take_3d(st, &grid, &sz);
+        if (BM == 128 && BN == 128 && g_compute_bf16) hipLaunchKernelGGL((igemm2_wgrad<BM, BN, BM == 128 && BN == 128>), grid, dim3(256), 0, st, a, sd, sz);
+        else hipLaunchKernelGGL((igemm2_wgrad<BM, BN>), grid, dim3(256), 0, st, a, sd, sz);
         MOVAE_CHECK_LAUNCH("igemm2_wgrad");
     }
     if (slab) {  // ONE reduce launch for all groups (blockIdx.y = group)
         RGroups rg{};
         for (int i = 0; i < G; ++i) rg.out[i] = dW[i], rg.out2[i] = colsum ? colsum[i] : nullptr;
         rg.slab_gs = (long)Sp * stride;
-        return launch_reduce_groups(out, rg, G, (long)M * N, colsum ? M : 0, Sp, N, nullptr, 0, 0.f, accumulate, st);
+        // (deferrable: movae_reduce_defer armed this call -- the reduce waits for the next launch that can carry it)
+        return launch_reduce_groups(out, rg, G, (long)M * N, colsum ? M : 0, Sp, N, nullptr, 0, 0.f, accumulate, st,
+                                    ActMul{nullptr, 0, 0.f, 0, 0, nullptr}, true);
     }
     return MOVAE_OK;
 }

@@ -330,9 +330,14 @@ __device__ __forceinline__ void kgemm_body(const KArgs& a, float* __restrict__ s
 }
 
 template <int FORM, int NW, int KS, bool NRM>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void kgemm_k(KArgs a) {
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void kgemm_k(KArgs a, RSide sd, int sz) {
     __shared__ __attribute__((aligned(16))) float smem[smem_floats<NW>()];
-    kgemm_body<FORM, NW, KS, NRM>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+    if (NW == 4 && (int)blockIdx.z < sz) {  // a parked weight-gradient reduce rides in front of this launch's own blocks (conv_igemm.hip: RSide)
+        const int bid = ((int)blockIdx.z * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
+        if (bid < sd.nblk) side_reduce(sd, bid, smem);
+        return;
+    }
+    kgemm_body<FORM, NW, KS, NRM>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z - sz);
 }
 
 // ---- weight gradient: dW[a][tap][b] = sum_p S[p][a] * Bg[p * s - pad + tap][b]   (M = Cs, N = taps * Cb) ------------------------
@@ -549,10 +554,16 @@ inline bool small_problem(long rows, long cols, long k, long copies) {
 
 template <int FORM, bool NRM>
 inline void launch_k2(const KArgs& a, KSplit k, dim3 tiles, hipStream_t st) {  // tiles: (row tiles, column tiles, classes)
-    if (k.ks == 8) hipLaunchKernelGGL((kgemm_k<FORM, 8, 8, NRM>), tiles, dim3(512), 0, st, a);
-    else if (k.ks == 4) hipLaunchKernelGGL((kgemm_k<FORM, 4, 4, NRM>), tiles, dim3(256), 0, st, a);
-    else if (k.ks == 2) hipLaunchKernelGGL((kgemm_k<FORM, 4, 2, NRM>), dim3((tiles.x + 1) / 2, tiles.y, tiles.z), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((kgemm_k<FORM, 4, 1, NRM>), dim3((tiles.x + 3) / 4, tiles.y, tiles.z), dim3(256), 0, st, a);
+    if (k.ks == 8) {
+        hipLaunchKernelGGL((kgemm_k<FORM, 8, 8, NRM>), tiles, dim3(512), 0, st, a, RSide{}, 0);
+        return;
+    }
+    dim3 grid = k.ks == 4 ? tiles : k.ks == 2 ? dim3((tiles.x + 1) / 2, tiles.y, tiles.z) : dim3((tiles.x + 3) / 4, tiles.y, tiles.z);
+    int sz;
+    const RSide sd = defer_take_3d(st, &grid, &sz);
+    if (k.ks == 4) hipLaunchKernelGGL((kgemm_k<FORM, 4, 4, NRM>), grid, dim3(256), 0, st, a, sd, sz);
+    else if (k.ks == 2) hipLaunchKernelGGL((kgemm_k<FORM, 4, 2, NRM>), grid, dim3(256), 0, st, a, sd, sz);
+    else hipLaunchKernelGGL((kgemm_k<FORM, 4, 1, NRM>), grid, dim3(256), 0, st, a, sd, sz);
 }
 template <int FORM>
 inline void launch_k(const KArgs& a, KSplit k, dim3 tiles, hipStream_t st) {
@@ -563,10 +574,15 @@ inline void launch_k(const KArgs& a, KSplit k, dim3 tiles, hipStream_t st) {
 // ---- one launch, two problems (see v2::igemm2_pair): blocks [0, nd) run a stashed kgemm input gradient (four waves, KS = 4),
 // the rest the tiled weight gradient of the same layer.  The two share read-only operands only.
 template <int FORM, int WBM, int WBN>
-__global__ __launch_bounds__(256) void kpair_k(KArgs ka, v2::WgArgs wa, int nd, int dgx, int dgy, int wgx, int wgy) {
+__global__ __launch_bounds__(256) void kpair_k(KArgs ka, v2::WgArgs wa, int nd, int dgx, int dgy, int wgx, int wgy, int nw, RSide sd) {
     constexpr int DF = smem_floats<4>(), WF = v2::WgSmem<WBM, WBN>::FLOATS;
     __shared__ __attribute__((aligned(16))) float smem[DF > WF ? DF : WF];
     int b = blockIdx.x;
+    if (b < sd.nblk) {  // in front: the previous layer's parked weight-gradient reduce (conv_igemm.hip: RSide)
+        side_reduce(sd, b, smem);
+        return;
+    }
+    b -= sd.nblk;
     if (b < nd) {
         const int bx = b % dgx, r = b / dgx;
         kgemm_body<FORM, 4, 4, false>(ka, smem, bx, r % dgy, r / dgy);
@@ -601,8 +617,9 @@ inline int kpend_pair(const v2::WgArgs& wa, int wgx, int wgy, int wgz, bool w64,
     KPending& p = g_kpend;
     p.active = false;
     const int nd = p.tiles.x * p.tiles.y * p.tiles.z, nw = wgx * wgy * wgz;
-    const dim3 grid(nd + nw);
-#define MOVAE_KP(F_, BM_, BN_) hipLaunchKernelGGL((kpair_k<F_, BM_, BN_>), grid, dim3(256), 0, st, p.a, wa, nd, (int)p.tiles.x, (int)p.tiles.y, wgx, wgy)
+    const RSide sd = defer_take(st);  // the previous layer's parked weight-gradient reduce rides in front of the two problems
+    const dim3 grid(nd + nw + sd.nblk);
+#define MOVAE_KP(F_, BM_, BN_) hipLaunchKernelGGL((kpair_k<F_, BM_, BN_>), grid, dim3(256), 0, st, p.a, wa, nd, (int)p.tiles.x, (int)p.tiles.y, wgx, wgy, nw, sd)
     if (p.form == 0 && w64) {
         MOVAE_KP(0, 64, 64);
         g_last_kernel = "kpair_k<0,64,64>";

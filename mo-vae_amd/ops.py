@@ -6,6 +6,7 @@ are the reference's parameter shapes ([Co,Ci,kh,kw] / [Ci,Co,kh,kw]) held in cha
 so that `w.permute(0,2,3,1)` is the contiguous [.,kh,kw,.] image the kernels read.
 """
 import ctypes as C
+import os
 import weakref
 
 import torch
@@ -299,6 +300,46 @@ def join_wgrad():
     """Make the compute stream wait for every deferred weight gradient (no-op outside wgrad_side_stream)."""
     if L.DEFER is not None:
         L.DEFER.join()
+
+
+#: MOVAE_DEFER_REDUCE=0: every weight-gradient reduce is a launch of its own (A/B knob)
+DEFER_REDUCE = os.environ.get("MOVAE_DEFER_REDUCE", "1") != "0"
+
+
+class deferred_reduces:
+    """Inside this block a convolution's weight-gradient split-K reduce whose destinations are gradient SINKS (a Jacobian row, an
+    in-place accumulation target: autojac registers them, and reads them only through this library's aggregation / optimizer
+    entry points) is not launched on the spot: the library parks it and the next implicit-GEMM launch of the backward carries it
+    as extra blocks (include/movae.h: movae_reduce_defer).  The block's exit -- and every library call that
+    is not one of the backward's own ops (_lib.DEFER_PASS) -- launches a reduce that is still parked; code that hands a weight
+    gradient to anything else (torch arithmetic, a collective) inside the block calls flush_deferred() first."""
+
+    def __init__(self, enabled=True):
+        self.enabled = enabled and DEFER_REDUCE and L.DEFER is None
+        self.prev = False
+
+    def __enter__(self):
+        if self.enabled:
+            self.prev, L.DEFER_ON[0] = L.DEFER_ON[0], True
+        return self
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            L.DEFER_ON[0] = self.prev
+            if not self.prev:
+                L.defer_flush()
+        return False
+
+
+def flush_deferred():
+    L.defer_flush()
+
+
+def _defer_ws(t, sunk):
+    """(ws pointer, bytes) for a weight-gradient call: armed for a deferred reduce when every destination is a sink."""
+    if sunk and L.DEFER_ON[0] and L.DEFER is None:
+        return L.defer_arm(t.device)
+    return None
 
 
 class ActLink:
@@ -634,6 +675,7 @@ class Conv(Function):
             plain_bias = ctx.has_bias and ctx.needs_input_grad[2] and db_done is None and not ctx.bias_grad_is_zero
             acc_w, acc_b = _accum_targets(w, b, plain_bias) if (db_done is None and not (ctx.has_bias and ctx.bias_grad_is_zero)) else (None, None)
             acc = 1 if acc_w is not None else 0
+            nlog = len(SINK_LOG)
             dwm = acc_w.view(wm_shape) if acc else _sink(w, wm_shape)
             db_k = None
             if db_done is not None:
@@ -646,6 +688,10 @@ class Conv(Function):
                 else:
                     db = db_k = (acc_b if acc else _sink(b, (co,)))
             dbp = (C.c_void_p * 1)(db_k.data_ptr()) if db_k is not None else None
+            # every destination a sink (or an in-place accumulation target): the split-K reduce may ride on a later launch
+            armed = _defer_ws(dy, not fork and (acc or len(SINK_LOG) - nlog == 1 + (db_k is not None)))
+            if armed is not None:
+                wsp, wsb = armed
             tail = (n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, acc, wsp, wsb, st)
             if pair:
                 x, f = Conv._wgrad_call(pre + "dgrad_wgrad_grouped", in_norm, ctx.geom,
@@ -720,6 +766,7 @@ class Conv(Function):
             wsp, wsb, st = ws2.data_ptr(), ws2.numel(), side.cuda_stream
         if need_w:
             wm_shape = (ci, kh, kw, co) if ctx.transposed else (co, kh, kw, ci)
+            nlog = len(SINK_LOG)
             dwm = [_sink_row(g, w, wm_shape) for g in range(G)]
             arr = C.c_void_p * G
             if db_done is not None:
@@ -729,6 +776,10 @@ class Conv(Function):
                 dbp = arr(*[t.data_ptr() for t in db]) if (need_b and not ctx.bias_grad_is_zero) else None
             # one grouped launch: blockIdx.z = group * splits + split, x is read by every group, dy by its own; with the
             # input gradient wanted too, dgrad and wgrad share the launch (igemm2_pair)
+            # every destination a Jacobian row: the split-K reduce may ride on a later launch (deferred_reduces)
+            armed = _defer_ws(dy, defer is None and len(SINK_LOG) - nlog == G * (1 + (dbp is not None)))
+            if armed is not None:
+                wsp, wsb = armed
             tail = (n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, 0, wsp, wsb, st)
             if pair:
                 x, f = Conv._wgrad_call(pre + "dgrad_wgrad_grouped", in_norm, ctx.geom,
@@ -1467,7 +1518,8 @@ class CombineLosses(Function):
         out = torch.empty(K + 1, dtype=torch.float32, device=inputs[0].device)
         row, it_dev, steps, training = anneal if anneal is not None else (-1, None, 1.0, False)
         fac = torch.empty(1, dtype=torch.float32, device=out.device) if it_dev is not None else None
-        _call("movae_combine_losses_fwd", T, C.addressof(ptrs), K, C.addressof(flat), it_dev.data_ptr() if it_dev is not None else 0,
+        # (the host arrays are passed as ctypes objects, not addresses: a recorded call -- bench.py's replay -- keeps them alive)
+        _call("movae_combine_losses_fwd", T, ptrs, K, flat, it_dev.data_ptr() if it_dev is not None else 0,
               float(steps), int(row), int(bool(training)), out.data_ptr(), fac.data_ptr() if fac is not None else 0, _st(out))
         ctx.coef, ctx.sizes, ctx.row, ctx.fac, ctx.flat = coef, sizes, int(row), fac, flat
         ctx.shapes = [t.shape for t in inputs]
@@ -1482,7 +1534,7 @@ class CombineLosses(Function):
         dev = next(x for x in g if x is not None).device
         gp = (C.c_void_p * (K + 1))(*[0 if x is None else x.data_ptr() for x in g])
         gterms = torch.empty(T, dtype=torch.float32, device=dev)
-        _call("movae_combine_losses_bwd", T, K, C.addressof(gp), C.addressof(ctx.flat),
+        _call("movae_combine_losses_bwd", T, K, gp, ctx.flat,
               ctx.fac.data_ptr() if ctx.fac is not None else 0, ctx.row, gterms.data_ptr(), _st(gterms))
         reached = [any(ctx.coef[k][t] != 0 and (g[k] is not None or g[K] is not None) for k in range(K)) for t in range(T)]
         grads, off = [], 0
