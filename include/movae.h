@@ -161,6 +161,11 @@ int movae_recon_loss_fwd(const float* recons, const float* inputs, float* out, s
 /* drecons = (*gscale_dev) * scale * d(mean loss)/d(recons) ; gscale_dev may be NULL (=1) */
 int movae_recon_loss_bwd(const float* recons, const float* inputs, const float* gscale_dev, float* drecons,
                          size_t n, int kind, float scale, movae_stream_t stream);
+/* The same, times act'(pre) for recons = act(pre) -- the decoder's output activation, whose derivative is a function of its output
+ * (MOVAE_ACT_*): dpre is the gradient w.r.t. the PRE-activation values, so the producing convolution's backward needs no
+ * activation-backward pass (ops.ActLink). */
+int movae_recon_loss_bwd_act(const float* recons, const float* inputs, const float* gscale_dev, float* dpre, size_t n, int kind,
+                             float scale, int act, float slope, movae_stream_t stream);
 /* kl: utils/objectives.py:141-144, out[0] = scale * mean_b(-0.5 sum_d(1 + lv - mu^2 - e^lv)) */
 int movae_kl_fwd(const float* mu, const float* log_var, float* out, int b, int d, float scale,
                  void* ws, size_t ws_bytes, movae_stream_t stream);
@@ -288,8 +293,10 @@ int movae_adam_step(float* p, const float* g, float* m, float* v, size_t n, floa
 /* the same update for a LIST of tensors in one launch per 64 tensors (torch.optim.Adam(foreach) semantics:
  * main.py:1169-1178 builds it, main.py:214 steps it).  p/g/m/v/numel are HOST arrays of n_tensors device
  * pointers / element counts.  hyper_dev == NULL: `step` (>= 1) is the step count and lr the learning rate.
- * hyper_dev != NULL: device float[2] = {step counter, lr}; the call first increments the counter on `stream`,
- * then uses the device values (`step` and `lr` arguments are ignored) -- the form a captured hipGraph replays. */
+ * hyper_dev != NULL: device float[2] = {steps made so far, lr}; the update is made for step counter + 1 with the device lr
+ * (`step` and `lr` arguments are ignored) and the counter is advanced inside the same launch, by the block that finishes last
+ * -- the form a captured hipGraph replays.  (One such call at a time per process: the kernel keeps its arrival count in a
+ * device global.) */
 int movae_adam_multi(int n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v,
                      const size_t* numel, float lr, float beta1, float beta2, float eps, float weight_decay,
                      int decoupled_wd, int step, float* hyper_dev, movae_stream_t stream);
@@ -324,7 +331,7 @@ int movae_reduce_defer(int on);
 int movae_reduce_flush(void);
 int movae_reduce_defer_stats(long long* out3, int reset);
 /* Only reduces whose slabs hold at most this many bytes are parked (a parked reduce runs with its carrier's occupancy: right for a
- * launch-bound reduce, wrong for a bandwidth-bound one).  Default 2 MiB (MOVAE_DEFER_MAX_BYTES); bytes < 0 only reads.  Returns the
+ * launch-bound reduce, wrong for a bandwidth-bound one).  Default 12 MiB (MOVAE_DEFER_MAX_BYTES; measured: C2 0.841 -> 0.816 ms, C4 4.49 -> 4.44, larger slabs cost their carrier more than the launch saves); bytes < 0 only reads.  Returns the
  * previous value. */
 long long movae_reduce_defer_max_bytes(long long bytes);
 

@@ -66,6 +66,7 @@ SIGNATURES = {
     "movae_reduce_ws_bytes": ([_z], _z),
     "movae_recon_loss_fwd": ([_p, _p, _p, _z, _i, _f, _p, _z, _p], _i),
     "movae_recon_loss_bwd": ([_p, _p, _p, _p, _z, _i, _f, _p], _i),
+    "movae_recon_loss_bwd_act": ([_p, _p, _p, _p, _z, _i, _f, _i, _f, _p], _i),
     "movae_kl_fwd": ([_p, _p, _p, _i, _i, _f, _p, _z, _p], _i),
     "movae_combine_losses_fwd": ([_i, _p, _i, _p, _p, _f, _i, _i, _p, _p, _p], _i),
     "movae_combine_losses_bwd": ([_i, _i, _p, _p, _p, _i, _p, _p], _i),
@@ -209,7 +210,7 @@ DEFER_PASS = frozenset(
                                                        "dgrad_wgrad_grouped_f")] +
     ["movae_bn_bwd_finalize", "movae_bn_bwd_apply", "movae_bn_bwd_finalize_apply", "movae_bn_act_bwd", "movae_bn_act_bwd_grouped",
      "movae_act_bwd", "movae_act_bwd_bias_grouped", "movae_colsum", "movae_add", "movae_axpby", "movae_copy_channels", "movae_mul",
-     "movae_nchw_to_nhwc", "movae_nhwc_to_nchw", "movae_reparam_bwd", "movae_kl_bwd", "movae_recon_loss_bwd", "movae_tc_decomp_bwd",
+     "movae_nchw_to_nhwc", "movae_nhwc_to_nchw", "movae_reparam_bwd", "movae_kl_bwd", "movae_recon_loss_bwd", "movae_recon_loss_bwd_act", "movae_tc_decomp_bwd",
      "movae_combine_losses_bwd", "movae_vq_bwd", "movae_linear_pair_bwd", "movae_edge_weighted_mse_bwd", "movae_edge_match_bwd",
      "movae_gated_residual_bwd"])
 _defer_arena = [0]

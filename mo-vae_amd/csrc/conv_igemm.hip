@@ -939,23 +939,22 @@ inline RSide defer_take(hipStream_t st) {
     return g_defer.r;
 }
 
-// a 3-D launch takes the parked reduce as whole extra z layers in FRONT of its own (*sz = those layers, g.z grows): blocks are
-// dispatched in index order, so the reduce's short blocks run beside the launch's first wave instead of after its last one.
-// The hardware's z limit can refuse (a reduce of many blocks in front of a one-tile layer): the reduce stays parked then
-inline RSide defer_take_3d(hipStream_t st, dim3* g, int* sz) {
-    *sz = 0;
+// a 3-D launch takes the parked reduce as whole extra z layers BEHIND its own (*gz = the main problem's z extent, g.z grows).
+// (In front -- the reduce's blocks dispatched first -- measured worse: C2 0.871 vs 0.823 ms, C4 4.72 vs 4.49.)  The hardware's z
+// limit can refuse (a reduce of many blocks behind a one-tile layer): the reduce stays parked then
+inline RSide defer_take_3d(hipStream_t st, dim3* g, int* gz) {
+    *gz = (int)g->z;
     RSide none{};
     if (!g_defer.pending || g_defer.st != st || g_bench_main_only) return none;
     const long layers = ((long)g_defer.r.nblk + (long)g->x * g->y - 1) / ((long)g->x * g->y);
     if ((long)g->z + layers > 65535) return none;
     g->z += (unsigned)layers;
-    *sz = (int)layers;
     return defer_take(st);
 }
 
 // a parked reduce is a few blocks' work in a launch built for something else (its occupancy, not the reduce's): only reduces that
 // are launch-bound on their own are parked -- slabs of at most this many bytes (33 MB of slabs behind a 185 us kernel cost it 49 us)
-static size_t g_defer_max_bytes = getenv("MOVAE_DEFER_MAX_BYTES") ? (size_t)atol(getenv("MOVAE_DEFER_MAX_BYTES")) : (size_t)(2u << 20);
+static size_t g_defer_max_bytes = getenv("MOVAE_DEFER_MAX_BYTES") ? (size_t)atol(getenv("MOVAE_DEFER_MAX_BYTES")) : (size_t)(12u << 20);
 inline size_t defer_max_bytes() { return g_defer_max_bytes; }
 
 inline int launch_reduce_groups(const float* slab, const RGroups& rg, int G, long n1, long n2, int S, int N, const float* bias, int act,

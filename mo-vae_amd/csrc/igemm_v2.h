@@ -545,14 +545,14 @@ __device__ __forceinline__ void igemm2_fwd_body(const FwdArgs& a, float* __restr
 }
 
 template <int BM, int BN, bool BF = false>
-__global__ __launch_bounds__(256) void igemm2_fwd(FwdArgs a, RSide sd, int sz) {
+__global__ __launch_bounds__(256) void igemm2_fwd(FwdArgs a, RSide sd, int gz) {
     __shared__ __attribute__((aligned(16))) float smem[FwdSmem<BM, BN>::FLOATS];
-    if ((int)blockIdx.z < sz) {  // a parked weight-gradient reduce rides in FRONT of this launch's own blocks (conv_igemm.hip: RSide)
-        const int bid = ((int)blockIdx.z * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
+    if ((int)blockIdx.z >= gz) {  // a parked weight-gradient reduce rides BEHIND this launch's own blocks (conv_igemm.hip: RSide)
+        const int bid = (((int)blockIdx.z - gz) * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
         if (bid < sd.nblk) side_reduce(sd, bid, smem);
         return;
     }
-    igemm2_fwd_body<BM, BN, BF>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z - sz);
+    igemm2_fwd_body<BM, BN, BF>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -988,14 +988,14 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
 }
 
 template <int BM, int BN, bool BF = false>
-__global__ __launch_bounds__(256) void igemm2_bwd(BwdArgs a, RSide sd, int sz) {
+__global__ __launch_bounds__(256) void igemm2_bwd(BwdArgs a, RSide sd, int gz) {
     __shared__ __attribute__((aligned(16))) float smem[BwdSmem<BM, BN>::FLOATS];
-    if ((int)blockIdx.z < sz) {  // a parked weight-gradient reduce rides in FRONT of this launch's own blocks (conv_igemm.hip: RSide)
-        const int bid = ((int)blockIdx.z * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
+    if ((int)blockIdx.z >= gz) {  // a parked weight-gradient reduce rides BEHIND this launch's own blocks (conv_igemm.hip: RSide)
+        const int bid = (((int)blockIdx.z - gz) * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
         if (bid < sd.nblk) side_reduce(sd, bid, smem);
         return;
     }
-    igemm2_bwd_body<BM, BN, BF>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z - sz);
+    igemm2_bwd_body<BM, BN, BF>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1295,14 +1295,14 @@ __device__ __forceinline__ void igemm2_wgrad_body(const WgArgs& a, float* __rest
 }
 
 template <int BM, int BN, bool BF = false>
-__global__ __launch_bounds__(256) void igemm2_wgrad(WgArgs a, RSide sd, int sz) {
+__global__ __launch_bounds__(256) void igemm2_wgrad(WgArgs a, RSide sd, int gz) {
     __shared__ __attribute__((aligned(16))) float smem[WgSmem<BM, BN>::FLOATS];
-    if ((int)blockIdx.z < sz) {  // a parked weight-gradient reduce rides in FRONT of this launch's own blocks (conv_igemm.hip: RSide)
-        const int bid = ((int)blockIdx.z * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
+    if ((int)blockIdx.z >= gz) {  // a parked weight-gradient reduce rides BEHIND this launch's own blocks (conv_igemm.hip: RSide)
+        const int bid = (((int)blockIdx.z - gz) * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
         if (bid < sd.nblk) side_reduce(sd, bid, smem);
         return;
     }
-    igemm2_wgrad_body<BM, BN, BF>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z - sz);
+    igemm2_wgrad_body<BM, BN, BF>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // ---- one launch, two problems: the input gradient (FWD or BWD gather form) and the weight gradient of one layer ----------
@@ -1317,11 +1317,10 @@ __global__ __launch_bounds__(256) void igemm2_pair(FwdArgs fa, BwdArgs ba, WgArg
     constexpr int WF = WgSmem<WBM, WBN>::FLOATS;
     __shared__ __attribute__((aligned(16))) float smem[DF > WF ? DF : WF];
     int b = blockIdx.x;
-    if (b < sd.nblk) {  // ... and, in front of the two, the previous layer's parked weight-gradient reduce (conv_igemm.hip: RSide)
-        side_reduce(sd, b, smem);
+    if (b >= nd + nw) {  // ... and, behind the two, the previous layer's parked weight-gradient reduce (conv_igemm.hip: RSide)
+        side_reduce(sd, b - nd - nw, smem);
         return;
     }
-    b -= sd.nblk;
     if (inter == 2) {  // weight-gradient blocks first
         b = b < nw ? nd + b : b - nw;
     } else if (inter) {  // alternate the two problems' blocks while both last (the dispatcher hands out blocks in index order)
@@ -1421,14 +1420,14 @@ inline int flush_pending(hipStream_t st) {  // launch the stashed dgrad on its o
     if (!p.active) return MOVAE_OK;
     p.active = false;
     dim3 grid(p.gx, p.gy, p.gz);
-    int sz;
-    const RSide sd = defer_take_3d(st, &grid, &sz);
+    int gz;
+    const RSide sd = defer_take_3d(st, &grid, &gz);
     if (p.form == 0) {
-        if (p.bm == 64) hipLaunchKernelGGL((igemm2_fwd<64, 64>), grid, dim3(256), 0, st, p.fa, sd, sz);
-        else hipLaunchKernelGGL((igemm2_fwd<128, 32>), grid, dim3(256), 0, st, p.fa, sd, sz);
+        if (p.bm == 64) hipLaunchKernelGGL((igemm2_fwd<64, 64>), grid, dim3(256), 0, st, p.fa, sd, gz);
+        else hipLaunchKernelGGL((igemm2_fwd<128, 32>), grid, dim3(256), 0, st, p.fa, sd, gz);
     } else {
-        if (p.bm == 64) hipLaunchKernelGGL((igemm2_bwd<64, 64>), grid, dim3(256), 0, st, p.ba, sd, sz);
-        else hipLaunchKernelGGL((igemm2_bwd<128, 32>), grid, dim3(256), 0, st, p.ba, sd, sz);
+        if (p.bm == 64) hipLaunchKernelGGL((igemm2_bwd<64, 64>), grid, dim3(256), 0, st, p.ba, sd, gz);
+        else hipLaunchKernelGGL((igemm2_bwd<128, 32>), grid, dim3(256), 0, st, p.ba, sd, gz);
     }
     MOVAE_CHECK_LAUNCH("igemm2 dgrad (unpaired)");
     return finish_pending(st);
@@ -1494,10 +1493,10 @@ int launch_fwd2(const float* X, const float* W, float* Y, const Geom& g, const E
         return MOVAE_OK;
     }
     dim3 grid(gx, gy, S);
-    int sz;
-    const RSide sd = defer_take_3d(st, &grid, &sz);
-    if (BM == 128 && BN == 128 && g_compute_bf16) hipLaunchKernelGGL((igemm2_fwd<BM, BN, BM == 128 && BN == 128>), grid, dim3(256), 0, st, a, sd, sz);
-    else hipLaunchKernelGGL((igemm2_fwd<BM, BN>), grid, dim3(256), 0, st, a, sd, sz);
+    int gz;
+    const RSide sd = defer_take_3d(st, &grid, &gz);
+    if (BM == 128 && BN == 128 && g_compute_bf16) hipLaunchKernelGGL((igemm2_fwd<BM, BN, BM == 128 && BN == 128>), grid, dim3(256), 0, st, a, sd, gz);
+    else hipLaunchKernelGGL((igemm2_fwd<BM, BN>), grid, dim3(256), 0, st, a, sd, gz);
     MOVAE_CHECK_LAUNCH("igemm2_fwd");
     if (S > 1) {
         if (rbb.y && !g_bench_main_only) {
@@ -1634,10 +1633,10 @@ int launch_bwd2(const float* X, const float* W, float* Y, const Geom& g, const E
         return MOVAE_OK;
     }
     dim3 grid(gx, gy, zsum);
-    int sz;
-    const RSide sd = defer_take_3d(st, &grid, &sz);
-    if (BM == 128 && BN == 128 && g_compute_bf16) hipLaunchKernelGGL((igemm2_bwd<BM, BN, BM == 128 && BN == 128>), grid, dim3(256), 0, st, a, sd, sz);
-    else hipLaunchKernelGGL((igemm2_bwd<BM, BN>), grid, dim3(256), 0, st, a, sd, sz);
+    int gz;
+    const RSide sd = defer_take_3d(st, &grid, &gz);
+    if (BM == 128 && BN == 128 && g_compute_bf16) hipLaunchKernelGGL((igemm2_bwd<BM, BN, BM == 128 && BN == 128>), grid, dim3(256), 0, st, a, sd, gz);
+    else hipLaunchKernelGGL((igemm2_bwd<BM, BN>), grid, dim3(256), 0, st, a, sd, gz);
     MOVAE_CHECK_LAUNCH("igemm2_bwd");
     if (Sreal > 1 && !g_bench_main_only) {
         if (rbb.y) {
@@ -1662,7 +1661,7 @@ template <int FORM, int ABM, int ABN, int WBM, int WBN>
 inline void launch_pair(const PendingDgrad& p, const WgArgs& wa, int wgx, int wgy, int wgz, hipStream_t st) {
     const int nd = p.gx * p.gy * p.gz, nw = wgx * wgy * wgz;
     static const int inter = getenv("MOVAE_PAIR_INTERLEAVE") ? atoi(getenv("MOVAE_PAIR_INTERLEAVE")) : 0;
-    const RSide sd = defer_take(st);  // the previous layer's parked weight-gradient reduce rides in front of the two problems
+    const RSide sd = defer_take(st);  // the previous layer's parked weight-gradient reduce rides behind the two problems
     hipLaunchKernelGGL((igemm2_pair<FORM, ABM, ABN, WBM, WBN>), dim3(nd + nw + sd.nblk), dim3(256), 0, st, p.fa, p.ba, wa, nd, p.gx, p.gy,
                        wgx, wgy, nw, inter, sd);
 }
@@ -1718,10 +1717,10 @@ int launch_wgrad2(const float* Sm, const float* Bg, float* const* dW, int G, lon
     } else {
         if (int rc = flush_pending(st)) return rc;
         dim3 grid(gx, gy, Sp * G);
-        int sz;
-        const RSide sd = defer_take_3d(st, &grid, &sz);
-        if (BM == 128 && BN == 128 && g_compute_bf16) hipLaunchKernelGGL((igemm2_wgrad<BM, BN, BM == 128 && BN == 128>), grid, dim3(256), 0, st, a, sd, sz);
-        else hipLaunchKernelGGL((igemm2_wgrad<BM, BN>), grid, dim3(256), 0, st, a, sd, sz);
+        int gz;
+        const RSide sd = defer_take_3d(st, &grid, &gz);
+        if (BM == 128 && BN == 128 && g_compute_bf16) hipLaunchKernelGGL((igemm2_wgrad<BM, BN, BM == 128 && BN == 128>), grid, dim3(256), 0, st, a, sd, gz);
+        else hipLaunchKernelGGL((igemm2_wgrad<BM, BN>), grid, dim3(256), 0, st, a, sd, gz);
         MOVAE_CHECK_LAUNCH("igemm2_wgrad");
     }
     if (slab) {  // ONE reduce launch for all groups (blockIdx.y = group)

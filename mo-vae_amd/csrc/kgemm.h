@@ -330,14 +330,14 @@ __device__ __forceinline__ void kgemm_body(const KArgs& a, float* __restrict__ s
 }
 
 template <int FORM, int NW, int KS, bool NRM>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void kgemm_k(KArgs a, RSide sd, int sz) {
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void kgemm_k(KArgs a, RSide sd, int gz) {
     __shared__ __attribute__((aligned(16))) float smem[smem_floats<NW>()];
-    if (NW == 4 && (int)blockIdx.z < sz) {  // a parked weight-gradient reduce rides in front of this launch's own blocks (conv_igemm.hip: RSide)
-        const int bid = ((int)blockIdx.z * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
+    if (NW == 4 && (int)blockIdx.z >= gz) {  // a parked weight-gradient reduce rides behind this launch's own blocks (conv_igemm.hip: RSide)
+        const int bid = (((int)blockIdx.z - gz) * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
         if (bid < sd.nblk) side_reduce(sd, bid, smem);
         return;
     }
-    kgemm_body<FORM, NW, KS, NRM>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z - sz);
+    kgemm_body<FORM, NW, KS, NRM>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // ---- weight gradient: dW[a][tap][b] = sum_p S[p][a] * Bg[p * s - pad + tap][b]   (M = Cs, N = taps * Cb) ------------------------
@@ -555,15 +555,15 @@ inline bool small_problem(long rows, long cols, long k, long copies) {
 template <int FORM, bool NRM>
 inline void launch_k2(const KArgs& a, KSplit k, dim3 tiles, hipStream_t st) {  // tiles: (row tiles, column tiles, classes)
     if (k.ks == 8) {
-        hipLaunchKernelGGL((kgemm_k<FORM, 8, 8, NRM>), tiles, dim3(512), 0, st, a, RSide{}, 0);
+        hipLaunchKernelGGL((kgemm_k<FORM, 8, 8, NRM>), tiles, dim3(512), 0, st, a, RSide{}, (int)tiles.z);
         return;
     }
     dim3 grid = k.ks == 4 ? tiles : k.ks == 2 ? dim3((tiles.x + 1) / 2, tiles.y, tiles.z) : dim3((tiles.x + 3) / 4, tiles.y, tiles.z);
-    int sz;
-    const RSide sd = defer_take_3d(st, &grid, &sz);
-    if (k.ks == 4) hipLaunchKernelGGL((kgemm_k<FORM, 4, 4, NRM>), grid, dim3(256), 0, st, a, sd, sz);
-    else if (k.ks == 2) hipLaunchKernelGGL((kgemm_k<FORM, 4, 2, NRM>), grid, dim3(256), 0, st, a, sd, sz);
-    else hipLaunchKernelGGL((kgemm_k<FORM, 4, 1, NRM>), grid, dim3(256), 0, st, a, sd, sz);
+    int gz;
+    const RSide sd = defer_take_3d(st, &grid, &gz);
+    if (k.ks == 4) hipLaunchKernelGGL((kgemm_k<FORM, 4, 4, NRM>), grid, dim3(256), 0, st, a, sd, gz);
+    else if (k.ks == 2) hipLaunchKernelGGL((kgemm_k<FORM, 4, 2, NRM>), grid, dim3(256), 0, st, a, sd, gz);
+    else hipLaunchKernelGGL((kgemm_k<FORM, 4, 1, NRM>), grid, dim3(256), 0, st, a, sd, gz);
 }
 template <int FORM>
 inline void launch_k(const KArgs& a, KSplit k, dim3 tiles, hipStream_t st) {
@@ -578,11 +578,10 @@ __global__ __launch_bounds__(256) void kpair_k(KArgs ka, v2::WgArgs wa, int nd, 
     constexpr int DF = smem_floats<4>(), WF = v2::WgSmem<WBM, WBN>::FLOATS;
     __shared__ __attribute__((aligned(16))) float smem[DF > WF ? DF : WF];
     int b = blockIdx.x;
-    if (b < sd.nblk) {  // in front: the previous layer's parked weight-gradient reduce (conv_igemm.hip: RSide)
-        side_reduce(sd, b, smem);
+    if (b >= nd + nw) {  // behind the two: the previous layer's parked weight-gradient reduce (conv_igemm.hip: RSide)
+        side_reduce(sd, b - nd - nw, smem);
         return;
     }
-    b -= sd.nblk;
     if (b < nd) {
         const int bx = b % dgx, r = b / dgx;
         kgemm_body<FORM, 4, 4, false>(ka, smem, bx, r % dgy, r / dgy);
@@ -617,7 +616,7 @@ inline int kpend_pair(const v2::WgArgs& wa, int wgx, int wgy, int wgz, bool w64,
     KPending& p = g_kpend;
     p.active = false;
     const int nd = p.tiles.x * p.tiles.y * p.tiles.z, nw = wgx * wgy * wgz;
-    const RSide sd = defer_take(st);  // the previous layer's parked weight-gradient reduce rides in front of the two problems
+    const RSide sd = defer_take(st);  // the previous layer's parked weight-gradient reduce rides behind the two problems
     const dim3 grid(nd + nw + sd.nblk);
 #define MOVAE_KP(F_, BM_, BN_) hipLaunchKernelGGL((kpair_k<F_, BM_, BN_>), grid, dim3(256), 0, st, p.a, wa, nd, (int)p.tiles.x, (int)p.tiles.y, wgx, wgy, nw, sd)
     if (p.form == 0 && w64) {

@@ -66,6 +66,27 @@ __global__ __launch_bounds__(256) void final_sum(const double* __restrict__ part
     if (threadIdx.x == 0) out[0] = (float)(s * factor);
 }
 
+// recon_partial on blocks [0, nb1), kl_partial on blocks [nb1, nb1 + nb2): the two partial passes of VAE.loss_function in one
+// launch, each block doing exactly what its stand-alone kernel's block does (same strides, same partials)
+__global__ __launch_bounds__(256) void recon_kl_partial(const float* __restrict__ r, const float* __restrict__ x, long n, int kind,
+                                                        const float* __restrict__ mu, const float* __restrict__ lv, long nk, int nb1,
+                                                        int nb2, double* __restrict__ part) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    if ((int)blockIdx.x < nb1) {
+        const long stride = (long)nb1 * 256;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) s += recon_term(r[i], x[i], kind);
+    } else {
+        const long stride = (long)nb2 * 256;
+        for (long i = (long)((int)blockIdx.x - nb1) * 256 + threadIdx.x; i < nk; i += stride) {
+            const float m = mu[i], l = lv[i];
+            s += 1.f + l - m * m - expf(l);
+        }
+    }
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
 // two loss terms and their sum in one launch: out[0] = f1 * sum(part[0 .. n1)), out[1] = f2 * sum(part[n1 .. n1 + n2)),
 // out[2] = out[0] + out[1] in fp32 (the total_loss of models/vae.py:226: a tensor add of the two fp32 scalars)
 __global__ __launch_bounds__(256) void final_sum2(const double* __restrict__ part, int n1, int n2, double f1, double f2,
@@ -87,6 +108,16 @@ __global__ void recon_bwd_k(const float* __restrict__ r, const float* __restrict
     const float f = factor * (gs ? gs[0] : 1.f);
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dr[i] = f * recon_dterm(r[i], x[i], kind);
+}
+
+// ... times act'(pre) where recons = act(pre) is the output of the decoder's last activation (tanh / sigmoid: the derivative is a
+// function of the output): the gradient leaves this kernel as the PRE-activation gradient, no activation-backward pass
+__global__ void recon_bwd_act_k(const float* __restrict__ r, const float* __restrict__ x, const float* __restrict__ gs,
+                                float* __restrict__ dr, long n, int kind, float factor, int act, float slope) {
+    const float f = factor * (gs ? gs[0] : 1.f);
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        dr[i] = (f * recon_dterm(r[i], x[i], kind)) * act_grad_from_out(r[i], act, slope);
 }
 
 __global__ __launch_bounds__(256) void kl_partial(const float* __restrict__ mu, const float* __restrict__ lv,
@@ -355,6 +386,17 @@ int movae_recon_loss_bwd(const float* recons, const float* inputs, const float* 
     return MOVAE_OK;
 }
 
+int movae_recon_loss_bwd_act(const float* recons, const float* inputs, const float* gscale_dev, float* dpre, size_t n, int kind,
+                             float scale, int act, float slope, movae_stream_t stream) {
+    MOVAE_CHECK_ARG(recons && inputs && dpre && n > 0, "movae_recon_loss_bwd_act: bad argument");
+    MOVAE_CHECK_ARG(kind >= 0 && kind <= 3, "movae_recon_loss_bwd_act: unknown objective %d", kind);
+    MOVAE_CHECK_ARG(act >= MOVAE_ACT_NONE && act <= MOVAE_ACT_SIGMOID, "movae_recon_loss_bwd_act: unknown activation %d", act);
+    hipLaunchKernelGGL(recon_bwd_act_k, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, recons, inputs, gscale_dev, dpre, (long)n,
+                       kind, scale / (float)n, act, slope);
+    MOVAE_CHECK_LAUNCH("recon_bwd_act");
+    return MOVAE_OK;
+}
+
 int movae_kl_fwd(const float* mu, const float* log_var, float* out, int b, int d, float scale, void* ws, size_t ws_bytes,
                  movae_stream_t stream) {
     MOVAE_WS_SCRATCH(ws, ws_bytes);
@@ -370,8 +412,8 @@ int movae_kl_fwd(const float* mu, const float* log_var, float* out, int b, int d
     return MOVAE_OK;
 }
 
-// models/vae.py:211-228 in three launches instead of five: the two partial-sum passes of movae_recon_loss_fwd / movae_kl_fwd and ONE
-// final kernel that also forms total_loss.  out[3] = (reconstruction_loss, kld_loss, total_loss), each value bit-identical to what
+// models/vae.py:211-228 in two launches instead of five: the two partial-sum passes of movae_recon_loss_fwd / movae_kl_fwd as one
+// launch and ONE final kernel that also forms total_loss.  out[3] = (reconstruction_loss, kld_loss, total_loss), each value bit-identical to what
 // the separate entry points + a tensor add give.
 int movae_vae_losses_fwd(const float* recons, const float* inputs, size_t n, int kind, float rec_scale, const float* mu,
                          const float* log_var, int b, int d, float kl_scale, float* out, void* ws, size_t ws_bytes,
@@ -383,10 +425,9 @@ int movae_vae_losses_fwd(const float* recons, const float* inputs, size_t n, int
     MOVAE_CHECK_ARG(ws && ws_bytes >= movae_reduce_ws_bytes(n) + movae_reduce_ws_bytes(nk), "movae_vae_losses_fwd: workspace too small");
     const int nb1 = red_blocks(n), nb2 = red_blocks(nk);
     double* part = static_cast<double*>(ws);
-    hipLaunchKernelGGL(recon_partial, dim3(nb1), dim3(256), 0, (hipStream_t)stream, recons, inputs, part, (long)n, kind);
-    MOVAE_CHECK_LAUNCH("recon_partial");
-    hipLaunchKernelGGL(kl_partial, dim3(nb2), dim3(256), 0, (hipStream_t)stream, mu, log_var, part + nb1, (long)nk);
-    MOVAE_CHECK_LAUNCH("kl_partial");
+    hipLaunchKernelGGL(recon_kl_partial, dim3(nb1 + nb2), dim3(256), 0, (hipStream_t)stream, recons, inputs, (long)n, kind, mu, log_var,
+                       (long)nk, nb1, nb2, part);
+    MOVAE_CHECK_LAUNCH("recon_kl_partial");
     hipLaunchKernelGGL(final_sum2, dim3(1), dim3(256), 0, (hipStream_t)stream, part, nb1, nb2, (double)rec_scale / (double)n,
                        -0.5 * (double)kl_scale / (double)b, out);
     MOVAE_CHECK_LAUNCH("final_sum2");

@@ -54,13 +54,19 @@ __device__ __forceinline__ void adam_one(float& pi, float gi, float& mi, float& 
 // C5 to 256 blocks -- one per CU, 3.4 TB/s -- and launched mostly empty blocks for the small ones).  hyper (optional) = device
 // {step, lr}: the step counter has already been incremented by adam_tick on the same stream, so a captured hipGraph replays with a
 // live counter / learning rate.
+__device__ unsigned g_adam_done = 0;  // blocks of the running adam_multi_k launch that have read the step counter and finished
+
 __global__ __launch_bounds__(256) void adam_multi_k(AdamTable tab, int cnt, float lr, float b1, float b2, float eps, float wd,
-                                                    int decoupled, float bc1, float bc2_sqrt, const float* __restrict__ hyper) {
+                                                    int decoupled, float bc1, float bc2_sqrt, float* __restrict__ hyper, int tick) {
     int t = 0;
     while (t + 1 < cnt && blockIdx.x >= tab.first[t + 1]) ++t;  // (uniform: <= 64 scalar compares)
     const unsigned n = tab.n[t], base = (blockIdx.x - tab.first[t]) * ADAM_BLK;
+    float step_f = 0.f;
     if (hyper) {
-        const double step = (double)hyper[0];
+        // the counter holds the number of steps made so far; this one is step + 1.  It is advanced by the block that finishes LAST
+        // (below) -- every block has read it by then -- instead of by a one-thread launch in front of this one
+        step_f = hyper[0] + 1.f;
+        const double step = (double)step_f;
         lr = hyper[1];
         bc1 = (float)(1.0 - pow((double)b1, step));
         bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, step));
@@ -93,8 +99,7 @@ __global__ __launch_bounds__(256) void adam_multi_k(AdamTable tab, int cnt, floa
             *reinterpret_cast<f32x4*>(m + i) = mv[u];
             *reinterpret_cast<f32x4*>(v + i) = vv[u];
         }
-        return;
-    }
+    } else
     for (unsigned u = 0; u < 4; ++u) {
         const unsigned i = base + u * 1024u + threadIdx.x * 4;
         if (i >= n) break;
@@ -119,9 +124,17 @@ __global__ __launch_bounds__(256) void adam_multi_k(AdamTable tab, int cnt, floa
             }
         }
     }
+    if (hyper) {  // (every path of this kernel falls through to here)
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned done = atomicAdd(&g_adam_done, 1u);
+            if (done == gridDim.x - 1) {
+                g_adam_done = 0;
+                if (tick) hyper[0] = step_f;
+            }
+        }
+    }
 }
-
-__global__ void adam_tick(float* hyper) { hyper[0] += 1.f; }
 
 __global__ __launch_bounds__(256) void sumsq_partial(const float* __restrict__ x, long n, double* __restrict__ part) {
     __shared__ double sh[4];
@@ -207,10 +220,7 @@ int movae_adam_multi(int n_tensors, float* const* p, const float* const* g, floa
     MOVAE_CHECK_ARG(n_tensors >= 0 && (n_tensors == 0 || (p && g && m && v && numel)), "movae_adam_multi: null table");
     MOVAE_CHECK_ARG(hyper_dev || step >= 1, "movae_adam_multi: step must be >= 1 when no device counter is given");
     float bc1 = 1.f, bc2_sqrt = 1.f;
-    if (hyper_dev) {
-        hipLaunchKernelGGL(adam_tick, dim3(1), dim3(1), 0, (hipStream_t)stream, hyper_dev);
-        MOVAE_CHECK_LAUNCH("adam_tick");
-    } else {
+    if (!hyper_dev) {
         bc1 = (float)(1.0 - pow((double)beta1, step));
         bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, step));
     }
@@ -229,7 +239,7 @@ int movae_adam_multi(int n_tensors, float* const* p, const float* const* g, floa
         for (int i = cnt; i < ADAM_MT; ++i) { tab.p[i] = nullptr; tab.g[i] = nullptr; tab.m[i] = nullptr; tab.v[i] = nullptr; tab.n[i] = 0; }
         for (int i = cnt; i <= ADAM_MT; ++i) tab.first[i] = nblk;
         hipLaunchKernelGGL(adam_multi_k, dim3(nblk), dim3(256), 0, (hipStream_t)stream, tab, cnt, lr, beta1, beta2, eps, weight_decay,
-                           decoupled_wd, bc1, bc2_sqrt, (const float*)hyper_dev);
+                           decoupled_wd, bc1, bc2_sqrt, hyper_dev, t0 + ADAM_MT >= n_tensors ? 1 : 0);
         MOVAE_CHECK_LAUNCH("adam_multi");
     }
     return MOVAE_OK;

@@ -82,7 +82,10 @@ class VAE(HotPathModel):
         return ops.reparameterize(mu, log_var, self._noise_like(mu))
 
     def decode(self, z):
-        return nchw_view(self.final_layer(self.decoder(self.decoder_input(z))))
+        y = self.final_layer(self.decoder(self.decoder_input(z)))
+        # the output activation's link (nn.Stack): the reconstruction loss is the one reader of `recons` in a training step
+        self._recons_link, self.final_layer._out_link = self.final_layer._out_link, None
+        return nchw_view(y)
 
     def forward(self, x):
         mu, log_var = self.encode(x)
@@ -96,7 +99,9 @@ class VAE(HotPathModel):
                 and args["mu"].dim() == 2 and os.environ.get("MOVAE_FUSE_LOSSES", "1") != "0"):
             # both terms and their sum from one final kernel (ops.VAELosses): the same values, two launches fewer
             x, r = ops.to_nhwc(inputs), ops.to_nhwc(args["recons"])
-            rec, kld, total = ops.vae_losses(r, x, rec_fn.kind, lw["reconstruction_loss"], args["mu"], args["log_var"], lw["kld_loss"])
+            link = getattr(self, "_recons_link", None)
+            rec, kld, total = ops.vae_losses(r, x, rec_fn.kind, lw["reconstruction_loss"], args["mu"], args["log_var"], lw["kld_loss"],
+                                             act_link=link if (link is not None and link.y is not None and link.y.data_ptr() == r.data_ptr()) else None)
             return {"reconstruction_loss": rec, "kld_loss": kld, "total_loss": total}
         rec = self.objectives["reconstruction_loss"](inputs, args["recons"], lw["reconstruction_loss"])
         kld = self.objectives["kld_loss"](args["mu"], args["log_var"], lw["kld_loss"])

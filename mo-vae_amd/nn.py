@@ -208,9 +208,18 @@ class Stack(tnn.Sequential):
                     link = None
                     i += 3 if act is not None else 2
                 elif isinstance(nxt, _Act):
-                    out = ops.ActLink() if (nxt.kind in ("lrelu", "relu") and not isinstance(x, ops.LazyBN)) else None
-                    x = m(x, nxt.kind, False, ops.ConvFusion(act_in=link, act_out=out, res_in=rin)
-                          if (link is not None or out is not None or rin is not None) else None)
+                    # (a tanh / sigmoid pair that ENDS the Stack gets a link too: the decoder's output activation, whose one reader
+                    # is the reconstruction loss -- ops.VAELosses applies the derivative in its backward kernel)
+                    lazy = isinstance(x, ops.LazyBN)
+                    ends = i + 2 == n and nxt.kind in ("tanh", "sigmoid")
+                    out = ops.ActLink() if ((nxt.kind in ("lrelu", "relu") and not lazy) or ends) else None
+                    if lazy and out is not None:  # the conv applies the producer's BatchNorm on load AND publishes its own activation
+                        f = x.fusion()
+                        f.act_out = out
+                        x = m(x, nxt.kind, False, f)
+                    else:
+                        x = m(x, nxt.kind, False, ops.ConvFusion(act_in=link, act_out=out, res_in=rin)
+                              if (link is not None or out is not None or rin is not None) else None)
                     link = out
                     i += 2
                 else:

@@ -1459,7 +1459,7 @@ class VAELosses(Function):
     cotangents arrive (mtl_backward differentiates the components one at a time, `--agg sum` the total)."""
 
     @staticmethod
-    def forward(ctx, recons, inputs, kind, scale_r, mu, log_var, scale_k):
+    def forward(ctx, recons, inputs, kind, scale_r, mu, log_var, scale_k, act_link=None):
         ctx.set_materialize_grads(False)
         L.require_gpu(recons)
         recons, inputs, mu, log_var = _c(recons), _c(inputs), _c(mu), _c(log_var)
@@ -1470,6 +1470,9 @@ class VAELosses(Function):
         _call("movae_vae_losses_fwd", recons.data_ptr(), inputs.data_ptr(), recons.numel(), L.RECON[kind], float(scale_r), mu.data_ptr(),
               log_var.data_ptr(), b, d, float(scale_k), out.data_ptr(), wsp, wsb, _st(recons))
         ctx.kind, ctx.scale_r, ctx.scale_k = kind, scale_r, scale_k
+        # recons = act(pre) is the decoder's output activation and this loss its one reader (ActLink): the backward kernel applies
+        # act'(pre) and hands the producing conv the PRE-activation gradient
+        ctx.act_link = act_link if (FUSE_ACT and act_link is not None and act_link.act in ("tanh", "sigmoid")) else None
         ctx.save_for_backward(recons, inputs, mu, log_var)
         return out[0], out[1], out[2]
 
@@ -1482,19 +1485,25 @@ class VAELosses(Function):
         if gr is not None and ctx.needs_input_grad[0]:
             gr = _c(gr)
             dr = torch.empty_like(recons)
-            _call("movae_recon_loss_bwd", recons.data_ptr(), inputs.data_ptr(), gr.data_ptr(), dr.data_ptr(), recons.numel(),
-                  L.RECON[ctx.kind], float(ctx.scale_r), _st(recons))
+            link = ctx.act_link
+            if link is not None:
+                _call("movae_recon_loss_bwd_act", recons.data_ptr(), inputs.data_ptr(), gr.data_ptr(), dr.data_ptr(), recons.numel(),
+                      L.RECON[ctx.kind], float(ctx.scale_r), L.ACT[link.act], float(link.slope), _st(recons))
+                link.applied = dr.data_ptr()
+            else:
+                _call("movae_recon_loss_bwd", recons.data_ptr(), inputs.data_ptr(), gr.data_ptr(), dr.data_ptr(), recons.numel(),
+                      L.RECON[ctx.kind], float(ctx.scale_r), _st(recons))
         if gk is not None and (ctx.needs_input_grad[4] or ctx.needs_input_grad[5]):
             gk = _c(gk)
             b, d = mu.shape
             dmu, dlv = _cot(mu.data_ptr(), mu), _cot(log_var.data_ptr(), mu)
             _call("movae_kl_bwd", mu.data_ptr(), log_var.data_ptr(), gk.data_ptr(), dmu.data_ptr(), dlv.data_ptr(), b, d,
                   float(ctx.scale_k), _st(mu))
-        return dr, None, None, None, dmu, dlv, None
+        return dr, None, None, None, dmu, dlv, None, None
 
 
-def vae_losses(recons, inputs, kind, scale_r, mu, log_var, scale_k):
-    return VAELosses.apply(recons, inputs, kind, scale_r, mu, log_var, scale_k)
+def vae_losses(recons, inputs, kind, scale_r, mu, log_var, scale_k, act_link=None):
+    return VAELosses.apply(recons, inputs, kind, scale_r, mu, log_var, scale_k, act_link)
 
 
 class CombineLosses(Function):

@@ -1,5 +1,5 @@
 mkdir -p gpurun_out/r3g && cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for mb in 1000000000000 33554432 8388608; do
+for mb in 1000000000000 33554432 12582912 6291456; do
 export MOVAE_DEFER_MAX_BYTES=$mb
 for c in C2 C4 C5; do timeout -k 10 200 python bench.py --config $c --no-cpu-baseline --no-roofline > gpurun_out/r3g/bench_${c}_$mb.json 2> gpurun_out/r3g/bench_${c}_$mb.err || exit 1; done
 done
