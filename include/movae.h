@@ -150,6 +150,12 @@ int movae_colsum(const float* x, float* out, int rows, int c, int accumulate, vo
 
 /* reparameterize  z = mu + eps * exp(0.5 * log_var)      models/vae.py:187-192, betatc_vae.py:206-216 */
 int movae_reparam_fwd(const float* mu, const float* log_var, const float* eps, float* z, size_t n, movae_stream_t stream);
+/* z = mu + exp(0.5 * log_var) * eps with eps ~ N(0, 1) drawn inside the launch (Philox4x32-10 keyed by state[0], counter block =
+ * (output quad, state[1]); Box-Muller) and written to `eps` for the backward.  state: device uint64[2] = {seed, draws made so far};
+ * advance != 0: state[1] += 1 by the block that finishes last, so a replayed hipGraph draws fresh noise each time (one launch
+ * where torch.randn_like + movae_reparam_fwd are four).  One such call at a time per process (the arrival count is a device global). */
+int movae_reparam_rng_fwd(const float* mu, const float* log_var, float* eps, float* z, size_t n, unsigned long long* state, int advance,
+                          movae_stream_t stream);
 int movae_reparam_bwd(const float* dz, const float* log_var, const float* eps, float* dmu, float* dlog_var, size_t n, movae_stream_t stream);
 
 /* ---- losses -------------------------------------------------------------------------------------

@@ -62,6 +62,7 @@ SIGNATURES = {
     "movae_copy_channels": ([_p, _p, _i, _i, _i, _i, _i, _i, _p], _i),
     "movae_colsum": ([_p, _p, _i, _i, _i, _p, _z, _p], _i),
     "movae_reparam_fwd": ([_p, _p, _p, _p, _z, _p], _i),
+    "movae_reparam_rng_fwd": ([_p, _p, _p, _p, _z, _p, _i, _p], _i),
     "movae_reparam_bwd": ([_p, _p, _p, _p, _p, _z, _p], _i),
     "movae_reduce_ws_bytes": ([_z], _z),
     "movae_recon_loss_fwd": ([_p, _p, _p, _z, _i, _f, _p, _z, _p], _i),

@@ -266,6 +266,63 @@ __global__ void reparam_fwd_k(const float* __restrict__ mu, const float* __restr
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) z[i] = mu[i] + eps[i] * expf(0.5f * lv[i]);
 }
 
+// ---- reparameterisation with the noise drawn in the kernel --------------------------------------------------------------------
+// torch.randn_like inside a captured hipGraph costs three launches per replay (two Philox state updates and the generator kernel)
+// in front of this 5 us op.  Here the standard normal eps is drawn from Philox4x32-10 (Salmon et al., SC'11; the generator family
+// torch / cuRAND / rocRAND use) keyed by `seed`, one counter block (quad index, draw number) per four outputs, Box-Muller on the
+// four words.  state[0] = seed, state[1] = number of draws made so far: read by every block, advanced by the block that finishes
+// last (g_reparam_done), so a replayed graph draws fresh noise every time.  eps is written out for the backward.
+__device__ unsigned g_reparam_done = 0;
+
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+        k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+    }
+    out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
+}
+
+__device__ __forceinline__ float unit_open(unsigned x) { return ((float)(x >> 8) + 0.5f) * (1.f / 16777216.f); }  // (0, 1), 24 bits
+
+__global__ __launch_bounds__(256) void reparam_rng_fwd_k(const float* __restrict__ mu, const float* __restrict__ lv, float* __restrict__ eps,
+                                                         float* __restrict__ z, long n, unsigned long long* __restrict__ state,
+                                                         int advance) {
+    const unsigned long long seed = state[0], draw = state[1];
+    const long nq = (n + 3) / 4, stride = (long)gridDim.x * blockDim.x;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += stride) {
+        unsigned w[4];
+        philox4x32_10((unsigned)q, (unsigned)((unsigned long long)q >> 32), (unsigned)draw, (unsigned)(draw >> 32), (unsigned)seed,
+                      (unsigned)(seed >> 32), w);
+        float e[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float r = sqrtf(-2.f * logf(unit_open(w[2 * h]))), t = 6.28318530717958647692f * unit_open(w[2 * h + 1]);
+            float sn, cs;
+            sincosf(t, &sn, &cs);
+            e[2 * h] = r * cs, e[2 * h + 1] = r * sn;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long i = q * 4 + j;
+            if (i < n) {
+                eps[i] = e[j];
+                z[i] = mu[i] + e[j] * expf(0.5f * lv[i]);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned done = atomicAdd(&g_reparam_done, 1u);
+        if (done == gridDim.x - 1) {
+            g_reparam_done = 0;
+            if (advance) state[1] = draw + 1;
+        }
+    }
+}
+
 __global__ void reparam_bwd_k(const float* __restrict__ dz, const float* __restrict__ lv, const float* __restrict__ eps,
                               float* __restrict__ dmu, float* __restrict__ dlv, long n) {
     const long stride = (long)gridDim.x * blockDim.x;
@@ -428,6 +485,15 @@ int movae_reparam_fwd(const float* mu, const float* log_var, const float* eps, f
     MOVAE_CHECK_ARG(mu && log_var && eps && z && n > 0, "movae_reparam_fwd: bad argument");
     hipLaunchKernelGGL(reparam_fwd_k, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, mu, log_var, eps, z, (long)n);
     MOVAE_CHECK_LAUNCH("reparam_fwd");
+    return MOVAE_OK;
+}
+
+int movae_reparam_rng_fwd(const float* mu, const float* log_var, float* eps, float* z, size_t n, unsigned long long* state, int advance,
+                          movae_stream_t stream) {
+    MOVAE_CHECK_ARG(mu && log_var && eps && z && state && n > 0, "movae_reparam_rng_fwd: bad argument");
+    hipLaunchKernelGGL(reparam_rng_fwd_k, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, mu, log_var, eps, z, (long)n, state,
+                       advance);
+    MOVAE_CHECK_LAUNCH("reparam_rng_fwd");
     return MOVAE_OK;
 }
 

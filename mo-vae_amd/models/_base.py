@@ -1,4 +1,6 @@
 """Shared plumbing of the four hot-path models: loss-weight validation, summaries, noise source."""
+import os
+
 import torch
 import torch.nn as tnn
 
@@ -137,7 +139,35 @@ class HotPathModel(tnn.Module):
     graph_safe = False
 
     def prepare_for_graph(self):
-        """Hook called once before capture; models with per-step host state move it to the device here."""
+        """Hook called once before capture; models with per-step host state move it to the device here.  The reparameterisation
+        noise is drawn inside the reparameterisation kernel from here on (ops.ReparameterizeRNG): torch.randn_like under capture
+        costs three extra launches per replay.  MOVAE_DEVICE_RNG=0 keeps torch's generator."""
+        if os.environ.get("MOVAE_DEVICE_RNG", "1") != "0":
+            self.noise_on_device = True
+            params = list(self.parameters())
+            if params and params[0].is_cuda:
+                self._noise_state(params[0].device)  # (exists before the capture's state snapshot: train._state_tensors)
+
+    #: draw the reparameterisation noise in the kernel (set by prepare_for_graph); `_noise_state_t`: device int64 {seed, draws}
+    noise_on_device = False
+    _noise_state_t = None
+
+    def _noise_state(self, device):
+        st = self._noise_state_t
+        if st is None or st.device != device:
+            seed = torch.initial_seed()  # the run's torch.manual_seed (read, not drawn: the host generator's stream is untouched)
+            if torch.distributed.is_available() and torch.distributed.is_initialized():
+                seed ^= (torch.distributed.get_rank() + 1) * 0x9E3779B97F4A7C15  # ranks draw different noise
+            seed &= (1 << 63) - 1
+            st = self._noise_state_t = torch.tensor([seed, 0], dtype=torch.int64, device=device)
+        return st
+
+    def _reparameterize(self, mu, log_var):
+        """z = mu + exp(0.5 log_var) * eps (models/vae.py:196-209): eps from eps_override (tests), from the kernel's own
+        generator (graph mode), or from torch.randn_like like the reference."""
+        if self.eps_override is None and self.noise_on_device and mu.is_cuda:
+            return ops.reparameterize_rng(mu, log_var, self._noise_state(mu.device))
+        return ops.reparameterize(mu, log_var, self._noise_like(mu))
 
     #: set to a tensor to replace torch.randn_like in reparameterize (seed-parity tests: the CPU and
     #: HIP generators draw different streams, SURVEY section 7 "hard parts")

@@ -61,11 +61,12 @@ class BetaTCVAE(HotPathModel):
 
     def prepare_for_graph(self):
         """Moves the annealing counter (models/betatc_vae.py:13,301-305) to the device, starting from its current value."""
+        super().prepare_for_graph()
         if self._iter_dev is None:
             self._iter_dev = torch.tensor(float(self.num_iter), dtype=torch.float32, device=next(self.parameters()).device)
 
     def reparameterize(self, mu, logvar):
-        return ops.reparameterize(mu, logvar, self._noise_like(mu))
+        return self._reparameterize(mu, logvar)
 
     def forward(self, x, **kwargs):
         mu, log_var = self.encode(x)

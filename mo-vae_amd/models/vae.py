@@ -79,7 +79,7 @@ class VAE(HotPathModel):
         return mnn.linear_pair(h, self.mu, self.log_var)  # (fc_mu || fc_var in one launch where the shapes allow)
 
     def reparameterize(self, mu, log_var):
-        return ops.reparameterize(mu, log_var, self._noise_like(mu))
+        return self._reparameterize(mu, log_var)
 
     def decode(self, z):
         y = self.final_layer(self.decoder(self.decoder_input(z)))

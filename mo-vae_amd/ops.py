@@ -1310,6 +1310,38 @@ def reparameterize(mu, log_var, eps):
     return Reparameterize.apply(mu, log_var, eps)
 
 
+class ReparameterizeRNG(Function):
+    """z = mu + exp(0.5 * log_var) * eps with eps ~ N(0, 1) drawn inside the kernel (movae_reparam_rng_fwd): `state` is a device
+    int64[2] = {seed, draws so far}, advanced by the launch itself -- one launch per step where torch.randn_like under graph capture
+    plus the reparameterisation are four.  The backward is Reparameterize's (eps is kept)."""
+
+    @staticmethod
+    def forward(ctx, mu, log_var, state):
+        ctx.set_materialize_grads(False)
+        L.require_gpu(mu)
+        mu, log_var = _c(mu), _c(log_var)
+        assert state.dtype == torch.int64 and state.numel() == 2 and state.device == mu.device
+        z, eps = torch.empty_like(mu), torch.empty_like(mu)
+        _call("movae_reparam_rng_fwd", mu.data_ptr(), log_var.data_ptr(), eps.data_ptr(), z.data_ptr(), mu.numel(), state.data_ptr(), 1, _st(mu))
+        ctx.save_for_backward(log_var, eps)
+        ctx.in_ptrs = (mu.data_ptr(), log_var.data_ptr())
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        if dz is None:
+            return (None,) * 3
+        log_var, eps = ctx.saved_tensors
+        dz = _c(dz)
+        dmu, dlv = _cot(ctx.in_ptrs[0], dz), _cot(ctx.in_ptrs[1], dz)
+        _call("movae_reparam_bwd", dz.data_ptr(), log_var.data_ptr(), eps.data_ptr(), dmu.data_ptr(), dlv.data_ptr(), dz.numel(), _st(dz))
+        return dmu, dlv, None
+
+
+def reparameterize_rng(mu, log_var, state):
+    return ReparameterizeRNG.apply(mu, log_var, state)
+
+
 # ---------------------------------------------------------------------------------------------
 class ReconLoss(Function):
     """scale * mean(objective(recons, inputs)); both tensors must share one memory order."""

@@ -130,7 +130,8 @@ DP_OVERLAP_MIN_BYTES = 32 << 20
 
 
 def _state_tensors(net):
-    extra = [t for t in (getattr(net, "_iter_dev", None),) if isinstance(t, torch.Tensor)]  # BetaTC's device-side step counter
+    # BetaTC's device-side step counter; the in-kernel noise generator's {seed, draws} (models/_base.py)
+    extra = [t for t in (getattr(net, "_iter_dev", None), getattr(net, "_noise_state_t", None)) if isinstance(t, torch.Tensor)]
     return list(net.parameters()) + list(net.buffers()) + extra
 
 

@@ -827,3 +827,54 @@ def test_linear_pair_matches_two_linears(M, m, k, n):
             close(db1[g], c1[g].sum(0), f"G={G} db1[{g}]", rtol=2e-3, atol=2e-4)
             close(dw2[g], (c2[g].t() @ x) if with2 else torch.zeros(n, k), f"G={G} dw2[{g}]", rtol=2e-3, atol=2e-4)
             close(db2[g], c2[g].sum(0) if with2 else torch.zeros(n), f"G={G} db2[{g}]", rtol=2e-3, atol=2e-4)
+
+
+def _philox4x32_10(c, k):
+    """Philox4x32-10 (Salmon et al., SC'11) on numpy uint32: c [n, 4] counters, k (k0, k1) -> [n, 4] words."""
+    c = [c[:, i].astype(np.uint64) for i in range(4)]
+    k0, k1 = np.uint64(k[0]), np.uint64(k[1])
+    m32 = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = np.uint64(0xD2511F53) * c[0], np.uint64(0xCD9E8D57) * c[2]
+        c = [((p1 >> np.uint64(32)) ^ c[1] ^ k0) & m32, p1 & m32, ((p0 >> np.uint64(32)) ^ c[3] ^ k1) & m32, p0 & m32]
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & m32, (k1 + np.uint64(0xBB67AE85)) & m32
+    return np.stack(c, 1)
+
+
+def test_reparameterize_rng_philox_stream_moments_and_backward(M):
+    """ops.reparameterize_rng: the noise is the documented stream (Philox4x32-10 keyed by the seed, counter block = (quad, draw),
+    Box-Muller on the four words -- restated here in numpy), standard normal in its moments, fresh on every call (the launch
+    advances the draw counter itself), and the op's values / gradients are those of ops.reparameterize fed the same eps."""
+    ops, _ = M
+    dev = torch.device("cuda")
+    n_rows, d = 4096, 250  # (not a multiple of 4 per row: the quads run over the flat array; the tail quad is partial)
+    mu, lv = rnd(n_rows, d, seed=1).to(dev).requires_grad_(True), (rnd(n_rows, d, seed=2) * 0.3).to(dev).requires_grad_(True)
+    seed = 0x1234_5678_9ABC_DEF
+    state = torch.tensor([seed, 7], dtype=torch.int64, device=dev)
+    z = ops.reparameterize_rng(mu, lv, state)
+    assert state.cpu().tolist() == [seed, 8], "the launch advances the draw counter"
+    eps = ((z - mu) / torch.exp(0.5 * lv)).detach().cpu().double().numpy().reshape(-1)
+    # the documented stream
+    n = eps.size
+    q = np.arange((n + 3) // 4, dtype=np.uint64)
+    ctr = np.stack([q & np.uint64(0xFFFFFFFF), q >> np.uint64(32), np.full_like(q, 7), np.zeros_like(q)], 1)
+    w = _philox4x32_10(ctr, (seed & 0xFFFFFFFF, seed >> 32)).astype(np.float64)
+    u = (np.floor(w / 256.0) + 0.5) / 16777216.0
+    r0, t0, r1, t1 = np.sqrt(-2 * np.log(u[:, 0])), 2 * np.pi * u[:, 1], np.sqrt(-2 * np.log(u[:, 2])), 2 * np.pi * u[:, 3]
+    want = np.stack([r0 * np.cos(t0), r0 * np.sin(t0), r1 * np.cos(t1), r1 * np.sin(t1)], 1).reshape(-1)[:n]
+    np.testing.assert_allclose(eps, want, rtol=0, atol=2e-4)  # (fp32 log / sincos and the division above)
+    # moments of a standard normal (1 M samples: the standard errors are 1e-3, 1.4e-3, 5e-3)
+    assert abs(eps.mean()) < 5e-3 and abs(eps.var() - 1.0) < 7e-3 and abs(((eps - eps.mean()) ** 4).mean() / eps.var() ** 2 - 3.0) < 0.03
+    # a second call draws different noise, the same state the same noise
+    z2 = ops.reparameterize_rng(mu, lv, state)
+    assert not torch.equal(z2, z)
+    state.copy_(torch.tensor([seed, 7], dtype=torch.int64))
+    assert torch.equal(ops.reparameterize_rng(mu, lv, state), z)
+    # gradients: those of the plain op with this eps
+    g = rnd(n_rows, d, seed=3).to(dev)
+    dmu, dlv = torch.autograd.grad(z, [mu, lv], g)
+    eps_t = ((z - mu) / torch.exp(0.5 * lv)).detach()
+    zr = ops.reparameterize(mu, lv, eps_t)
+    rmu, rlv = torch.autograd.grad(zr, [mu, lv], g)
+    assert torch.equal(dmu, rmu)
+    np.testing.assert_allclose(dlv.cpu().numpy(), rlv.cpu().numpy(), rtol=1e-4, atol=1e-6)  # (eps_t is eps up to the rounding of the division above)
