@@ -1407,9 +1407,11 @@ int launch_thin_wgrad_impl(const float* S, const float* Bg, float* const* dW, in
                 if (nblk > cap) nblk = cap;
             }
             // column sums of S (the bias gradient when S is dy) from the MFMA kernel: S is its thin operand, the images equally large
-            // (from 512 k pixels: the three extra floats per slab row take the reduce off its 16-byte path, which costs a small layer
-            // -- C2's last conv: +5 us -- more than the stand-alone column sum it saves; C5's last conv: 34 us saved)
-            bool cs_on = use_mfma && thin_small && colsum && g.Hs == g.Hb && g.Ws == g.Wb && (long)K >= (1L << 19);
+            // (from 256 k pixels: the three extra floats per slab row take the reduce off its 16-byte path, +5 us at C2's last conv,
+            // but the stand-alone column sum it saves is two launches there -- C2 0.822 -> 0.801 ms; C5's last conv: 34 us saved;
+            // at C1's 128 k pixels the two are level)
+            static const long cs_min = getenv("MOVAE_THIN_CS_MIN") ? atol(getenv("MOVAE_THIN_CS_MIN")) : (1L << 18);
+            bool cs_on = use_mfma && thin_small && colsum && g.Hs == g.Hb && g.Ws == g.Wb && (long)K >= cs_min;
             for (int i = 0; cs_on && i < G; ++i) cs_on = colsum[i] != nullptr;
             const long row = (long)M * N + (cs_on ? M : 0);  // floats per slab row
             const size_t per1 = (size_t)row * sizeof(float);
