@@ -544,15 +544,31 @@ __device__ __forceinline__ void igemm2_fwd_body(const FwdArgs& a, float* __restr
     }
 }
 
+// XCD-aware block -> tile map.  The hardware deals consecutive workgroups to the 8 XCDs in turn (linear id % 8), each with an L2 of
+// its own: with tile = block id, the row tiles an XCD works on are every 8th one -- neighbours' halo rows and the column tiles that
+// re-read the same activation rows land in other XCDs' L2s, and every XCD streams (nearly) the whole activation (PMC: 541 MB per
+// launch of igemm2_bwd<128,128> at C3 for ~75 MB algorithmic).  Here XCD x takes a CONTIGUOUS run of tiles in (row tile, column
+// tile) order -- column tiles of one row tile adjacent -- so an activation row is fetched by one XCD.  A bijection on [0, gx * gy).
+__device__ __forceinline__ void xcd_tile(int xr, int& bx, int& by) {
+    if (!xr) return;
+    const int gx = (int)gridDim.x, gy = (int)gridDim.y, T = gx * gy;
+    const int lin = bx + gx * by, x = lin & 7, j = lin >> 3;
+    const int per = T >> 3, rem = T & 7;
+    const int t = x * per + (x < rem ? x : rem) + j;
+    bx = t / gy, by = t - bx * gy;
+}
+
 template <int BM, int BN, bool BF = false>
-__global__ __launch_bounds__(256) void igemm2_fwd(FwdArgs a, RSide sd, int gz) {
+__global__ __launch_bounds__(256) void igemm2_fwd(FwdArgs a, RSide sd, int gz, int xr) {
     __shared__ __attribute__((aligned(16))) float smem[FwdSmem<BM, BN>::FLOATS];
     if ((int)blockIdx.z >= gz) {  // a parked weight-gradient reduce rides BEHIND this launch's own blocks (conv_igemm.hip: RSide)
         const int bid = (((int)blockIdx.z - gz) * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
         if (bid < sd.nblk) side_reduce(sd, bid, smem);
         return;
     }
-    igemm2_fwd_body<BM, BN, BF>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+    int bx = blockIdx.x, by = blockIdx.y;
+    xcd_tile(xr, bx, by);
+    igemm2_fwd_body<BM, BN, BF>(a, smem, bx, by, blockIdx.z);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -988,14 +1004,16 @@ __device__ __forceinline__ void igemm2_bwd_body(const BwdArgs& a, float* __restr
 }
 
 template <int BM, int BN, bool BF = false>
-__global__ __launch_bounds__(256) void igemm2_bwd(BwdArgs a, RSide sd, int gz) {
+__global__ __launch_bounds__(256) void igemm2_bwd(BwdArgs a, RSide sd, int gz, int xr) {
     __shared__ __attribute__((aligned(16))) float smem[BwdSmem<BM, BN>::FLOATS];
     if ((int)blockIdx.z >= gz) {  // a parked weight-gradient reduce rides BEHIND this launch's own blocks (conv_igemm.hip: RSide)
         const int bid = (((int)blockIdx.z - gz) * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
         if (bid < sd.nblk) side_reduce(sd, bid, smem);
         return;
     }
-    igemm2_bwd_body<BM, BN, BF>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+    int bx = blockIdx.x, by = blockIdx.y;
+    xcd_tile(xr, bx, by);
+    igemm2_bwd_body<BM, BN, BF>(a, smem, bx, by, blockIdx.z);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1295,14 +1313,16 @@ __device__ __forceinline__ void igemm2_wgrad_body(const WgArgs& a, float* __rest
 }
 
 template <int BM, int BN, bool BF = false>
-__global__ __launch_bounds__(256) void igemm2_wgrad(WgArgs a, RSide sd, int gz) {
+__global__ __launch_bounds__(256) void igemm2_wgrad(WgArgs a, RSide sd, int gz, int xr) {
     __shared__ __attribute__((aligned(16))) float smem[WgSmem<BM, BN>::FLOATS];
     if ((int)blockIdx.z >= gz) {  // a parked weight-gradient reduce rides BEHIND this launch's own blocks (conv_igemm.hip: RSide)
         const int bid = (((int)blockIdx.z - gz) * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
         if (bid < sd.nblk) side_reduce(sd, bid, smem);
         return;
     }
-    igemm2_wgrad_body<BM, BN, BF>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+    int bx = blockIdx.x, by = blockIdx.y;
+    xcd_tile(xr, bx, by);
+    igemm2_wgrad_body<BM, BN, BF>(a, smem, bx, by, blockIdx.z);
 }
 
 // ---- one launch, two problems: the input gradient (FWD or BWD gather form) and the weight gradient of one layer ----------
@@ -1413,6 +1433,12 @@ inline int finish_pending(hipStream_t st) {  // the stashed dgrad's reduce
     return MOVAE_OK;
 }
 
+// MOVAE_XCD_REMAP: 1 = XCD-aware tile map (xcd_tile) for launches of at least 64 tiles per z slice, 0 = tile = block id
+inline int xcd_remap(const dim3& grid) {
+    static const int mode = getenv("MOVAE_XCD_REMAP") ? atoi(getenv("MOVAE_XCD_REMAP")) : 0;
+    return mode && (long)grid.x * grid.y >= 64 ? 1 : 0;
+}
+
 inline int flush_pending(hipStream_t st) {  // launch the stashed dgrad on its own
     if (g_kpair.flush)
         if (int rc = g_kpair.flush(st)) return rc;
@@ -1423,11 +1449,11 @@ inline int flush_pending(hipStream_t st) {  // launch the stashed dgrad on its o
     int gz;
     const RSide sd = defer_take_3d(st, &grid, &gz);
     if (p.form == 0) {
-        if (p.bm == 64) hipLaunchKernelGGL((igemm2_fwd<64, 64>), grid, dim3(256), 0, st, p.fa, sd, gz);
-        else hipLaunchKernelGGL((igemm2_fwd<128, 32>), grid, dim3(256), 0, st, p.fa, sd, gz);
+        if (p.bm == 64) hipLaunchKernelGGL((igemm2_fwd<64, 64>), grid, dim3(256), 0, st, p.fa, sd, gz, xcd_remap(grid));
+        else hipLaunchKernelGGL((igemm2_fwd<128, 32>), grid, dim3(256), 0, st, p.fa, sd, gz, xcd_remap(grid));
     } else {
-        if (p.bm == 64) hipLaunchKernelGGL((igemm2_bwd<64, 64>), grid, dim3(256), 0, st, p.ba, sd, gz);
-        else hipLaunchKernelGGL((igemm2_bwd<128, 32>), grid, dim3(256), 0, st, p.ba, sd, gz);
+        if (p.bm == 64) hipLaunchKernelGGL((igemm2_bwd<64, 64>), grid, dim3(256), 0, st, p.ba, sd, gz, xcd_remap(grid));
+        else hipLaunchKernelGGL((igemm2_bwd<128, 32>), grid, dim3(256), 0, st, p.ba, sd, gz, xcd_remap(grid));
     }
     MOVAE_CHECK_LAUNCH("igemm2 dgrad (unpaired)");
     return finish_pending(st);
@@ -1495,8 +1521,8 @@ int launch_fwd2(const float* X, const float* W, float* Y, const Geom& g, const E
     dim3 grid(gx, gy, S);
     int gz;
     const RSide sd = defer_take_3d(st, &grid, &gz);
-    if (BM == 128 && BN == 128 && g_compute_bf16) hipLaunchKernelGGL((igemm2_fwd<BM, BN, BM == 128 && BN == 128>), grid, dim3(256), 0, st, a, sd, gz);
-    else hipLaunchKernelGGL((igemm2_fwd<BM, BN>), grid, dim3(256), 0, st, a, sd, gz);
+    if (BM == 128 && BN == 128 && g_compute_bf16) hipLaunchKernelGGL((igemm2_fwd<BM, BN, BM == 128 && BN == 128>), grid, dim3(256), 0, st, a, sd, gz, xcd_remap(grid));
+    else hipLaunchKernelGGL((igemm2_fwd<BM, BN>), grid, dim3(256), 0, st, a, sd, gz, xcd_remap(grid));
     MOVAE_CHECK_LAUNCH("igemm2_fwd");
     if (S > 1) {
         if (rbb.y && !g_bench_main_only) {
@@ -1635,8 +1661,8 @@ int launch_bwd2(const float* X, const float* W, float* Y, const Geom& g, const E
     dim3 grid(gx, gy, zsum);
     int gz;
     const RSide sd = defer_take_3d(st, &grid, &gz);
-    if (BM == 128 && BN == 128 && g_compute_bf16) hipLaunchKernelGGL((igemm2_bwd<BM, BN, BM == 128 && BN == 128>), grid, dim3(256), 0, st, a, sd, gz);
-    else hipLaunchKernelGGL((igemm2_bwd<BM, BN>), grid, dim3(256), 0, st, a, sd, gz);
+    if (BM == 128 && BN == 128 && g_compute_bf16) hipLaunchKernelGGL((igemm2_bwd<BM, BN, BM == 128 && BN == 128>), grid, dim3(256), 0, st, a, sd, gz, xcd_remap(grid));
+    else hipLaunchKernelGGL((igemm2_bwd<BM, BN>), grid, dim3(256), 0, st, a, sd, gz, xcd_remap(grid));
     MOVAE_CHECK_LAUNCH("igemm2_bwd");
     if (Sreal > 1 && !g_bench_main_only) {
         if (rbb.y) {
@@ -1719,8 +1745,8 @@ int launch_wgrad2(const float* Sm, const float* Bg, float* const* dW, int G, lon
         dim3 grid(gx, gy, Sp * G);
         int gz;
         const RSide sd = defer_take_3d(st, &grid, &gz);
-        if (BM == 128 && BN == 128 && g_compute_bf16) hipLaunchKernelGGL((igemm2_wgrad<BM, BN, BM == 128 && BN == 128>), grid, dim3(256), 0, st, a, sd, gz);
-        else hipLaunchKernelGGL((igemm2_wgrad<BM, BN>), grid, dim3(256), 0, st, a, sd, gz);
+        if (BM == 128 && BN == 128 && g_compute_bf16) hipLaunchKernelGGL((igemm2_wgrad<BM, BN, BM == 128 && BN == 128>), grid, dim3(256), 0, st, a, sd, gz, xcd_remap(grid));
+        else hipLaunchKernelGGL((igemm2_wgrad<BM, BN>), grid, dim3(256), 0, st, a, sd, gz, xcd_remap(grid));
         MOVAE_CHECK_LAUNCH("igemm2_wgrad");
     }
     if (slab) {  // ONE reduce launch for all groups (blockIdx.y = group)
