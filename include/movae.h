@@ -352,6 +352,9 @@ const char* movae_bench_last_kernel(void);
 /* s > 0 pins the conv family's split-K factor (tools/conv_microbench.py tuning sweeps); 0 restores the heuristic.
  * Returns the previous value. */
 int movae_bench_force_split(int s);
+/* 1 / 0: the kernels of csrc/kgemm.h do / do not honour movae_fuse_t::fin_* (finish the following BatchNorm inside the forward
+ * launch); -1: as MOVAE_KGEMM_BN_FIN says (default: not).  Returns the previous mode.  Tests and A/B measurements. */
+int movae_bench_kgemm_bn_fin(int mode);
 /* mode > 0: every conv-family call whose shape the block-internal split-K kernels (csrc/kgemm.h) can serve takes them, whatever
  * the size heuristic says; mode < 0: none does; 0: the heuristic (small, latency-bound problems only).  Lets the parity tests run
  * the whole conv test matrix through either family.  Returns the previous mode. */
@@ -402,6 +405,20 @@ typedef struct movae_fuse {
      * vq_vae2.py:13-28): ep_res [groups][n][hi][wi][ci] -- the gradient w.r.t. the block's output, i.e. the identity branch's
      * share -- is added to dx, which then is the block's complete input gradient. */
     const float* ep_res;
+    /* forward entry points with `stats`: the training-mode BatchNorm that follows can be FINISHED inside the convolution's own
+     * launch (kernels of csrc/kgemm.h: the block that arrives last at a column tile folds that tile's partial sums and writes what
+     * movae_bn_finalize would).  fin_out: device [4][co] = save_mean, save_rstd, scale, shift; fin_running_* / fin_nbt as in
+     * movae_bn_finalize (nullable).  fin_done == 1 on return: done, do not call movae_bn_finalize; 0: not done (another kernel
+     * family served the shape), stats / stats_parts are as without the request.  Needs the workspace header (ws as passed). */
+    const float* fin_gamma;
+    const float* fin_beta;
+    float fin_eps;
+    float fin_momentum;
+    float* fin_out;
+    float* fin_running_mean;
+    float* fin_running_var;
+    long long* fin_nbt;
+    int fin_done;          /* OUT */
 } movae_fuse_t;
 int movae_conv2d_fwd_f(const float* x, const float* w, const float* bias, float* y,
                        int n, int hi, int wi, int ci, int ho, int wo, int co, int kh, int kw, int stride, int pad,

@@ -28,7 +28,10 @@ class MovaeFuse(C.Structure):
                 ("bn_y", C.c_void_p), ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p), ("bn_slope", C.c_float), ("bn_part", C.c_void_p),
                 ("bn_cap", C.c_size_t), ("bn_ppg", C.c_int),
                 ("ep_act_y", C.c_void_p), ("ep_act", C.c_int), ("ep_slope", C.c_float), ("ep_act_done", C.c_int),
-                ("ep_res", C.c_void_p)]
+                ("ep_res", C.c_void_p),
+                ("fin_gamma", C.c_void_p), ("fin_beta", C.c_void_p), ("fin_eps", C.c_float), ("fin_momentum", C.c_float),
+                ("fin_out", C.c_void_p), ("fin_running_mean", C.c_void_p), ("fin_running_var", C.c_void_p), ("fin_nbt", C.c_void_p),
+                ("fin_done", C.c_int)]
 
 
 _conv_fwd = [_p, _p, _p, _p] + [_i] * 11 + [_i, _f, _p, _z, _p]
@@ -134,6 +137,7 @@ SIGNATURES = {
     "movae_reduce_defer_stats": ([_p, _i], _i),
     "movae_reduce_defer_max_bytes": ([C.c_longlong], C.c_longlong),
     "movae_bench_force_split": ([_i], _i),
+    "movae_bench_kgemm_bn_fin": ([_i], _i),
     "movae_bench_force_kgemm": ([_i], _i),
     "movae_set_compute_dtype": ([_i], _i),
 }

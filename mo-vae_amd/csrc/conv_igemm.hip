@@ -130,7 +130,22 @@ struct BnBwd {
 // error raised BEFORE anything is launched (MOVAE_EUNSUPPORTED: the caller materialises the activation and calls the plain
 // entry point); statistics that the dispatched kernel cannot emit leave stats_parts at 0 (the caller runs the stand-alone
 // statistics pass instead).
+// "finish the BatchNorm that follows inside this launch" (movae_fuse_t::fin_*): what the finalizing block needs
+struct BnFin {
+    const float* gamma = nullptr;  // null: no request
+    const float* beta = nullptr;
+    float* out = nullptr;           // [4][N]: save_mean, save_rstd, scale, shift
+    float* running_mean = nullptr;
+    float* running_var = nullptr;
+    long long* nbt = nullptr;
+    unsigned* counter = nullptr;    // arrival counters, one per column tile (workspace header, zero between launches)
+    float eps = 0.f, momentum = 0.f;
+    int rows = 0, parts = 0, group = 0;  // rows of the result, partial pairs per column, blocks per column tile
+};
+
 struct FuseCtx {
+    BnFin fin;                        // in: the request (gamma .. nbt, eps, momentum); fin_done: a kernel honoured it
+    bool fin_done = false;
     Norm nrm{nullptr, nullptr, 1.f};  // virtual activation operand (x of fwd / wgrad)
     int nrm_side = 0;                 // wgrad: which operand is the activation -- 1 small side Sm, 2 gathered side Bg
     float* stats = nullptr;           // column partial sums of the forward result
@@ -1411,6 +1426,12 @@ struct FuseScope {
         f->stats_parts = 0;
         if (f->in_scale && f->in_shift) g_fuse.nrm = Norm{f->in_scale, f->in_shift, f->in_slope}, g_fuse.nrm_side = nrm_side;
         if (f->stats && f->stats_cap > 0) g_fuse.stats = f->stats, g_fuse.stats_cap = f->stats_cap;
+        f->fin_done = 0;
+        if (fwd && g_fuse.stats && f->fin_gamma && f->fin_beta && f->fin_out) {
+            g_fuse.fin.gamma = f->fin_gamma, g_fuse.fin.beta = f->fin_beta, g_fuse.fin.out = f->fin_out;
+            g_fuse.fin.running_mean = f->fin_running_mean, g_fuse.fin.running_var = f->fin_running_var, g_fuse.fin.nbt = f->fin_nbt;
+            g_fuse.fin.eps = f->fin_eps, g_fuse.fin.momentum = f->fin_momentum;
+        }
         // forward passes: out = conv(x) (+ bias) + ep_res -- the last conv of a residual branch adds the block's input itself
         if (fwd) {
             f->ep_act_done = 0;
@@ -1420,7 +1441,7 @@ struct FuseScope {
     }
     ~FuseScope() {
         if (f) f->stats_parts = g_fuse.stats_parts;
-        if (f && fwd) f->ep_act_done = g_fuse.am_done ? 1 : 0;
+        if (f && fwd) f->ep_act_done = g_fuse.am_done ? 1 : 0, f->fin_done = g_fuse.fin_done ? 1 : 0;
         g_fuse = FuseCtx();
     }
 };
@@ -1493,6 +1514,12 @@ int movae_bench_force_kgemm(int mode) {
     return prev;
 }
 
+int movae_bench_kgemm_bn_fin(int mode) {  // 1 / 0: kgemm forwards do / do not finish the following BatchNorm in-launch; -1: the environment's choice
+    const int prev = kg::g_kgemm_bn_fin;
+    kg::g_kgemm_bn_fin = mode;
+    return prev;
+}
+
 int movae_bench_main_kernel_only(int on) {
     const int prev = g_bench_main_only ? 1 : 0;
     g_bench_main_only = on != 0;
@@ -1502,11 +1529,13 @@ int movae_bench_main_kernel_only(int on) {
 int movae_conv2d_fwd_f(const float* x, const float* w, const float* bias, float* y, int n, int hi, int wi, int ci, int ho,
                        int wo, int co, int kh, int kw, int stride, int pad, int act, float slope, void* ws, size_t ws_bytes,
                        movae_stream_t stream, movae_fuse_t* fuse) {
+    unsigned* const ws_header = ws && ws_bytes > (size_t)MOVAE_WS_HEADER_BYTES ? static_cast<unsigned*>(ws) : nullptr;
     MOVAE_WS_SCRATCH(ws, ws_bytes);
     MOVAE_CHECK_ARG(x && w && y, "movae_conv2d_fwd: null pointer");
     if (int rc = check_conv_shape("movae_conv2d_fwd", n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, false)) return rc;
     MOVAE_CHECK_FUSE(fuse, ci);
     FuseScope scope(fuse, 0);
+    g_fuse.fin.counter = ws_header ? ws_header + 64 : nullptr;  // words 64 .. 127 of the header: one arrival counter per column tile
     Geom g{n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad};
     return launch_fwd(x, w, y, g, Epilogue{bias, act, slope}, ws, ws_bytes, (hipStream_t)stream);
 }
@@ -1581,11 +1610,13 @@ int movae_conv2d_wgrad(const float* dy, const float* x, float* dw, float* dbias,
 int movae_convT2d_fwd_f(const float* x, const float* w, const float* bias, float* y, int n, int hi, int wi, int ci, int ho,
                         int wo, int co, int kh, int kw, int stride, int pad, int act, float slope, void* ws, size_t ws_bytes,
                         movae_stream_t stream, movae_fuse_t* fuse) {
+    unsigned* const ws_header = ws && ws_bytes > (size_t)MOVAE_WS_HEADER_BYTES ? static_cast<unsigned*>(ws) : nullptr;
     MOVAE_WS_SCRATCH(ws, ws_bytes);
     MOVAE_CHECK_ARG(x && w && y, "movae_convT2d_fwd: null pointer");
     if (int rc = check_conv_shape("movae_convT2d_fwd", n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad, true)) return rc;
     MOVAE_CHECK_FUSE(fuse, ci);
     FuseScope scope(fuse, 0);
+    g_fuse.fin.counter = ws_header ? ws_header + 64 : nullptr;  // words 64 .. 127 of the header: one arrival counter per column tile
     Geom g{n, hi, wi, ci, ho, wo, co, kh, kw, stride, pad};
     return launch_bwd(x, w, y, g, Epilogue{bias, act, slope}, ws, ws_bytes, (hipStream_t)stream);
 }

@@ -57,6 +57,7 @@ struct KArgs {
     FastDiv fd_cr, fd_kw, fd_wlen, fd_hw, fd_w;
     FastDiv fd_nb[4];  // BWD: by the class's window width nBw
     ClsTaps ct;
+    BnFin fin;      // with stats: the block arriving last at its column tile finishes the BatchNorm that follows (gamma == null: off)
 };
 
 constexpr int SIDE_FLOATS = 2 * 32 * 32;      // per-thread column sums of one tile, before the row fold
@@ -321,10 +322,71 @@ __device__ __forceinline__ void kgemm_body(const KArgs& a, float* __restrict__ s
                     if (st_on) pidx = (long)cls * a.tiles_c + Tw;
                     else pidx = FORM == 0 ? (long)Tw : (long)gi * a.bb.ppg + (long)cls * a.tpg + (Tw - gi * a.tpg);
                     float* P = st_on ? a.stats : a.bb.part;
-                    P[(pidx * 2 + which) * N + n0 + col] = c;
+                    // (handed to another block inside this launch: write-through stores, read back with sc1 loads -- no fences)
+                    if (st_on && a.fin.gamma) __hip_atomic_store(P + (pidx * 2 + which) * N + n0 + col, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else P[(pidx * 2 + which) * N + n0 + col] = c;
                 }
             }
             if (w + 1 < WT) __syncthreads();
+        }
+    }
+    // ---- the BatchNorm that follows, finished here (movae_fuse_t::fin_*): the block that arrives LAST at this column tile folds the
+    // tile's partial pairs of every row tile / class and writes what bn_finalize_k would -- save_mean, save_rstd, the folded affine
+    // map and the running statistics of its 32 channels.  Hand-off in the guide's write-through form: the partials were stored sc1,
+    // the storing wave drains them, one lane takes an agent-scope ticket, the last arriver reads them with sc1 loads (no release /
+    // acquire fence: the conv output of this block is still dirty in L2, a release here is what made the fence form lose).
+    if (st_on && a.fin.gamma) {  // (block-uniform)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned* flag = reinterpret_cast<unsigned*>(side);
+        if (t == 0) {
+            const unsigned ticket = __hip_atomic_fetch_add(a.fin.counter + by, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned last = ticket == (unsigned)a.fin.group - 1u ? 1u : 0u;
+            if (last) __hip_atomic_store(a.fin.counter + by, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
+            flag[0] = last;
+        }
+        __syncthreads();
+        const bool last = flag[0] != 0u;
+        __syncthreads();
+        if (last) {
+            double* sd = reinterpret_cast<double*>(red);  // [2][32 part lanes][32 columns] doubles = 16 KB: the fold buffer is free now
+            if (ep_thread) {
+                // 16-byte sc1 buffer loads (aux 16), all independent: a dependent chain of 4-byte agent-scope atomic loads made this
+                // tail 8-25 us long
+                const int r = t >> 3;  // part lane 0..31; c4 = 4 (t & 7) as in the epilogue
+                const v2::rsrc_t rs = v2::buf_rsrc_if(a.stats, col_ok);
+                double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+                for (int p = r; p < a.fin.parts; p += 32) {
+                    const f32x4 u = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ((p * 2 + 0) * N + nq) * 4, 0, 16));
+                    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ((p * 2 + 1) * N + nq) * 4, 0, 16));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s1[j] += (double)u[j], s2[j] += (double)v[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sd[r * 32 + c4 + j] = s1[j], sd[1024 + r * 32 + c4 + j] = s2[j];
+            }
+            __syncthreads();
+            if (t < 32 && n0 + t < N) {
+                const int n = n0 + t;
+                double s1 = 0.0, s2 = 0.0;
+#pragma unroll 8
+                for (int r = 0; r < 32; ++r) s1 += sd[r * 32 + t], s2 += sd[1024 + r * 32 + t];  // fixed order
+                const double rows = (double)a.fin.rows, mean = s1 / rows;
+                double var = s2 / rows - mean * mean;
+                if (var < 0.0) var = 0.0;
+                const float m = (float)mean, rs = (float)(1.0 / sqrt(var + (double)a.fin.eps));
+                float* o = a.fin.out;
+                o[n] = m, o[N + n] = rs;
+                const float sc = rs * a.fin.gamma[n];  // the same fp32 arithmetic as bn_finalize_k
+                o[2 * N + n] = sc, o[3 * N + n] = fmaf(-m, sc, a.fin.beta[n]);
+                if (a.fin.running_mean) {
+                    const double unb = a.fin.rows > 1 ? var * (rows / (rows - 1.0)) : var, mom = (double)a.fin.momentum;
+                    a.fin.running_mean[n] = (float)((1.0 - mom) * a.fin.running_mean[n] + mom * mean);
+                    a.fin.running_var[n] = (float)((1.0 - mom) * a.fin.running_var[n] + mom * unb);
+                }
+            }
+            if (by == 0 && t == 0 && a.fin.nbt) a.fin.nbt[0] += 1;
         }
     }
 }
@@ -555,15 +617,19 @@ inline bool small_problem(long rows, long cols, long k, long copies) {
 template <int FORM, bool NRM>
 inline void launch_k2(const KArgs& a, KSplit k, dim3 tiles, hipStream_t st) {  // tiles: (row tiles, column tiles, classes)
     if (k.ks == 8) {
-        hipLaunchKernelGGL((kgemm_k<FORM, 8, 8, NRM>), tiles, dim3(512), 0, st, a, RSide{}, (int)tiles.z);
+        KArgs b8 = a;
+        b8.fin.group = (int)(tiles.x * tiles.z);
+        hipLaunchKernelGGL((kgemm_k<FORM, 8, 8, NRM>), tiles, dim3(512), 0, st, b8, RSide{}, (int)tiles.z);
         return;
     }
     dim3 grid = k.ks == 4 ? tiles : k.ks == 2 ? dim3((tiles.x + 1) / 2, tiles.y, tiles.z) : dim3((tiles.x + 3) / 4, tiles.y, tiles.z);
+    KArgs b = a;
+    b.fin.group = (int)(grid.x * grid.z);  // blocks per column tile (before any carried reduce's extra z layers)
     int gz;
     const RSide sd = defer_take_3d(st, &grid, &gz);
-    if (k.ks == 4) hipLaunchKernelGGL((kgemm_k<FORM, 4, 4, NRM>), grid, dim3(256), 0, st, a, sd, gz);
-    else if (k.ks == 2) hipLaunchKernelGGL((kgemm_k<FORM, 4, 2, NRM>), grid, dim3(256), 0, st, a, sd, gz);
-    else hipLaunchKernelGGL((kgemm_k<FORM, 4, 1, NRM>), grid, dim3(256), 0, st, a, sd, gz);
+    if (k.ks == 4) hipLaunchKernelGGL((kgemm_k<FORM, 4, 4, NRM>), grid, dim3(256), 0, st, b, sd, gz);
+    else if (k.ks == 2) hipLaunchKernelGGL((kgemm_k<FORM, 4, 2, NRM>), grid, dim3(256), 0, st, b, sd, gz);
+    else hipLaunchKernelGGL((kgemm_k<FORM, 4, 1, NRM>), grid, dim3(256), 0, st, b, sd, gz);
 }
 template <int FORM>
 inline void launch_k(const KArgs& a, KSplit k, dim3 tiles, hipStream_t st) {
@@ -641,6 +707,16 @@ struct KPairInstall {
 };
 static KPairInstall g_kpair_install;
 
+// MOVAE_KGEMM_BN_FIN=1 (or movae_bench_kgemm_bn_fin(1)): a kgemm forward finishes the BatchNorm that follows inside its own launch
+// (the tail of kgemm_body).  OFF by default: measured at C2 the six layers it applies to cost 7-9 us more per kernel under the
+// profiler (the agent-scope ticket, the write-through partials read back over the fabric, the barriers) against the 4.6 us
+// bn_finalize launch each replaces -- 0.818 vs 0.821 ms per step, inside the noise, C1 0.602 vs 0.599.
+static int g_kgemm_bn_fin = -1;
+inline bool kgemm_bn_fin() {
+    static const bool env = getenv("MOVAE_KGEMM_BN_FIN") && atoi(getenv("MOVAE_KGEMM_BN_FIN")) != 0;
+    return g_kgemm_bn_fin < 0 ? env : g_kgemm_bn_fin != 0;
+}
+
 // The side products / epilogue requests of the calling entry point (g_fuse), as launch_fwd2 / launch_bwd2 honour them.
 // rows_all: output rows over all cotangent groups (FWD: M; BWD: pixels), ncls: output-parity classes.  False: a requested
 // BatchNorm-backward epilogue cannot be served at this shape (the caller falls back to the tiled kernels, nothing claimed).
@@ -661,6 +737,11 @@ inline bool plan_side(KArgs& a, const Epilogue& ep, long rows_all, int ncls, int
         return true;
     }
     if (want_stats) a.stats = fuse_stats_claim((long)ncls * a.tiles_c, N);
+    if (a.stats && g_fuse.fin.gamma && g_fuse.fin.counter && kgemm_bn_fin() && ceil_div(N, 32) <= 64 && rows_all <= 0x7fffffffL) {
+        a.fin = g_fuse.fin;  // (group: set at the launch, where the grid is known)
+        a.fin.rows = (int)rows_all, a.fin.parts = ncls * a.tiles_c;
+        g_fuse.fin_done = true;
+    }
     if ((g_fuse.am.y || g_fuse.am.res) && ep.act == MOVAE_ACT_NONE && (!ep.bias || !g_fuse.am.y) && !a.stats && al16(g_fuse.am.y) &&
         al16(g_fuse.am.res)) {
         const int G = g_fuse.am_groups;

@@ -199,6 +199,8 @@ class Stack(tnn.Sequential):
                     kind = act.kind if act is not None else None
                     if FUSE_BN and nxt.training and kind in (None, "lrelu", "relu") and m.out_channels % 4 == 0:
                         fusion = ops.ConvFusion(want_stats=True, act_in=link, res_in=rin)
+                        # (a producer that can finishes this BatchNorm inside its own launch: ops.ConvFusion.bn_fin)
+                        fusion.bn_fin = (nxt.weight, nxt.bias, nxt.running_mean, nxt.running_var, nxt.num_batches_tracked, nxt.eps, nxt.momentum)
                         if isinstance(x, ops.LazyBN):
                             fusion.in_scale, fusion.in_shift, fusion.in_slope, fusion.link = x.scale, x.shift, x.slope, x.link
                             x = x.y

@@ -385,12 +385,16 @@ class ConvFusion:
     in_*: the input is the RAW output y of a producer conv whose BatchNorm + activation this conv applies while loading,
     x = leaky_relu(in_scale[c] * y + in_shift[c], in_slope).  want_stats: the epilogue (or split-K reduce) also emits the
     per-channel partial sums of this conv's own output for the BatchNorm that follows it: `stats` / `parts` on return."""
-    __slots__ = ("in_scale", "in_shift", "in_slope", "want_stats", "stats", "parts", "link", "act_in", "act_out", "res_in", "res_out")
+    __slots__ = ("in_scale", "in_shift", "in_slope", "want_stats", "stats", "parts", "link", "act_in", "act_out", "res_in", "res_out",
+                 "bn_fin", "fin")
 
     def __init__(self, in_scale=None, in_shift=None, in_slope=1.0, want_stats=False, link=None, act_in=None, act_out=None, res_in=None,
                  res_out=None):
         self.in_scale, self.in_shift, self.in_slope, self.want_stats = in_scale, in_shift, float(in_slope), want_stats
         self.stats, self.parts = None, 0
+        #: (gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum) of the training-mode BatchNorm that follows:
+        #: a producer that can (csrc/kgemm.h) finishes it inside its own launch; `fin` = [4, c] (mean, rstd, scale, shift) then
+        self.bn_fin, self.fin = None, None
         #: ActLink of the producer whose activation output is this conv's input / ActLink this conv fills for its consumer
         self.act_in, self.act_out = act_in, act_out
         #: ResCarrier of the residual block whose branch starts with THIS conv (its input is the block's input)
@@ -408,6 +412,17 @@ _NO_FUSE = set()
 #: A/B knobs of the fusion's three parts (development): the normalise-on-load of consumers, the statistics from producer epilogues
 FUSE_NORM = __import__("os").environ.get("MOVAE_FUSE_NORM", "1") != "0"
 FUSE_STATS = __import__("os").environ.get("MOVAE_FUSE_STATS", "1") != "0"
+
+
+#: MOVAE_BN_FIN=0: never ask a producer to finish the BatchNorm that follows (A/B knob; the kernels' own switch is MOVAE_KGEMM_BN_FIN)
+BN_FIN = os.environ.get("MOVAE_BN_FIN", "1") != "0"
+
+
+def _fuse_fin(f, bn_fin, out):
+    """movae_fuse_t::fin_*: bn_fin = (gamma, beta, running_mean, running_var, nbt, eps, momentum), out = [4, c] result buffer"""
+    gamma, beta, rm, rv, nbt, eps, mom = bn_fin
+    f.fin_gamma, f.fin_beta, f.fin_eps, f.fin_momentum = gamma.data_ptr(), beta.data_ptr(), float(eps), float(mom)
+    f.fin_out, f.fin_running_mean, f.fin_running_var, f.fin_nbt = out.data_ptr(), L.ptr(rm), L.ptr(rv), L.ptr(nbt)
 
 
 def _fuse_struct(in_norm, stats=None, bn=None, ep=None):
@@ -552,6 +567,10 @@ class Conv(Function):
             _call(fn, x.data_ptr(), wm.data_ptr(), L.ptr(b), y.data_ptr(), *geom, L.ACT[act], float(slope), wsp, wsb, _st(x))
         else:
             f = _fuse_struct(in_norm, stats, None, ep_fwd)
+            fin_out = None
+            if stats is not None and fusion.bn_fin is not None and BN_FIN:
+                fin_out = torch.empty((4, co), dtype=torch.float32, device=x.device)
+                _fuse_fin(f, fusion.bn_fin, fin_out)
             try:
                 _call(fn + "_f", x.data_ptr(), wm.data_ptr(), L.ptr(b), y.data_ptr(), *geom, L.ACT[act], float(slope), wsp, wsb, _st(x),
                       C.byref(f))
@@ -561,10 +580,13 @@ class Conv(Function):
                 _NO_FUSE.add((fn, geom))
                 x, in_norm = scale_shift_act(x, *in_norm), None
                 f = _fuse_struct(None, stats, None, ep_fwd)
+                if fin_out is not None:
+                    _fuse_fin(f, fusion.bn_fin, fin_out)
                 _call(fn + "_f", x.data_ptr(), wm.data_ptr(), L.ptr(b), y.data_ptr(), *geom, L.ACT[act], float(slope), wsp, wsb, _st(x),
                       C.byref(f))
             if fusion is not None:
                 fusion.stats, fusion.parts = stats, int(f.stats_parts)
+                fusion.fin = fin_out if (fin_out is not None and int(f.fin_done)) else None
             if ep_fwd is not None and not int(f.ep_act_done):  # this kernel has no such epilogue: one explicit add
                 _call("movae_add", y.data_ptr(), ep_fwd[1].data_ptr(), y.data_ptr(), y.numel(), _st(x))
         ctx.geom = geom
@@ -1015,11 +1037,19 @@ class BatchNormLazy(Function):
     (movae_bn_act_bwd) on the saved raw y."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum, slope, stats, parts, link=None):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum, slope, stats, parts, link=None, fin=None):
         L.require_gpu(y)
         c = y.shape[-1]
         rows = y.numel() // c
         st = _st(y)
+        if fin is not None:  # the producer conv finished this BatchNorm inside its own launch (movae_fuse_t::fin_*)
+            mean, rstd, scale, shift = fin[0], fin[1], fin[2], fin[3]
+            ctx.act, ctx.slope = ("lrelu" if slope not in _ACT_OF_SLOPE else _ACT_OF_SLOPE[slope]), slope
+            ctx.link = link
+            ctx.save_for_backward(y, gamma, beta, mean, rstd, scale, shift)
+            ctx.mark_non_differentiable(scale, shift)
+            ctx.set_materialize_grads(False)
+            return y.view_as(y), scale, shift
         if not parts:
             stats = torch.empty(1100 * 2 * c, dtype=torch.float32, device=y.device)  # movae_bn_stats: at most 1024 partials (+ room to fold them)
             pout = C.c_int(0)
@@ -1062,7 +1092,7 @@ class BatchNormLazy(Function):
     @staticmethod
     def backward(ctx, dout, _ds, _dh):
         if dout is None:
-            return (None,) * 12
+            return (None,) * 13
         y, gamma, beta, mean, rstd = ctx.saved_tensors[:5]
         dout = _c(dout)
         c = y.shape[-1]
@@ -1071,13 +1101,13 @@ class BatchNormLazy(Function):
         db = _sink(beta, beta.shape)
         dy = BatchNormLazy._from_sums(ctx, 1, dout, [dg], [db])
         if dy is not None:
-            return dy, dg, db, None, None, None, None, None, None, None, None, None
+            return dy, dg, db, None, None, None, None, None, None, None, None, None, None
         dy = torch.empty_like(y)
         wsp, wsb = _ws(y)
         _call("movae_bn_act_bwd", dout.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
               rstd.data_ptr(), dy.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, c, L.ACT[ctx.act], float(ctx.slope), 0,
               wsp, wsb, _st(y))
-        return dy, dg, db, None, None, None, None, None, None, None, None, None
+        return dy, dg, db, None, None, None, None, None, None, None, None, None, None
 
     @staticmethod
     def backward_batched(ctx, G, dout, _ds=None, _dh=None):
@@ -1089,14 +1119,14 @@ class BatchNormLazy(Function):
         dbs = [_sink_row(g, beta, beta.shape) for g in range(G)]
         dy = BatchNormLazy._from_sums(ctx, G, dout, dgs, dbs)
         if dy is not None:
-            return dy, dgs, dbs, None, None, None, None, None, None, None, None, None
+            return dy, dgs, dbs, None, None, None, None, None, None, None, None, None, None
         dy = torch.empty_like(dout)
         wsp, wsb = _ws(y)
         arr = C.c_void_p * G
         _call("movae_bn_act_bwd_grouped", G, dout.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
               rstd.data_ptr(), dy.data_ptr(), arr(*[t.data_ptr() for t in dgs]), arr(*[t.data_ptr() for t in dbs]), rows, c,
               L.ACT[ctx.act], float(ctx.slope), 0, wsp, wsb, _st(y))
-        return dy, dgs, dbs, None, None, None, None, None, None, None, None, None
+        return dy, dgs, dbs, None, None, None, None, None, None, None, None, None, None
 
 
 def batch_norm_lazy(y, gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum, act, slope, fusion):
@@ -1106,7 +1136,7 @@ def batch_norm_lazy(y, gamma, beta, running_mean, running_var, num_batches_track
     link = {}
     try:
         yv, scale, shift = BatchNormLazy.apply(y, gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum, sl, stats,
-                                               parts, link)
+                                               parts, link, fusion.fin if fusion is not None else None)
     except L.Unsupported:  # no partial sums from the producer and a shape the stand-alone statistics pass does not take
         return batch_norm_act(y, gamma, beta, running_mean, running_var, True, eps, momentum, act, slope, num_batches_tracked)
     return LazyBN(yv, scale, shift, sl, link)

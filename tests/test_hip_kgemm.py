@@ -187,3 +187,45 @@ def test_fused_batchnorm_chains_through_kgemm(force, gpu_device, monkeypatch):
         T.test_conv_bn_act_conv_chain(case, True, gpu_device, monkeypatch)
         ran += 1
     assert ran >= 4
+
+
+def test_batchnorm_finished_inside_the_producer_launch(force, gpu_device, monkeypatch):
+    """movae_fuse_t::fin_* (opt-in: MOVAE_KGEMM_BN_FIN / movae_bench_kgemm_bn_fin): the kgemm forward's last-arriving block per
+    column tile finishes the BatchNorm that follows -- no movae_bn_finalize call.  The fused-BatchNorm chains again with it ON
+    (against PyTorch), and the BatchNorm's saved statistics / affine map / running statistics against the stand-alone finalize
+    on one conv -> BatchNorm pair."""
+    import test_hip_fused_bn as T
+    from movae_amd import _lib as L
+    from movae_amd import nn as mnn
+
+    prev = force.movae_bench_kgemm_bn_fin(1)
+    try:
+        calls = []
+        monkeypatch.setattr(L, "TRACE", lambda name, args: calls.append(name))
+        ran = 0
+        for case in T.CHAINS:
+            name, _, _, B, size, cin, cmid, cout = case
+            if cin % 8 or cmid % 8 or cout % 4:
+                continue
+            T.test_conv_bn_act_conv_chain(case, True, gpu_device, monkeypatch)
+            ran += 1
+        assert ran >= 4
+        assert "movae_bn_finalize" not in calls, "the producer was asked to finish the BatchNorm itself"
+        monkeypatch.setattr(L, "TRACE", None)
+
+        res = {}
+        for on in (1, 0):
+            force.movae_bench_kgemm_bn_fin(on)
+            torch.manual_seed(5)
+            st = mnn.Stack(mnn.Conv2d(64, 96, 3, stride=2, padding=1), mnn.BatchNorm2d(96), mnn.LeakyReLU()).to(gpu_device).train()
+            x = _rnd(24, 8, 8, 64, seed=9).to(gpu_device)
+            out = st(x)
+            res[on] = (out.scale.clone(), out.shift.clone(), st[1].running_mean.clone(), st[1].running_var.clone(),
+                       int(st[1].num_batches_tracked), mnn.ops.materialize(out).clone())
+        for a, b, what in zip(res[1], res[0], ("scale", "shift", "running_mean", "running_var", "num_batches_tracked", "output")):
+            if isinstance(a, int):
+                assert a == b == 1, what
+            else:  # (the two fold the fp64 partial sums in different orders: equal to the last bit or one ulp apart)
+                np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=3e-7, atol=1e-7, err_msg=what)
+    finally:
+        force.movae_bench_kgemm_bn_fin(prev)
