@@ -222,7 +222,7 @@ def cpu_baseline(cfg, seconds, device=None, check_steps=20):
     return out
 
 
-FAMILY = [("conv", "movae_conv"), ("conv", "movae_linear_pair"), ("batchnorm", "movae_bn_"), ("batchnorm", "movae_scale_shift"), ("loss", "movae_recon"), ("loss", "movae_kl"), ("loss", "movae_tc"),
+FAMILY = [("loss", "movae_combine_losses"), ("loss", "movae_vae_losses"), ("conv", "movae_conv"), ("conv", "movae_linear_pair"), ("batchnorm", "movae_bn_"), ("batchnorm", "movae_scale_shift"), ("loss", "movae_recon"), ("loss", "movae_kl"), ("loss", "movae_tc"),
           ("vq", "movae_vq"), ("aggregation", "movae_gram"), ("aggregation", "movae_weights"), ("aggregation", "movae_combine"),
           ("aggregation", "movae_gd_"), ("optimizer", "movae_adam"), ("optimizer", "movae_sumsq"), ("optimizer", "movae_scale_by"),
           ("elementwise", "movae_")]

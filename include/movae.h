@@ -262,6 +262,11 @@ int movae_weights_upgrad(const float* G, int k, float norm_eps, float reg_eps, c
  * (utils/torchmoo/pnupgrad.py:13-24,127-134, main.py:1228); MOVAE_UPGRAD_TRACE is movae_weights_upgrad. */
 int movae_weights_upgrad_norm(const float* G, int k, int norm_mode, float norm_eps, float reg_eps, const float* pref, float* w,
                               movae_stream_t stream);
+/* movae_gram followed by movae_weights_upgrad_norm (dual == 0) or movae_weights_dualproj (dual != 0; norm_mode 0) in two launches
+ * instead of three: the solver kernel folds the Gramian's block partials itself -- the arithmetic of movae_gram's final kernel, so
+ * G [k][k] and w [k] are bit-identical to the two separate calls. */
+int movae_gram_upgrad(const float* J, size_t ldj, int k, size_t m, float* G, int norm_mode, float norm_eps, float reg_eps,
+                      const float* pref, float* w, int dual, void* ws, size_t ws_bytes, movae_stream_t stream);
 /* MGDA Frank-Wolfe (utils/torchmoo/mgda.py:221-367); losses may be NULL for norm NONE/L2. info[0]=iterations */
 int movae_weights_mgda(const float* G, int k, int norm, const float* losses, float epsilon, int max_iters,
                        float* w, int32_t* info, movae_stream_t stream);

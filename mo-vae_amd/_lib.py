@@ -91,6 +91,7 @@ SIGNATURES = {
     "movae_gram": ([_p, _z, _i, _z, _p, _p, _z, _p], _i),
     "movae_weights_upgrad": ([_p, _i, _f, _f, _p, _p, _p], _i),
     "movae_weights_upgrad_norm": ([_p, _i, _i, _f, _f, _p, _p, _p], _i),
+    "movae_gram_upgrad": ([_p, _z, _i, _z, _p, _i, _f, _f, _p, _p, _i, _p, _z, _p], _i),
     "movae_weights_mgda": ([_p, _i, _i, _p, _f, _i, _p, _p, _p], _i),
     "movae_weights_mgda_stable": ([_p, _i, _i, _p, _f, _i, _f, _p, _p, _p], _i),
     "movae_weights_amtl": ([_p, _i, _i, _p, _p, _p], _i),

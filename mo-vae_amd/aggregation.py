@@ -8,6 +8,8 @@ Everything numeric runs in libmovae_hip.so on the current stream: Gramian (one H
 the K x K solve in a single-wave fp64 kernel, combine (second pass).  No host synchronisation --
 the reference's UPGrad round trip to numpy/quadprog and MGDA's per-iteration `.item()` are gone.
 """
+import os
+
 import torch
 import torch.nn as tnn
 
@@ -26,6 +28,10 @@ def _check_matrix(J):
     L.require_gpu(J)
     if J.dtype != torch.float32 or J.stride(1) != 1:
         raise ValueError("the Jacobian must be fp32 with unit column stride")
+
+
+#: MOVAE_FUSE_GRAM=0: the Gramian is finished by its own kernel before the weighting runs (A/B knob)
+FUSE_GRAM = os.environ.get("MOVAE_FUSE_GRAM", "1") != "0"
 
 
 def compute_gramian(J):
@@ -81,8 +87,14 @@ class _FromJacobian(tnn.Module):
         self.gramian_weighting = gramian_weighting
 
     def forward(self, J):
+        gw = self.gramian_weighting
+        fused = getattr(gw, "from_jacobian", None)
+        if fused is not None and FUSE_GRAM and not gw._forward_hooks and not gw._forward_pre_hooks:
+            # the weighting's kernel folds the Gramian's partial sums itself (one launch fewer; same G, same weights)
+            self.last_gramian, w = fused(J)
+            return w
         self.last_gramian = compute_gramian(J)  # kept for aggregators that derive a second weighting from it (COMFORT)
-        return self.gramian_weighting(self.last_gramian)
+        return gw(self.last_gramian)
 
 
 class GramianWeightedAggregator(tnn.Module):
@@ -115,6 +127,19 @@ class UPGradWeighting(Weighting):
         L.call("movae_weights_upgrad_norm", G.data_ptr(), k, L.UPGRAD_NORM[self._mode()], float(self.norm_eps),
                float(self.reg_eps), L.ptr(pref), w.data_ptr(), _st(G))
         return w
+
+    def from_jacobian(self, J):
+        """(G, w) = (J J^T, forward(G)) in two launches (movae_gram_upgrad): the solver kernel finishes the Gramian itself."""
+        _check_matrix(J)
+        k, m = J.shape
+        G = torch.empty((k, k), dtype=torch.float32, device=J.device)
+        w = torch.empty(k, dtype=torch.float32, device=J.device)
+        pref = _pref_tensor(self.pref_vector, J.device)
+        ws = L.workspace(J.device)
+        L.call("movae_gram_upgrad", J.data_ptr(), J.stride(0) if k > 1 else max(J.stride(0), m), k, m, G.data_ptr(),
+               L.UPGRAD_NORM[self._mode()], float(self.norm_eps), float(self.reg_eps), L.ptr(pref), w.data_ptr(), 0, ws.data_ptr(),
+               ws.numel(), _st(J))
+        return G, w
 
 
 class _PNUPGradWeighting(UPGradWeighting):

@@ -167,10 +167,33 @@ __global__ void similarity_final(const double* __restrict__ part, int nblk, floa
 // without compaction: rows / columns outside the free set are replaced by the identity and their right-hand side by 0, which
 // leaves the free block's Cholesky arithmetic untouched and yields v = 0 on the active coordinates.
 template <int KT>
-__global__ __launch_bounds__(64) void upgrad_k(const float* __restrict__ Gin, int norm_mode, float norm_eps, float reg_eps,
-                                               const float* __restrict__ pref, float* __restrict__ wout, int dual) {
+__global__ __launch_bounds__(64) void upgrad_k(const float* __restrict__ Gptr, int norm_mode, float norm_eps, float reg_eps,
+                                               const float* __restrict__ pref, float* __restrict__ wout, int dual,
+                                               const double* __restrict__ gpart, int gnb, float* __restrict__ Gout) {
     constexpr int K = KT;
     const int lane = threadIdx.x;
+    // gpart: the Gramian has not been formed yet -- gram_partial's block partials are folded HERE, entry by entry, in gram_final's
+    // order (lanes stride over the blocks, one wave fold), so the values are gram_final's to the bit; Gout receives them
+    float Gin[K * K];
+    if (gpart) {
+        constexpr int NP = K * (K + 1) / 2;
+        int q = 0;
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+#pragma unroll
+            for (int j = i; j < K; ++j, ++q) {
+                double s = 0.0;
+                for (int b = lane; b < gnb; b += 64) s += gpart[(long)b * NP + q];
+                s = wave_sum(s);
+                Gin[i * K + j] = Gin[j * K + i] = (float)s;
+            }
+        if (lane == 0 && Gout)
+#pragma unroll
+            for (int i = 0; i < K * K; ++i) Gout[i] = Gin[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < K * K; ++i) Gin[i] = Gptr[i];
+    }
     double G[K][K];
     if (norm_mode == 0) {
         double tr = 0.0;
@@ -472,9 +495,9 @@ inline void launch_cagrad(const float* G, int k, float c, float norm_eps, float*
 }
 
 inline void launch_upgrad(const float* G, int k, int norm_mode, float norm_eps, float reg_eps, const float* pref, float* w, int dual,
-                          hipStream_t st) {
+                          hipStream_t st, const double* gpart = nullptr, int gnb = 0, float* Gout = nullptr) {
 #define MOVAE_UPG(KV) \
-    hipLaunchKernelGGL((upgrad_k<KV>), dim3(1), dim3(64), 0, st, G, norm_mode, norm_eps, reg_eps, pref, w, dual)
+    hipLaunchKernelGGL((upgrad_k<KV>), dim3(1), dim3(64), 0, st, G, norm_mode, norm_eps, reg_eps, pref, w, dual, gpart, gnb, Gout)
     switch (k) {
         case 1: MOVAE_UPG(1); break;
         case 2: MOVAE_UPG(2); break;
@@ -795,6 +818,29 @@ int movae_weights_upgrad_norm(const float* G, int k, int norm_mode, float norm_e
     MOVAE_CHECK_ARG(norm_mode >= 0 && norm_mode <= 2, "movae_weights_upgrad: unknown normalisation %d", norm_mode);
     launch_upgrad(G, k, norm_mode, norm_eps, reg_eps, pref, w, 0, (hipStream_t)stream);
     MOVAE_CHECK_LAUNCH("upgrad");
+    return MOVAE_OK;
+}
+
+// movae_gram + movae_weights_upgrad_norm / movae_weights_dualproj in two launches instead of three: the solver kernel folds the
+// Gramian's block partials itself (gram_final's arithmetic) and writes G too.
+int movae_gram_upgrad(const float* J, size_t ldj, int k, size_t m, float* G, int norm_mode, float norm_eps, float reg_eps,
+                      const float* pref, float* w, int dual, void* ws, size_t ws_bytes, movae_stream_t stream) {
+    MOVAE_WS_SCRATCH(ws, ws_bytes);
+    MOVAE_CHECK_ARG(J && G && w && m > 0 && ldj >= m, "movae_gram_upgrad: bad argument");
+    MOVAE_CHECK_ARG(k >= 1 && k <= MAXK, "movae_gram_upgrad: k=%d outside 1..%d", k, MAXK);
+    MOVAE_CHECK_ARG(norm_mode >= 0 && norm_mode <= 2, "movae_gram_upgrad: unknown normalisation %d", norm_mode);
+    MOVAE_CHECK_ARG(ws && ws_bytes >= movae_gram_ws_bytes(k, m), "movae_gram_upgrad: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    double* part = static_cast<double*>(ws);
+    const int nb = gram_blocks(m);
+    const bool vec = (ldj % 4 == 0) && (reinterpret_cast<uintptr_t>(J) & 15) == 0;
+    int rc = MOVAE_EINVAL;
+#define CALL_GRAM(KK) launch_gram_k<KK>(J, ldj, m, part, nb, vec, st)
+    rc = [&]() -> int { DISPATCH_K(k, CALL_GRAM) return MOVAE_EINVAL; }();
+#undef CALL_GRAM
+    if (rc) return rc;
+    launch_upgrad(nullptr, k, norm_mode, norm_eps, reg_eps, pref, w, dual ? 1 : 0, st, part, nb, G);
+    MOVAE_CHECK_LAUNCH("upgrad (with the Gramian's final fold)");
     return MOVAE_OK;
 }
 

@@ -878,3 +878,27 @@ def test_reparameterize_rng_philox_stream_moments_and_backward(M):
     rmu, rlv = torch.autograd.grad(zr, [mu, lv], g)
     assert torch.equal(dmu, rmu)
     np.testing.assert_allclose(dlv.cpu().numpy(), rlv.cpu().numpy(), rtol=1e-4, atol=1e-6)  # (eps_t is eps up to the rounding of the division above)
+
+
+@pytest.mark.parametrize("k", [2, 3, 5])
+@pytest.mark.parametrize("norm", ["trace", "min_l2", "cosine"])
+def test_gram_upgrad_in_two_launches_equals_the_three(M, k, norm):
+    """movae_gram_upgrad (the solver kernel folds the Gramian's block partials itself) against movae_gram + movae_weights_upgrad_norm:
+    the same G and the same weights, bit for bit; the aggregator's `weighting` takes the fused form only without hooks on the inner
+    weighting and reports the same values to hooks on itself."""
+    ops, agg = M
+    J = rnd(k, 300_001, seed=20 + k).cuda()
+    J[1] = 0.3 * J[0] + 0.7 * J[1]  # correlated rows: an active constraint in the dual-cone projection
+    w8 = agg.UPGradWeighting(None, 1e-4, 1e-4, norm=norm)
+    G_ref = agg.compute_gramian(J)
+    w_ref = w8(G_ref)
+    G, w = w8.from_jacobian(J)
+    assert torch.equal(G, G_ref) and torch.equal(w, w_ref)
+    a = agg.UPGrad()
+    seen = []
+    a.weighting.register_forward_hook(lambda mod, inp, out: seen.append(out.clone()))
+    g1 = a(J)
+    h = a.gramian_weighting.register_forward_hook(lambda mod, inp, out: None)  # a hook on the inner weighting: the separate calls
+    g2 = a(J)
+    h.remove()
+    assert torch.equal(g1, g2) and len(seen) == 2 and torch.equal(seen[0], seen[1])
