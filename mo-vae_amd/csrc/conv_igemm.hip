@@ -1255,6 +1255,13 @@ int launch_bwd(const float* X, const float* W, float* Y, const Geom& g, const Ep
     if (is_linear(g) && lin::linear_small_ok(Ml, g.Nn, g.Cr) && g.Nn % 4 == 0 && aligned16(X) && aligned16(W)) {
         MOVAE_NO_NORM("linear (bwd form)");
         float* ys[1] = {Y};
+        if (v2::g_pair_collect) {  // inside a dgrad + wgrad call: planned, launched together with the weight gradient (linear_bwd_k)
+            lin::g_lin_pend.d = lin::make_prob<1>(X, nullptr, W, nullptr, ys, nullptr, 1, 1, 0, ep.bias, nullptr, (int)Ml, g.Nn, g.Cr, ep.act,
+                                                  ep.slope, 0);
+            lin::g_lin_pend.active = true;
+            g_last_kernel = "linear_small_k<NN>";
+            return MOVAE_OK;
+        }
         return (g_last_kernel = "linear_small_k<NN>",
                 lin::launch_linear_small<1>(X, W, ys, nullptr, 1, 0, ep.bias, (int)Ml, g.Nn, g.Cr, ep.act, ep.slope, 0, st));
     }
@@ -1347,6 +1354,13 @@ int launch_wgrad(const float* S, const float* Bg, float* const* dW, int G, long 
         lin::linear_small_ok(g.Cs, g.Cb, (Kl + 3) / 4 * 4) && !g_bench_main_only) {  // reduction = batch rows, any count
         MOVAE_NO_NORM("linear (wgrad)");
         if (colsum_done) *colsum_done = colsum_S != nullptr;
+        if (lin::g_lin_pend.active) {  // the layer's input gradient waits: one launch for both
+            lin::g_lin_pend.active = false;
+            const lin::LinProb wp = lin::make_prob<2>(S, nullptr, Bg, nullptr, dW, colsum_S, G, 1, s_gs, nullptr, nullptr, g.Cs, g.Cb, (int)Kl, 0,
+                                                      0.f, accumulate);
+            g_last_kernel = "linear_bwd_k<false>";
+            return lin::launch_linear_bwd<false>(lin::g_lin_pend.d, wp, st);
+        }
         return (g_last_kernel = "linear_small_k<TN>",
                 lin::launch_linear_small<2>(S, Bg, dW, colsum_S, G, s_gs, nullptr, g.Cs, g.Cb, (int)Kl, 0, 0.f, accumulate, st));
     }
@@ -1694,6 +1708,7 @@ static int pair_calls(bool transposed, int groups, const float* dy, const float*
     static const bool enabled = !getenv("MOVAE_NO_PAIR");
     v2::g_pending.active = false;
     kg::g_kpend.active = false;
+    lin::g_lin_pend.active = false;
     v2::g_pair_collect = enabled;
     g_fuse = FuseCtx();
     fuse_bn_install(const_cast<movae_fuse_t*>(fuse), groups);  // (the dgrad's plan -- also a stashed one -- keeps what it claimed)
@@ -1705,6 +1720,7 @@ static int pair_calls(bool transposed, int groups, const float* dy, const float*
     if (rc) {
         v2::g_pending.active = false;
         kg::g_kpend.active = false;
+        lin::g_lin_pend.active = false;
         return rc;
     }
     size_t used = v2::g_pending.active ? (v2::g_pending.ws_used + 255) / 256 * 256 : 0;
@@ -1722,7 +1738,11 @@ static int pair_calls(bool transposed, int groups, const float* dy, const float*
         const int rc2 = v2::flush_pending((hipStream_t)stream);
         if (!rc) rc = rc2;
     }
-    if (strncmp(g_last_kernel, "igemm2_pair", 11) != 0 && strncmp(g_last_kernel, "kpair_k", 7) != 0) {  // two main launches: movae_bench_last_kernel() names both
+    if (lin::g_lin_pend.active) {  // a linear input gradient whose weight gradient took another kernel
+        const int rc2 = lin::lin_flush((hipStream_t)stream);
+        if (!rc) rc = rc2;
+    }
+    if (strncmp(g_last_kernel, "igemm2_pair", 11) != 0 && strncmp(g_last_kernel, "kpair_k", 7) != 0 && strncmp(g_last_kernel, "linear_bwd_k", 12) != 0) {  // two main launches: movae_bench_last_kernel() names both
         static thread_local char both[128];
         snprintf(both, sizeof(both), "%s + %s", dgrad_kernel, g_last_kernel);
         g_last_kernel = both;
@@ -1785,6 +1805,21 @@ int movae_linear_pair_bwd(int groups, const float* dy1, const float* dy2, const 
     MOVAE_CHECK_ARG(dy1 && dy2 && w1 && w2 && x, "movae_linear_pair_bwd: null pointer");
     if (!linear_pair_ok(groups, m, n, k, dy1, dy2, w1, w2) || (reinterpret_cast<uintptr_t>(x) & 15) != 0) return MOVAE_EUNSUPPORTED;
     const long gs = (long)m * n;  // one cotangent group of dy
+    if (dx && dw1 && dw2 && !g_bench_main_only) {  // both gradients: ONE launch (linear_bwd_k<true>)
+        float* yd[8];
+        float* yw[8];
+        float* cs[8];
+        for (int g = 0; g < groups; ++g) {
+            yd[g] = dx + (long)g * m * k;
+            yw[g] = dw1[g], yw[groups + g] = dw2[g];
+            cs[g] = db1 ? db1[g] : nullptr, cs[groups + g] = db2 ? db2[g] : nullptr;
+            MOVAE_CHECK_ARG(yw[g] && yw[groups + g], "movae_linear_pair_bwd: null weight-gradient destination");
+        }
+        const lin::LinProb dp = lin::make_prob<1>(dy1, dy2, w1, w2, yd, nullptr, groups, groups, gs, nullptr, nullptr, m, k, n, 0, 0.f, 0);
+        const lin::LinProb wp = lin::make_prob<2>(dy1, dy2, x, nullptr, yw, cs, 2 * groups, groups, gs, nullptr, nullptr, n, k, m, 0, 0.f, 0);
+        g_last_kernel = "linear_bwd_k<true>";
+        return lin::launch_linear_bwd<true>(dp, wp, (hipStream_t)stream);
+    }
     if (dx) {  // dx[g] = dy1[g] W1 + dy2[g] W2: [m][n] x [n][k]
         float* ys[8];
         for (int g = 0; g < groups; ++g) ys[g] = dx + (long)g * m * k;

@@ -35,29 +35,42 @@ struct LinPair {
     int G;  // TN: cotangent groups per layer
 };
 
-template <int FORM, bool PAIR = false>  // 0 = NT, 1 = NN, 2 = TN
-__global__ __launch_bounds__(256) void linear_small_k(const float* __restrict__ A, const float* __restrict__ B, LinOut out,
-                                                      const float* __restrict__ bias, int M, int N, int K, int act, float slope,
-                                                      long a_gs, int accumulate, LinPair pr = LinPair{nullptr, nullptr, nullptr, 1}) {
-    __shared__ float red[4][16][64];
-    __shared__ float csum[4][32];
+// one problem of the family, as a launch argument (the backward launches two: linear_bwd_k)
+struct LinProb {
+    const float* A;
+    const float* B;
+    LinOut out;
+    const float* bias;
+    int M, N, K, act;
+    float slope;
+    long a_gs;
+    int accumulate;
+    LinPair pr;
+    int gx, gy, gz;  // the problem's grid
+};
+
+template <int FORM, bool PAIR>  // 0 = NT, 1 = NN, 2 = TN
+__device__ __forceinline__ void linear_small_body(const float* __restrict__ A, const float* __restrict__ B, const LinOut& out,
+                                                  const float* __restrict__ bias, int M, int N, int K, int act, float slope, long a_gs,
+                                                  int accumulate, const LinPair& pr, int bx, int by, int bz, float (*red)[16][64],
+                                                  float (*csum)[32]) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int m0 = bx * 32, n0 = by * 32;
     int slot = wave, nslots = 4;  // this wave's share of the reduction
     if (PAIR) {
         if (FORM == 0) {
-            if (blockIdx.z) B = pr.B2, bias = pr.bias2;
+            if (bz) B = pr.B2, bias = pr.bias2;
         } else if (FORM == 2) {
-            const int layer = blockIdx.z / pr.G;
-            A = (layer ? pr.A2 : A) + (blockIdx.z - layer * pr.G) * a_gs;
+            const int layer = bz / pr.G;
+            A = (layer ? pr.A2 : A) + (bz - layer * pr.G) * a_gs;
         } else {
             const int layer = wave >> 1;
-            A = (layer ? pr.A2 : A) + blockIdx.z * a_gs;
+            A = (layer ? pr.A2 : A) + bz * a_gs;
             if (layer) B = pr.B2;
             slot = wave & 1, nslots = 2;
         }
     } else {
-        A += blockIdx.z * a_gs;  // cotangent group: only the A operand (dy) is per group
+        A += bz * a_gs;  // cotangent group: only the A operand (dy) is per group
     }
     // reduction slice of this wave, in groups of 8
     const int groups = (K + 7) / 8, gper = (groups + nslots - 1) / nslots;
@@ -110,7 +123,7 @@ __global__ __launch_bounds__(256) void linear_small_k(const float* __restrict__ 
         const int row = t >> 3, c4 = (t & 7) * 4;  // 32 rows x 8 column quads
         const int i = (row & 3) + 4 * (row >> 3), hh = (row >> 2) & 1;
         const int m = m0 + row;
-        float* Y = out.y[blockIdx.z];
+        float* Y = out.y[bz];
         if (m < M) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -125,12 +138,39 @@ __global__ __launch_bounds__(256) void linear_small_k(const float* __restrict__ 
             }
         }
     }
-    if (FORM == 2 && blockIdx.y == 0 && t < 32 && m0 + t < M) {
-        float* dbias = out.colsum[blockIdx.z];
+    if (FORM == 2 && by == 0 && t < 32 && m0 + t < M) {
+        float* dbias = out.colsum[bz];
         if (dbias) {
             const float v = (csum[0][t] + csum[1][t]) + (csum[2][t] + csum[3][t]);
             dbias[m0 + t] = accumulate ? dbias[m0 + t] + v : v;
         }
+    }
+}
+
+template <int FORM, bool PAIR = false>
+__global__ __launch_bounds__(256) void linear_small_k(const float* __restrict__ A, const float* __restrict__ B, LinOut out,
+                                                      const float* __restrict__ bias, int M, int N, int K, int act, float slope,
+                                                      long a_gs, int accumulate, LinPair pr = LinPair{nullptr, nullptr, nullptr, 1}) {
+    __shared__ float red[4][16][64];
+    __shared__ float csum[4][32];
+    linear_small_body<FORM, PAIR>(A, B, out, bias, M, N, K, act, slope, a_gs, accumulate, pr, blockIdx.x, blockIdx.y, blockIdx.z, red, csum);
+}
+
+// A linear layer's backward in ONE launch: blocks [0, nd) the input gradient (NN), the rest the weight gradient (TN) -- the two
+// only share read-only operands, and each alone is a few blocks of latency (the dgrad || wgrad pairing of igemm2_pair at the
+// fully connected layers' scale).
+template <bool PAIR>
+__global__ __launch_bounds__(256) void linear_bwd_k(LinProb d, LinProb w, int nd) {
+    __shared__ float red[4][16][64];
+    __shared__ float csum[4][32];
+    int b = blockIdx.x;
+    if (b < nd) {
+        const int bx = b % d.gx, r = b / d.gx;
+        linear_small_body<1, PAIR>(d.A, d.B, d.out, d.bias, d.M, d.N, d.K, d.act, d.slope, d.a_gs, d.accumulate, d.pr, bx, r % d.gy, r / d.gy, red, csum);
+    } else {
+        b -= nd;
+        const int bx = b % w.gx, r = b / w.gx;
+        linear_small_body<2, PAIR>(w.A, w.B, w.out, w.bias, w.M, w.N, w.K, w.act, w.slope, w.a_gs, w.accumulate, w.pr, bx, r % w.gy, r / w.gy, red, csum);
     }
 }
 
@@ -167,6 +207,44 @@ int launch_linear_pair(const float* A, const float* A2, const float* B, const fl
     hipLaunchKernelGGL((linear_small_k<FORM, true>), dim3(ceil_div(M, 32), ceil_div(N, 32), nz), dim3(256), 0, st, A, B, out, bias, M, N, K,
                        0, 0.f, a_gs, 0, LinPair{A2, B2, bias2, G});
     MOVAE_CHECK_LAUNCH("linear_pair");
+    return MOVAE_OK;
+}
+
+template <int FORM>
+inline LinProb make_prob(const float* A, const float* A2, const float* B, const float* B2, float* const* Y, float* const* colsum, int nz,
+                         int G, long a_gs, const float* bias, const float* bias2, int M, int N, int K, int act, float slope, int accumulate) {
+    LinProb p{};
+    p.A = A, p.B = B, p.bias = bias, p.M = M, p.N = N, p.K = K, p.act = act, p.slope = slope, p.a_gs = a_gs, p.accumulate = accumulate;
+    p.pr = LinPair{A2, B2, bias2, G};
+    for (int i = 0; i < 8; ++i) {
+        p.out.y[i] = i < nz ? Y[i] : nullptr;
+        p.out.colsum[i] = (i < nz && colsum) ? colsum[i] : nullptr;
+    }
+    p.gx = ceil_div(M, 32), p.gy = ceil_div(N, 32), p.gz = nz;
+    return p;
+}
+
+template <bool PAIR>
+inline int launch_linear_bwd(const LinProb& d, const LinProb& w, hipStream_t st) {
+    const int nd = d.gx * d.gy * d.gz, nw = w.gx * w.gy * w.gz;
+    hipLaunchKernelGGL((linear_bwd_k<PAIR>), dim3(nd + nw), dim3(256), 0, st, d, w, nd);
+    MOVAE_CHECK_LAUNCH("linear_bwd");
+    return MOVAE_OK;
+}
+
+// a linear layer's input gradient planned inside a dgrad + wgrad call (v2::g_pair_collect), waiting for its weight gradient
+struct LinPending {
+    bool active = false;
+    LinProb d;
+};
+static thread_local LinPending g_lin_pend;
+inline int lin_flush(hipStream_t st) {  // the weight gradient took another kernel: the input gradient goes alone
+    if (!g_lin_pend.active) return MOVAE_OK;
+    g_lin_pend.active = false;
+    const LinProb& d = g_lin_pend.d;
+    hipLaunchKernelGGL((linear_small_k<1>), dim3(d.gx, d.gy, d.gz), dim3(256), 0, st, d.A, d.B, d.out, d.bias, d.M, d.N, d.K, d.act, d.slope,
+                       d.a_gs, d.accumulate, d.pr);
+    MOVAE_CHECK_LAUNCH("linear_small (unpaired input gradient)");
     return MOVAE_OK;
 }
 
