@@ -640,7 +640,8 @@ inline void launch_k(const KArgs& a, KSplit k, dim3 tiles, hipStream_t st) {
 // ---- one launch, two problems (see v2::igemm2_pair): blocks [0, nd) run a stashed kgemm input gradient (four waves, KS = 4),
 // the rest the tiled weight gradient of the same layer.  The two share read-only operands only.
 template <int FORM, int WBM, int WBN>
-__global__ __launch_bounds__(256) void kpair_k(KArgs ka, v2::WgArgs wa, int nd, int dgx, int dgy, int wgx, int wgy, int nw, RSide sd) {
+__global__ __launch_bounds__(256) void kpair_k(KArgs ka, v2::WgArgs wa, int nd, int dgx, int dgy, int wgx, int wgy, int nw, RSide sd,
+                                               int wfirst) {
     constexpr int DF = smem_floats<4>(), WF = v2::WgSmem<WBM, WBN>::FLOATS;
     __shared__ __attribute__((aligned(16))) float smem[DF > WF ? DF : WF];
     int b = blockIdx.x;
@@ -648,6 +649,7 @@ __global__ __launch_bounds__(256) void kpair_k(KArgs ka, v2::WgArgs wa, int nd, 
         side_reduce(sd, b - nd - nw, smem);
         return;
     }
+    if (wfirst) b = b < nw ? nd + b : b - nw;  // the weight gradient's (longer) blocks are dispatched first (v2::pair_order)
     if (b < nd) {
         const int bx = b % dgx, r = b / dgx;
         kgemm_body<FORM, 4, 4, false>(ka, smem, bx, r % dgy, r / dgy);
@@ -684,7 +686,7 @@ inline int kpend_pair(const v2::WgArgs& wa, int wgx, int wgy, int wgz, bool w64,
     const int nd = p.tiles.x * p.tiles.y * p.tiles.z, nw = wgx * wgy * wgz;
     const RSide sd = defer_take(st);  // the previous layer's parked weight-gradient reduce rides behind the two problems
     const dim3 grid(nd + nw + sd.nblk);
-#define MOVAE_KP(F_, BM_, BN_) hipLaunchKernelGGL((kpair_k<F_, BM_, BN_>), grid, dim3(256), 0, st, p.a, wa, nd, (int)p.tiles.x, (int)p.tiles.y, wgx, wgy, nw, sd)
+#define MOVAE_KP(F_, BM_, BN_) hipLaunchKernelGGL((kpair_k<F_, BM_, BN_>), grid, dim3(256), 0, st, p.a, wa, nd, (int)p.tiles.x, (int)p.tiles.y, wgx, wgy, nw, sd, v2::pair_order() == 2 ? 1 : 0)
     if (p.form == 0 && w64) {
         MOVAE_KP(0, 64, 64);
         g_last_kernel = "kpair_k<0,64,64>";
