@@ -54,4 +54,4 @@ class OracleTrainer:
             p.grad = grads[n].detach().clone() if n in grads else None
         self.opt.step()
         self.last = dict(out=out, losses=ld, grads=grads, info=info)
-        return {k: float(v) for k, v in ld.items()}
+        return {k: float(v.detach()) if hasattr(v, "detach") else float(v) for k, v in ld.items()}
