@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256) void igemm2_fwd(FwdArgs a, RSide sd, int gz, i
         return;
     }
     int bx = blockIdx.x, by = blockIdx.y;
-    xcd_tile(xr, bx, by);
+    xcd_tile(xr & 1, bx, by);
     igemm2_fwd_body<BM, BN, BF>(a, smem, bx, by, blockIdx.z);
 }
 
@@ -1012,8 +1012,10 @@ __global__ __launch_bounds__(256) void igemm2_bwd(BwdArgs a, RSide sd, int gz, i
         return;
     }
     int bx = blockIdx.x, by = blockIdx.y;
-    xcd_tile(xr, bx, by);
-    igemm2_bwd_body<BM, BN, BF>(a, smem, bx, by, blockIdx.z);
+    xcd_tile(xr & 1, bx, by);
+    // (xr & 2: the (class, split) pairs in REVERSE order -- the last output-parity class of a 3x3 stride-2 layer carries 4 of the 9
+    // taps, the first one 1: blocks are dispatched in index order, and the long ones should not be the tail; cls_order())
+    igemm2_bwd_body<BM, BN, BF>(a, smem, bx, by, (xr & 2) ? gz - 1 - (int)blockIdx.z : (int)blockIdx.z);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1321,7 +1323,7 @@ __global__ __launch_bounds__(256) void igemm2_wgrad(WgArgs a, RSide sd, int gz, 
         return;
     }
     int bx = blockIdx.x, by = blockIdx.y;
-    xcd_tile(xr, bx, by);
+    xcd_tile(xr & 1, bx, by);
     igemm2_wgrad_body<BM, BN, BF>(a, smem, bx, by, blockIdx.z);
 }
 
@@ -1341,6 +1343,8 @@ __global__ __launch_bounds__(256) void igemm2_pair(FwdArgs fa, BwdArgs ba, WgArg
         side_reduce(sd, b - nd - nw, smem);
         return;
     }
+    const int rev = inter >> 2;  // (bit 2: cls_order())
+    inter &= 3;
     if (inter == 2) {  // weight-gradient blocks first
         b = b < nw ? nd + b : b - nw;
     } else if (inter) {  // alternate the two problems' blocks while both last (the dispatcher hands out blocks in index order)
@@ -1353,7 +1357,7 @@ __global__ __launch_bounds__(256) void igemm2_pair(FwdArgs fa, BwdArgs ba, WgArg
         if (FORM == 0)
             igemm2_fwd_body<ABM, ABN>(fa, smem, bx, r % dgy, r / dgy);
         else
-            igemm2_bwd_body<ABM, ABN>(ba, smem, bx, r % dgy, r / dgy);
+            igemm2_bwd_body<ABM, ABN>(ba, smem, bx, r % dgy, rev ? nd / (dgx * dgy) - 1 - r / dgy : r / dgy);  // (cls_order())
     } else {
         b -= nd;
         const int bx = b % wgx, r = b / wgx;
@@ -1433,6 +1437,13 @@ inline int finish_pending(hipStream_t st) {  // the stashed dgrad's reduce
     return MOVAE_OK;
 }
 
+// MOVAE_CLS_ORDER=1: a BWD-form launch enumerates its (class, split) pairs last class first (bit 1 of the kernels' `xr`).  Measured
+// neutral (C2 0.759 vs 0.768 ms, inside the noise; C1, C5 level: the per-class split factors already balance the classes): off.
+inline int cls_order() {
+    static const int v = getenv("MOVAE_CLS_ORDER") ? atoi(getenv("MOVAE_CLS_ORDER")) : 0;
+    return v ? 2 : 0;
+}
+
 // MOVAE_XCD_REMAP: 1 = XCD-aware tile map (xcd_tile) for launches of at least 64 tiles per z slice, 0 = tile = block id
 inline int xcd_remap(const dim3& grid) {
     static const int mode = getenv("MOVAE_XCD_REMAP") ? atoi(getenv("MOVAE_XCD_REMAP")) : 0;
@@ -1452,8 +1463,8 @@ inline int flush_pending(hipStream_t st) {  // launch the stashed dgrad on its o
         if (p.bm == 64) hipLaunchKernelGGL((igemm2_fwd<64, 64>), grid, dim3(256), 0, st, p.fa, sd, gz, xcd_remap(grid));
         else hipLaunchKernelGGL((igemm2_fwd<128, 32>), grid, dim3(256), 0, st, p.fa, sd, gz, xcd_remap(grid));
     } else {
-        if (p.bm == 64) hipLaunchKernelGGL((igemm2_bwd<64, 64>), grid, dim3(256), 0, st, p.ba, sd, gz, xcd_remap(grid));
-        else hipLaunchKernelGGL((igemm2_bwd<128, 32>), grid, dim3(256), 0, st, p.ba, sd, gz, xcd_remap(grid));
+        if (p.bm == 64) hipLaunchKernelGGL((igemm2_bwd<64, 64>), grid, dim3(256), 0, st, p.ba, sd, gz, xcd_remap(grid) | cls_order());
+        else hipLaunchKernelGGL((igemm2_bwd<128, 32>), grid, dim3(256), 0, st, p.ba, sd, gz, xcd_remap(grid) | cls_order());
     }
     MOVAE_CHECK_LAUNCH("igemm2 dgrad (unpaired)");
     return finish_pending(st);
@@ -1661,8 +1672,8 @@ int launch_bwd2(const float* X, const float* W, float* Y, const Geom& g, const E
     dim3 grid(gx, gy, zsum);
     int gz;
     const RSide sd = defer_take_3d(st, &grid, &gz);
-    if (BM == 128 && BN == 128 && g_compute_bf16) hipLaunchKernelGGL((igemm2_bwd<BM, BN, BM == 128 && BN == 128>), grid, dim3(256), 0, st, a, sd, gz, xcd_remap(grid));
-    else hipLaunchKernelGGL((igemm2_bwd<BM, BN>), grid, dim3(256), 0, st, a, sd, gz, xcd_remap(grid));
+    if (BM == 128 && BN == 128 && g_compute_bf16) hipLaunchKernelGGL((igemm2_bwd<BM, BN, BM == 128 && BN == 128>), grid, dim3(256), 0, st, a, sd, gz, xcd_remap(grid) | cls_order());
+    else hipLaunchKernelGGL((igemm2_bwd<BM, BN>), grid, dim3(256), 0, st, a, sd, gz, xcd_remap(grid) | cls_order());
     MOVAE_CHECK_LAUNCH("igemm2_bwd");
     if (Sreal > 1 && !g_bench_main_only) {
         if (rbb.y) {
@@ -1694,7 +1705,7 @@ inline int pair_order() {
 template <int FORM, int ABM, int ABN, int WBM, int WBN>
 inline void launch_pair(const PendingDgrad& p, const WgArgs& wa, int wgx, int wgy, int wgz, hipStream_t st) {
     const int nd = p.gx * p.gy * p.gz, nw = wgx * wgy * wgz;
-    const int inter = pair_order();
+    const int inter = pair_order() | (cls_order() ? 4 : 0);
     const RSide sd = defer_take(st);  // the previous layer's parked weight-gradient reduce rides behind the two problems
     hipLaunchKernelGGL((igemm2_pair<FORM, ABM, ABN, WBM, WBN>), dim3(nd + nw + sd.nblk), dim3(256), 0, st, p.fa, p.ba, wa, nd, p.gx, p.gy,
                        wgx, wgy, nw, inter, sd);

@@ -392,14 +392,14 @@ __device__ __forceinline__ void kgemm_body(const KArgs& a, float* __restrict__ s
 }
 
 template <int FORM, int NW, int KS, bool NRM>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void kgemm_k(KArgs a, RSide sd, int gz) {
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void kgemm_k(KArgs a, RSide sd, int gz, int rev) {
     __shared__ __attribute__((aligned(16))) float smem[smem_floats<NW>()];
     if (NW == 4 && (int)blockIdx.z >= gz) {  // a parked weight-gradient reduce rides behind this launch's own blocks (conv_igemm.hip: RSide)
         const int bid = (((int)blockIdx.z - gz) * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
         if (bid < sd.nblk) side_reduce(sd, bid, smem);
         return;
     }
-    kgemm_body<FORM, NW, KS, NRM>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+    kgemm_body<FORM, NW, KS, NRM>(a, smem, blockIdx.x, blockIdx.y, (FORM == 1 && rev) ? gz - 1 - (int)blockIdx.z : (int)blockIdx.z);  // (v2::cls_order())
 }
 
 // ---- weight gradient: dW[a][tap][b] = sum_p S[p][a] * Bg[p * s - pad + tap][b]   (M = Cs, N = taps * Cb) ------------------------
@@ -619,7 +619,7 @@ inline void launch_k2(const KArgs& a, KSplit k, dim3 tiles, hipStream_t st) {  /
     if (k.ks == 8) {
         KArgs b8 = a;
         b8.fin.group = (int)(tiles.x * tiles.z);
-        hipLaunchKernelGGL((kgemm_k<FORM, 8, 8, NRM>), tiles, dim3(512), 0, st, b8, RSide{}, (int)tiles.z);
+        hipLaunchKernelGGL((kgemm_k<FORM, 8, 8, NRM>), tiles, dim3(512), 0, st, b8, RSide{}, (int)tiles.z, v2::cls_order());
         return;
     }
     dim3 grid = k.ks == 4 ? tiles : k.ks == 2 ? dim3((tiles.x + 1) / 2, tiles.y, tiles.z) : dim3((tiles.x + 3) / 4, tiles.y, tiles.z);
@@ -627,9 +627,9 @@ inline void launch_k2(const KArgs& a, KSplit k, dim3 tiles, hipStream_t st) {  /
     b.fin.group = (int)(grid.x * grid.z);  // blocks per column tile (before any carried reduce's extra z layers)
     int gz;
     const RSide sd = defer_take_3d(st, &grid, &gz);
-    if (k.ks == 4) hipLaunchKernelGGL((kgemm_k<FORM, 4, 4, NRM>), grid, dim3(256), 0, st, b, sd, gz);
-    else if (k.ks == 2) hipLaunchKernelGGL((kgemm_k<FORM, 4, 2, NRM>), grid, dim3(256), 0, st, b, sd, gz);
-    else hipLaunchKernelGGL((kgemm_k<FORM, 4, 1, NRM>), grid, dim3(256), 0, st, b, sd, gz);
+    if (k.ks == 4) hipLaunchKernelGGL((kgemm_k<FORM, 4, 4, NRM>), grid, dim3(256), 0, st, b, sd, gz, v2::cls_order());
+    else if (k.ks == 2) hipLaunchKernelGGL((kgemm_k<FORM, 4, 2, NRM>), grid, dim3(256), 0, st, b, sd, gz, v2::cls_order());
+    else hipLaunchKernelGGL((kgemm_k<FORM, 4, 1, NRM>), grid, dim3(256), 0, st, b, sd, gz, v2::cls_order());
 }
 template <int FORM>
 inline void launch_k(const KArgs& a, KSplit k, dim3 tiles, hipStream_t st) {
@@ -649,10 +649,10 @@ __global__ __launch_bounds__(256) void kpair_k(KArgs ka, v2::WgArgs wa, int nd, 
         side_reduce(sd, b - nd - nw, smem);
         return;
     }
-    if (wfirst) b = b < nw ? nd + b : b - nw;  // the weight gradient's (longer) blocks are dispatched first (v2::pair_order)
+    if (wfirst & 1) b = b < nw ? nd + b : b - nw;  // the weight gradient's (longer) blocks are dispatched first (v2::pair_order; bit 1: cls_order)
     if (b < nd) {
         const int bx = b % dgx, r = b / dgx;
-        kgemm_body<FORM, 4, 4, false>(ka, smem, bx, r % dgy, r / dgy);
+        kgemm_body<FORM, 4, 4, false>(ka, smem, bx, r % dgy, (FORM == 1 && (wfirst & 2)) ? nd / (dgx * dgy) - 1 - r / dgy : r / dgy);
     } else {
         b -= nd;
         const int bx = b % wgx, r = b / wgx;
@@ -686,7 +686,7 @@ inline int kpend_pair(const v2::WgArgs& wa, int wgx, int wgy, int wgz, bool w64,
     const int nd = p.tiles.x * p.tiles.y * p.tiles.z, nw = wgx * wgy * wgz;
     const RSide sd = defer_take(st);  // the previous layer's parked weight-gradient reduce rides behind the two problems
     const dim3 grid(nd + nw + sd.nblk);
-#define MOVAE_KP(F_, BM_, BN_) hipLaunchKernelGGL((kpair_k<F_, BM_, BN_>), grid, dim3(256), 0, st, p.a, wa, nd, (int)p.tiles.x, (int)p.tiles.y, wgx, wgy, nw, sd, v2::pair_order() == 2 ? 1 : 0)
+#define MOVAE_KP(F_, BM_, BN_) hipLaunchKernelGGL((kpair_k<F_, BM_, BN_>), grid, dim3(256), 0, st, p.a, wa, nd, (int)p.tiles.x, (int)p.tiles.y, wgx, wgy, nw, sd, (v2::pair_order() == 2 ? 1 : 0) | v2::cls_order())
     if (p.form == 0 && w64) {
         MOVAE_KP(0, 64, 64);
         g_last_kernel = "kpair_k<0,64,64>";
