@@ -1709,6 +1709,7 @@ static int pair_calls(bool transposed, int groups, const float* dy, const float*
     v2::g_pending.active = false;
     kg::g_kpend.active = false;
     lin::g_lin_pend.active = false;
+    thin::g_thin_pend.active = false;
     v2::g_pair_collect = enabled;
     g_fuse = FuseCtx();
     fuse_bn_install(const_cast<movae_fuse_t*>(fuse), groups);  // (the dgrad's plan -- also a stashed one -- keeps what it claimed)
@@ -1721,6 +1722,7 @@ static int pair_calls(bool transposed, int groups, const float* dy, const float*
         v2::g_pending.active = false;
         kg::g_kpend.active = false;
         lin::g_lin_pend.active = false;
+        thin::g_thin_pend.active = false;
         return rc;
     }
     size_t used = v2::g_pending.active ? (v2::g_pending.ws_used + 255) / 256 * 256 : 0;
@@ -1742,7 +1744,11 @@ static int pair_calls(bool transposed, int groups, const float* dy, const float*
         const int rc2 = lin::lin_flush((hipStream_t)stream);
         if (!rc) rc = rc2;
     }
-    if (strncmp(g_last_kernel, "igemm2_pair", 11) != 0 && strncmp(g_last_kernel, "kpair_k", 7) != 0 && strncmp(g_last_kernel, "linear_bwd_k", 12) != 0) {  // two main launches: movae_bench_last_kernel() names both
+    if (thin::g_thin_pend.active) {  // likewise a thin-channel input gradient
+        const int rc2 = thin::thin_flush((hipStream_t)stream);
+        if (!rc) rc = rc2;
+    }
+    if (strncmp(g_last_kernel, "igemm2_pair", 11) != 0 && strncmp(g_last_kernel, "kpair_k", 7) != 0 && strncmp(g_last_kernel, "linear_bwd_k", 12) != 0 && strncmp(g_last_kernel, "thin_pair_k", 11) != 0) {  // two main launches: movae_bench_last_kernel() names both
         static thread_local char both[128];
         snprintf(both, sizeof(both), "%s + %s", dgrad_kernel, g_last_kernel);
         g_last_kernel = both;

@@ -19,10 +19,11 @@ namespace thin {
 // applied) and are one contiguous 32 KiB run of Y.  BatchNorm statistics / backward sums of the tile, the ActMul factor, then stores of
 // 1 KiB per wave instead of 64 scattered 16-byte pieces.
 __device__ __forceinline__ void thin_in_tile_out(float* __restrict__ Wl, float* __restrict__ Y, int M, int t, float* __restrict__ stats,
-                                                 const BnBwd& bb, const ActMul& am, int N = 32, int n0 = 0) {
+                                                 const BnBwd& bb, const ActMul& am, int N, int n0, int bx) {
+    // bx: the block's index among the 256-pixel blocks (bx, or its place in a paired launch)
     // N > 32: the tile is columns n0 .. n0 + 31 of 256 rows of N floats (128-byte row segments; statistics / backward sums: N == 32 only)
-    float* yb = Y + (long)blockIdx.x * 256 * N + n0;
-    const long rows_left = (long)M - (long)blockIdx.x * 256;
+    float* yb = Y + (long)bx * 256 * N + n0;
+    const long rows_left = (long)M - (long)bx * 256;
     if (stats) {
         // column statistics of the block's 256 x 32 tile for the BatchNorm that follows (the tile sits in LDS anyway):
         // thread t sums channel t & 31 over rows 32 * (t >> 5) ..+31 (stride 33: conflict-free), the two row groups of a
@@ -38,7 +39,7 @@ __device__ __forceinline__ void thin_in_tile_out(float* __restrict__ Wl, float* 
         sm += __shfl_xor(sm, 32, 64);
         sq += __shfl_xor(sq, 32, 64);
         if ((t & 63) < 32) {
-            const long pidx = (long)blockIdx.x * 4 + (t >> 6);
+            const long pidx = (long)bx * 4 + (t >> 6);
             stats[(pidx * 2 + 0) * 32 + c] = sm;
             stats[(pidx * 2 + 1) * 32 + c] = sq;
         }
@@ -48,7 +49,7 @@ __device__ __forceinline__ void thin_in_tile_out(float* __restrict__ Wl, float* 
         // block's 256 rows never straddle two cotangent groups (host).  Each load instruction covers two whole 128-byte rows.
         const int c = t & 31, r0 = (t >> 5) * 32;
         const float sc = bb.scale[c], sh_ = bb.shift[c];
-        const float* yb_ = bb.y + ((long)blockIdx.x * 256 % bb.rows_per_group) * 32;
+        const float* yb_ = bb.y + ((long)bx * 256 % bb.rows_per_group) * 32;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int rb = 0; rb < 32; rb += 16) {  // sixteen loads of y in flight (one per trip paid an L2 round trip per row: 13 us at C2)
@@ -67,7 +68,7 @@ __device__ __forceinline__ void thin_in_tile_out(float* __restrict__ Wl, float* 
         s1 += __shfl_xor(s1, 32, 64);
         s2 += __shfl_xor(s2, 32, 64);
         if ((t & 63) < 32) {
-            const long pidx = (long)blockIdx.x * 4 + (t >> 6);
+            const long pidx = (long)bx * 4 + (t >> 6);
             bb.part[(pidx * 2 + 0) * 32 + c] = s1;
             bb.part[(pidx * 2 + 1) * 32 + c] = s2;
         }
@@ -83,7 +84,7 @@ __device__ __forceinline__ void thin_in_tile_out(float* __restrict__ Wl, float* 
             for (int j = 0; j < 4; ++j) {
                 const int i = h * 4 + j;
                 const int idx = i * 256 + t, px = idx >> 3, q = idx & 7;
-                const long o = ((long)blockIdx.x * 256 + px) * N + n0 + q * 4;
+                const long o = ((long)bx * 256 + px) * N + n0 + q * 4;
                 const bool ok = px < rows_left;
                 y4[j] = (ok && am.y) ? *reinterpret_cast<const f32x4*>(am.y + o % am.per_group) : f32x4{0.f, 0.f, 0.f, 0.f};
                 r4[j] = (ok && am.res) ? *reinterpret_cast<const f32x4*>(am.res + o) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256) void thin_in_k(const float* __restrict__ X, co
 #pragma unroll
         for (int n = 0; n < NN; ++n) Wl[t * 33 + n] = apply_act(acc[n], act, slope);
         __syncthreads();
-        thin_in_tile_out(Wl, Y, M, t, stats, bb, am);
+        thin_in_tile_out(Wl, Y, M, t, stats, bb, am, 32, 0, blockIdx.x);
         return;
     }
     if (!live) return;
@@ -208,16 +209,34 @@ __global__ __launch_bounds__(256) void thin_in_k(const float* __restrict__ X, co
 // (3 floats per pixel: lanes are consecutive pixels, stride 3 or 6 floats): address = pixel corner + a lane-half constant per step.
 // ~30x less LDS traffic than the VALU form; K / 2 MFMAs per 32 pixels.  A block owns 256 consecutive output pixels of one image --
 // whole rows or a row segment (host) -- and leaves through thin_in_tile_out like thin_in_k.  BWD: stride 1 only.
+struct ThinInArgs {  // thin_in_mfma_k's arguments (a paired launch carries them as one struct)
+    const float* X;
+    const float* W;
+    const float* bias;
+    float* Y;
+    Geom g;
+    int M, act;
+    float slope;
+    float* stats;
+    BnBwd bb;
+    ActMul am;
+    int ncols, RH, RW;
+    FastDiv fd_row, fd3, fd_ncols, fd_hw, fd_wo;
+    int gx, gy;        // the launch's grid
+    unsigned lds_bytes;
+};
+
 template <int KH, int KW, bool BWD>
-__global__ __launch_bounds__(256) void thin_in_mfma_k(const float* __restrict__ X, const float* __restrict__ W,
-                                                      const float* __restrict__ bias, float* __restrict__ Y, Geom g, int M, int act,
-                                                      float slope, float* __restrict__ stats, BnBwd bb, ActMul am, int ncols, int RH,
-                                                      int RW, FastDiv fd_row, FastDiv fd3, FastDiv fd_ncols, FastDiv fd_hw, FastDiv fd_wo) {
+__device__ __forceinline__ void thin_in_mfma_body(const float* __restrict__ X, const float* __restrict__ W,
+                                                  const float* __restrict__ bias, float* __restrict__ Y, const Geom& g, int M, int act,
+                                                  float slope, float* __restrict__ stats, const BnBwd& bb, const ActMul& am, int ncols, int RH,
+                                                  int RW, FastDiv fd_row, FastDiv fd3, FastDiv fd_ncols, FastDiv fd_hw, FastDiv fd_wo, int bx,
+                                                  int by) {
     constexpr int TC = 3, TAPS = KH * KW, K = TAPS * TC, KS = (K + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) float Wl[];  // input region [RH][RW * 3], then the output tile [256][33]
     const int t = threadIdx.x, lane = t & 63, half = lane >> 5, l31 = lane & 31, wave = t >> 6;
-    const int N = g.Nn, n0 = blockIdx.y * 32;  // N % 32 == 0 (host): a block computes 32 of the N outputs of its 256 pixels
-    const int p0 = blockIdx.x * 256, hw = g.Ho * g.Wo;
+    const int N = g.Nn, n0 = by * 32;  // N % 32 == 0 (host): a block computes 32 of the N outputs of its 256 pixels
+    const int p0 = bx * 256, hw = g.Ho * g.Wo;
     const int img = fdiv(p0, fd_hw), rem = p0 - img * hw;
     const int ho0 = fdiv(rem, fd_wo), wo0 = rem - ho0 * g.Wo;
     const int s = g.stride;
@@ -299,7 +318,16 @@ __global__ __launch_bounds__(256) void thin_in_mfma_k(const float* __restrict__ 
     __syncthreads();
     // (Loading the ActMul factor's source ahead of the staging / MFMA phase was measured slower: 32 more registers, three waves per SIMD,
     // 211 vs 176 us on the C5 layer.)
-    thin_in_tile_out(Wl, Y, M, t, stats, bb, am, N, n0);
+    thin_in_tile_out(Wl, Y, M, t, stats, bb, am, N, n0, bx);
+}
+
+template <int KH, int KW, bool BWD>
+__global__ __launch_bounds__(256) void thin_in_mfma_k(const float* __restrict__ X, const float* __restrict__ W,
+                                                      const float* __restrict__ bias, float* __restrict__ Y, Geom g, int M, int act,
+                                                      float slope, float* __restrict__ stats, BnBwd bb, ActMul am, int ncols, int RH,
+                                                      int RW, FastDiv fd_row, FastDiv fd3, FastDiv fd_ncols, FastDiv fd_hw, FastDiv fd_wo) {
+    thin_in_mfma_body<KH, KW, BWD>(X, W, bias, Y, g, M, act, slope, stats, bb, am, ncols, RH, RW, fd_row, fd3, fd_ncols, fd_hw, fd_wo,
+                                   blockIdx.x, blockIdx.y);
 }
 
 // ---- thin output side (FWD gather) -----------------------------------------------------------------
@@ -997,19 +1025,35 @@ __global__ __launch_bounds__(256) void thin_wgrad_sweep_k(const float* __restric
 // MFMAs where the sweep kernel issued (1 + TAPS) reads per TAPS * TC FMAs and was bound by the LDS return bandwidth of its
 // broadcast ds_read_b128 (C5 first layer, 4x4 taps: 217 us for 92 MB of operands).  Same tiling, staging, slab row per block and
 // deterministic reduce as the sweep kernel; the four waves take every fourth pixel pair and fold through LDS.
+struct ThinWgArgs {  // thin_wgrad_mfma_k's arguments (a paired launch carries them as one struct)
+    const float* Wide;
+    const float* Thin;
+    float* slab;
+    int Hw, Ww, Cw, Ht, Wt, stride, pad, TH, TW, tiles_h, tiles_w, Cs, Cb;
+    long wide_gs, thin_gs, slab_gs;
+    Norm nrm;
+    int ntiles;
+    FastDiv fd_tw, fd_bw;
+    int cs_on;
+    long row_stride;
+    int gx, gy, gz;    // the launch's grid
+    unsigned lds_bytes;
+};
+
 template <int TC, int KH, int KW, bool REV>
-__global__ __launch_bounds__(256) void thin_wgrad_mfma_k(const float* __restrict__ Wide, const float* __restrict__ Thin,
-                                                         float* __restrict__ slab, int Hw, int Ww, int Cw, int Ht, int Wt,
-                                                         int stride, int pad, int TH, int TW, int tiles_h, int tiles_w,
-                                                         int Cs, int Cb, long wide_gs, long thin_gs, long slab_gs, Norm nrm, int ntiles,
-                                                         FastDiv fd_tw, FastDiv fd_bw, int cs_on, long row_stride) {
+__device__ __forceinline__ void thin_wgrad_mfma_body(const float* __restrict__ Wide, const float* __restrict__ Thin,
+                                                     float* __restrict__ slab, int Hw, int Ww, int Cw, int Ht, int Wt,
+                                                     int stride, int pad, int TH, int TW, int tiles_h, int tiles_w,
+                                                     int Cs, int Cb, long wide_gs, long thin_gs, long slab_gs, const Norm& nrm, int ntiles,
+                                                     FastDiv fd_tw, FastDiv fd_bw, int cs_on, long row_stride, int bx, int by, int bz,
+                                                     int gdx) {
     // cs_on (REV, the two images equally large: host): the column sums of the thin operand -- the bias gradient when it is dy --
     // ride along: the blockIdx.y == 0 blocks add up the pixels their tiles own while they stage them; TC floats behind the slab row
     constexpr int TAPS = KH * KW, NA = TAPS * TC, NT = (NA + 31) / 32;
     static_assert(NT <= 2, "at most 64 columns");
-    Wide += blockIdx.z * wide_gs;
-    Thin += blockIdx.z * thin_gs;
-    slab += blockIdx.z * slab_gs;
+    Wide += bz * wide_gs;
+    Thin += bz * thin_gs;
+    slab += bz * slab_gs;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int t = threadIdx.x;
     const int BH = REV ? TH + KH - 1 : (TH - 1) * stride + KH, BW = REV ? TW + KW - 1 : (TW - 1) * stride + KW;
@@ -1017,7 +1061,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_mfma_k(const float* __restrict
     float* wideT = lds;                                 // [npix + 1][32] (one zero pixel behind the tile); reused for the fold
     const int wide_floats = max((npix + 1) * 32, 4 * NT * 1024);
     float* thinF = lds + wide_floats;                   // [BH * BW] pixels padded to 4 channels
-    const int c0 = blockIdx.y * 32;
+    const int c0 = by * 32;
     const int lane = t & 63, half = lane >> 5, l31 = lane & 31, wave = t >> 6;
     // column n = tile * 32 + l31 -> (tap, j): the float offset of that element from the thin pixel under the wide pixel's corner
     int delta[NT];
@@ -1083,11 +1127,11 @@ __global__ __launch_bounds__(256) void thin_wgrad_mfma_k(const float* __restrict
     float csum[TC];
 #pragma unroll
     for (int j = 0; j < TC; ++j) csum[j] = 0.f;
-    const bool cs_here = REV && cs_on && blockIdx.y == 0;
-    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+    const bool cs_here = REV && cs_on && by == 0;
+    if (bx < ntiles) fetch(bx);
     // persistent: the block walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and keeps ONE accumulator set -- one fold, one slab
     // row and one reduce input per block instead of per tile (the per-tile epilogue and the 8192-slab reduce were the cost)
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int tile = bx; tile < ntiles; tile += gdx) {
         __syncthreads();  // the previous tile's readers are done
 #pragma unroll
         for (int u = 0; u < WPF; ++u) {
@@ -1120,7 +1164,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_mfma_k(const float* __restrict
                 }
             }
         }
-        if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);  // in flight under this tile's MFMA loop
+        if (tile + gdx < ntiles) fetch(tile + gdx);  // in flight under this tile's MFMA loop
         __syncthreads();
         // this lane's pixel of the wave's first pair; every step moves on by 8 pixels (4 waves x 2).
         // Host: tile width a power of two, tile a multiple of 32 pixels.  Four pairs per trip -- their 4 * (1 + NT) LDS reads go out back
@@ -1150,7 +1194,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_mfma_k(const float* __restrict
         for (int r = 0; r < 16; ++r) wideT[((wave * NT + u) * 16 + r) * 64 + lane] = acc[u][r];
     __syncthreads();
     const int N = TAPS * Cb;
-    float* out = slab + (long)blockIdx.x * row_stride;
+    float* out = slab + (long)bx * row_stride;
     if (cs_here) {  // wave sums by shuffle, the four waves in fixed order
         __shared__ float csr[4][TC];
 #pragma unroll
@@ -1177,8 +1221,69 @@ __global__ __launch_bounds__(256) void thin_wgrad_mfma_k(const float* __restrict
     }
 }
 
+template <int TC, int KH, int KW, bool REV>
+__global__ __launch_bounds__(256) void thin_wgrad_mfma_k(const float* __restrict__ Wide, const float* __restrict__ Thin,
+                                                         float* __restrict__ slab, int Hw, int Ww, int Cw, int Ht, int Wt,
+                                                         int stride, int pad, int TH, int TW, int tiles_h, int tiles_w,
+                                                         int Cs, int Cb, long wide_gs, long thin_gs, long slab_gs, Norm nrm, int ntiles,
+                                                         FastDiv fd_tw, FastDiv fd_bw, int cs_on, long row_stride) {
+    thin_wgrad_mfma_body<TC, KH, KW, REV>(Wide, Thin, slab, Hw, Ww, Cw, Ht, Wt, stride, pad, TH, TW, tiles_h, tiles_w, Cs, Cb, wide_gs,
+                                          thin_gs, slab_gs, nrm, ntiles, fd_tw, fd_bw, cs_on, row_stride, blockIdx.x, blockIdx.y,
+                                          blockIdx.z, gridDim.x);
+}
+
+// The last conv's backward in ONE launch (a 3-channel output: its input gradient is thin_in_mfma_k's BWD form, its weight gradient
+// thin_wgrad_mfma_k): blocks [0, nw) the weight gradient's persistent blocks (the longer ones: dispatched first), the rest the
+// input gradient's.  The two share read-only operands only; one dynamic LDS allocation, the larger of the two needs.
+template <int K, bool REVV>
+__global__ __launch_bounds__(256) void thin_pair_k(ThinInArgs d, ThinWgArgs w, int nw) {
+    int b = blockIdx.x;
+    if (b < nw) {
+        const int bx = b % w.gx, r = b / w.gx;
+        thin_wgrad_mfma_body<3, K, K, REVV>(w.Wide, w.Thin, w.slab, w.Hw, w.Ww, w.Cw, w.Ht, w.Wt, w.stride, w.pad, w.TH, w.TW, w.tiles_h,
+                                            w.tiles_w, w.Cs, w.Cb, w.wide_gs, w.thin_gs, w.slab_gs, w.nrm, w.ntiles, w.fd_tw, w.fd_bw,
+                                            w.cs_on, w.row_stride, bx, r % w.gy, r / w.gy, w.gx);
+    } else {
+        b -= nw;
+        thin_in_mfma_body<K, K, true>(d.X, d.W, d.bias, d.Y, d.g, d.M, d.act, d.slope, d.stats, d.bb, d.am, d.ncols, d.RH, d.RW, d.fd_row,
+                                      d.fd3, d.fd_ncols, d.fd_hw, d.fd_wo, b % d.gx, b / d.gx);
+    }
+}
+
+// an input gradient of the thin MFMA form planned inside a dgrad + wgrad call (v2::g_pair_collect), waiting for its weight gradient
+struct ThinPending {
+    bool active = false;
+    int k = 3;
+    ThinInArgs d;
+};
+static thread_local ThinPending g_thin_pend;
+
 // ---- host side ---------------------------------------------------------------------------------------
 inline bool thin_in_ok(const Geom& g) { return g.Cr <= 4 && g.Nn >= 8 && g.KH * g.KW * g.Cr * 64 * 4 <= 48 * 1024; }
+
+// MOVAE_THIN_PAIR=1: the last conv's input gradient and weight gradient in one launch (thin_pair_k).  OFF by default: measured level
+// at C1-C4 (C2 0.766 vs 0.762 ms, C1 0.576 vs 0.579) and 1.3 % slower at C5 (5.49 vs 5.42 ms: the pair takes the larger of the two
+// LDS needs for every block, and these two HBM-bound kernels do not overlap the way two latency-bound ones do).
+inline bool thin_pair_on() {
+    static const bool v = getenv("MOVAE_THIN_PAIR") && atoi(getenv("MOVAE_THIN_PAIR")) != 0;
+    return v;
+}
+
+inline int thin_flush(hipStream_t st) {  // the weight gradient took another kernel: the planned input gradient goes alone
+    ThinPending& p = g_thin_pend;
+    if (!p.active) return MOVAE_OK;
+    p.active = false;
+    const ThinInArgs& d = p.d;
+    const dim3 grid(d.gx, d.gy);
+    if (p.k == 3)
+        hipLaunchKernelGGL((thin_in_mfma_k<3, 3, true>), grid, dim3(256), d.lds_bytes, st, d.X, d.W, d.bias, d.Y, d.g, d.M, d.act, d.slope,
+                           d.stats, d.bb, d.am, d.ncols, d.RH, d.RW, d.fd_row, d.fd3, d.fd_ncols, d.fd_hw, d.fd_wo);
+    else
+        hipLaunchKernelGGL((thin_in_mfma_k<4, 4, true>), grid, dim3(256), d.lds_bytes, st, d.X, d.W, d.bias, d.Y, d.g, d.M, d.act, d.slope,
+                           d.stats, d.bb, d.am, d.ncols, d.RH, d.RW, d.fd_row, d.fd3, d.fd_ncols, d.fd_hw, d.fd_wo);
+    MOVAE_CHECK_LAUNCH("thin_in_mfma (unpaired input gradient)");
+    return MOVAE_OK;
+}
 
 template <bool BWD>
 int launch_thin_in(const float* X, const float* W, float* Y, const Geom& g, const Epilogue& ep, hipStream_t st) {
@@ -1217,6 +1322,14 @@ int launch_thin_in(const float* X, const float* W, float* Y, const Geom& g, cons
     }
     if (mfma) {
         grid.y = g.Nn / 32;
+        if (BWD && v2::g_pair_collect && thin_pair_on()) {  // inside a dgrad + wgrad call: planned, launched with the weight gradient (thin_pair_k)
+            ThinPending& p = g_thin_pend;
+            p.active = true, p.k = k33 ? 3 : 4;
+            p.d = ThinInArgs{X, W, ep.bias, Y, g, M, ep.act, ep.slope, stats, bb, am, ncols, RH, RW, fastdiv_make(RW * 3), fastdiv_make(3),
+                             fastdiv_make(ncols), fastdiv_make(hw), fastdiv_make(g.Wo), (int)grid.x, (int)grid.y,
+                             (unsigned)(lf * sizeof(float))};
+            return MOVAE_OK;
+        }
 #define MOVAE_TI(K)                                                                                                                \
     hipLaunchKernelGGL((thin_in_mfma_k<K, K, BWD>), grid, dim3(256), lf * sizeof(float), st, X, W, ep.bias, Y, g, M, ep.act, ep.slope,  \
                        stats, bb, am, ncols, RH, RW, fastdiv_make(RW * 3), fastdiv_make(3), fastdiv_make(ncols), fastdiv_make(hw),  \
@@ -1439,7 +1552,19 @@ int launch_thin_wgrad_impl(const float* S, const float* Bg, float* const* dW, in
     hipLaunchKernelGGL((thin_wgrad_mfma_k<3, K, K, REVV>), grid, dim3(256), shb, st, Wd, Tn, slab, Hw, Ww, wide, Ht, Wt, g.stride, \
                        g.pad, TH, TW, tiles_h, tiles_w, g.Cs, g.Cb, wide_gs, thin_gs, slab_gs, wide_nrm, (int)ntiles, fastdiv_make(TW),    \
                        fastdiv_make(thin_small ? TW + g.KW - 1 : (TW - 1) * g.stride + g.KW), cs_on ? 1 : 0, row)
-                if (use_mfma) {
+                if (use_mfma && thin_small && g_thin_pend.active && g_thin_pend.k == (k33 ? 3 : 4)) {
+                    // the layer's input gradient waits: one launch for both (thin_pair_k)
+                    g_thin_pend.active = false;
+                    const ThinInArgs& d = g_thin_pend.d;
+                    const ThinWgArgs w{Wd, Tn, slab, Hw, Ww, wide, Ht, Wt, g.stride, g.pad, TH, TW, tiles_h, tiles_w, g.Cs, g.Cb, wide_gs, thin_gs,
+                                       slab_gs, wide_nrm, (int)ntiles, fastdiv_make(TW), fastdiv_make(TW + g.KW - 1), cs_on ? 1 : 0, row,
+                                       (int)grid.x, (int)grid.y, (int)grid.z, (unsigned)shb};
+                    const int nw = (int)(grid.x * grid.y * grid.z), nd = d.gx * d.gy;
+                    const unsigned lds = d.lds_bytes > (unsigned)shb ? d.lds_bytes : (unsigned)shb;
+                    if (k33) hipLaunchKernelGGL((thin_pair_k<3, true>), dim3(nw + nd), dim3(256), lds, st, d, w, nw);
+                    else hipLaunchKernelGGL((thin_pair_k<4, true>), dim3(nw + nd), dim3(256), lds, st, d, w, nw);
+                    g_last_kernel = k33 ? "thin_pair_k<3,true>" : "thin_pair_k<4,true>";
+                } else if (use_mfma) {
                     if (thin_small) {
                         if (k33) MOVAE_MF(3, true); else MOVAE_MF(4, true);
                     } else {
