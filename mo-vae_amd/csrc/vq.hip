@@ -321,6 +321,90 @@ __global__ __launch_bounds__(256) void vq_embed_final_k(const float* __restrict_
     }
 }
 
+// ---- the (code, row) order without a sort ------------------------------------------------------------------------------------------
+// The radix sort above is seven launches of rocprim for 8-32 k keys.  The order it produces -- codes ascending, rows ascending within a
+// code -- is a counting placement: (1) every block of 256 consecutive rows counts its codes (integer LDS atomics: the counts do not
+// depend on the order of the adds), (2) one block turns the per-block counts into each block's starting offset inside every code's
+// segment and the counts' totals into seg_lo / item_base (what vq_segments_k computes from the sorted keys), (3) every block places
+// its rows: position = seg_lo[code] + offset of the block in that code + number of EARLIER rows of the block with the same code.
+// Three launches, the same `sorted` array to the last element (so the sums below are bit-identical).
+constexpr int VQ_PLACE_MAX_K = 4096;  // codes whose per-block histogram fits the kernels' LDS
+
+__device__ __forceinline__ int vq_code_of(const int64_t* __restrict__ idx, int r, int K) {
+    long c = idx[r];
+    return (int)(c < 0 ? 0 : (c >= K ? K - 1 : c));  // clamped like vq_keys_k
+}
+
+__global__ __launch_bounds__(256) void vq_hist_k(const int64_t* __restrict__ idx, int rows, int K, int* __restrict__ blk_hist) {
+    extern __shared__ int hist[];
+    const int t = threadIdx.x, r = blockIdx.x * 256 + t;
+    for (int k = t; k < K; k += 256) hist[k] = 0;
+    __syncthreads();
+    if (r < rows) atomicAdd(&hist[vq_code_of(idx, r, K)], 1);
+    __syncthreads();
+    for (int k = t; k < K; k += 256) blk_hist[(long)blockIdx.x * K + k] = hist[k];
+}
+
+// one block: blk_hist[b][k] -> blk_off[b][k] = rows of code k in blocks < b; seg_lo / item_base as vq_segments_k
+__global__ __launch_bounds__(1024) void vq_scan_k(const int* __restrict__ blk_hist, int nblk, int rows, int K, int* __restrict__ blk_off,
+                                                   int* __restrict__ seg_lo, int* __restrict__ item_base) {
+    __shared__ int sh[1024];
+    __shared__ int carry_s, carry_i;
+    const int t = threadIdx.x;
+    if (t == 0) carry_s = 0, carry_i = 0;
+    __syncthreads();
+    for (int k0 = 0; k0 < K; k0 += 1024) {
+        const int k = k0 + t;
+        int count = 0;
+        if (k < K)
+            for (int b = 0; b < nblk; ++b) {  // (coalesced across the codes)
+                blk_off[(long)b * K + k] = count;
+                count += blk_hist[(long)b * K + k];
+            }
+        const int items = (count + VQ_CHUNK - 1) / VQ_CHUNK;
+        // two inclusive Hillis-Steele scans over the 1024 codes of this round: rows, then work items
+        sh[t] = count;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int v = t >= off ? sh[t - off] : 0;
+            __syncthreads();
+            sh[t] += v;
+            __syncthreads();
+        }
+        if (k < K) seg_lo[k] = carry_s + sh[t] - count;
+        __syncthreads();
+        const int tot_s = sh[1023];
+        __syncthreads();
+        sh[t] = items;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int v = t >= off ? sh[t - off] : 0;
+            __syncthreads();
+            sh[t] += v;
+            __syncthreads();
+        }
+        if (k < K) item_base[k] = carry_i + sh[t] - items;
+        __syncthreads();
+        if (t == 0) carry_s += tot_s, carry_i += sh[1023];
+        __syncthreads();
+    }
+    if (t == 0) seg_lo[K] = rows, item_base[K] = carry_i;
+}
+
+__global__ __launch_bounds__(256) void vq_place_k(const int64_t* __restrict__ idx, int rows, int K, const int* __restrict__ seg_lo,
+                                                  const int* __restrict__ blk_off, unsigned long long* __restrict__ sorted) {
+    __shared__ int codes[256];
+    const int t = threadIdx.x, r = blockIdx.x * 256 + t;
+    const int c = r < rows ? vq_code_of(idx, r, K) : -1;
+    codes[t] = c;
+    __syncthreads();
+    if (r >= rows) return;
+    int rank = 0;
+    for (int j = 0; j < t; ++j) rank += codes[j] == c ? 1 : 0;  // earlier rows of this block with the same code
+    const int pos = seg_lo[c] + blk_off[(long)blockIdx.x * K + c] + rank;
+    sorted[pos] = ((unsigned long long)c << 32) | (unsigned)r;
+}
+
 template <int D>
 void launch_mfma(const float* x, const float* e, float* q, int64_t* idx, double* part, int* used, int rows, int K, int nblk,
                  hipStream_t st) {
@@ -343,6 +427,23 @@ static int segmented_code_sum(const float* x, const float* q, const int64_t* idx
     int* item_base = seg_lo + k + 2;
     void* temp = reinterpret_cast<void*>(item_base + k + 2);
     temp = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(temp) + 255) & ~(uintptr_t)255);
+    static const bool no_place = getenv("MOVAE_VQ_RADIX") && atoi(getenv("MOVAE_VQ_RADIX")) != 0;  // (A/B knob: the radix-sort path)
+    if (k <= VQ_PLACE_MAX_K && !no_place) {  // counting placement: three launches instead of the sort's nine, the same order
+        const int nblk = ceil_div(rows, 256);
+        int* blk_hist = reinterpret_cast<int*>(temp);
+        int* blk_off = blk_hist + (size_t)nblk * k;
+        hipLaunchKernelGGL(vq_hist_k, dim3(nblk), dim3(256), (size_t)k * sizeof(int), st, idx, rows, k, blk_hist);
+        MOVAE_CHECK_LAUNCH("vq_hist");
+        hipLaunchKernelGGL(vq_scan_k, dim3(1), dim3(1024), 0, st, blk_hist, nblk, rows, k, blk_off, seg_lo, item_base);
+        MOVAE_CHECK_LAUNCH("vq_scan");
+        hipLaunchKernelGGL(vq_place_k, dim3(nblk), dim3(256), 0, st, idx, rows, k, seg_lo, blk_off, sorted);
+        MOVAE_CHECK_LAUNCH("vq_place");
+        hipLaunchKernelGGL(vq_embed_part_k, dim3(max_items), dim3(256), 0, st, x, q, sorted, seg_lo, item_base, part, k, d);
+        MOVAE_CHECK_LAUNCH("vq_embed_part");
+        hipLaunchKernelGGL(vq_embed_final_k, dim3(k), dim3(256), 0, st, part, item_base, ge, de, d, 1.f / (float)total);
+        MOVAE_CHECK_LAUNCH("vq_embed_final");
+        return MOVAE_OK;
+    }
     size_t temp_bytes = 0;
     (void)hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, keys, sorted, rows, 0, 64);
     hipLaunchKernelGGL(vq_keys_k, dim3(ceil_div(rows, 256)), dim3(256), 0, st, idx, keys, rows, k);
@@ -417,8 +518,10 @@ size_t movae_vq_bwd_ws_bytes(int rows, int k, int d) {
     size_t temp = 0;
     (void)hipcub::DeviceRadixSort::SortKeys(nullptr, temp, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, rows, 0, 64);
     const size_t items = (size_t)rows / VQ_CHUNK + k + 1;
+    // (the counting placement keeps two per-block histograms where the sort keeps its temporary storage)
+    const size_t place = k <= VQ_PLACE_MAX_K ? 2 * (size_t)ceil_div(rows, 256) * k * sizeof(int) : 0;
     return MOVAE_WS_HEADER_BYTES + 2 * (size_t)rows * sizeof(unsigned long long) + items * d * sizeof(float) +
-           2 * ((size_t)k + 2) * sizeof(int) + temp + 1024;
+           2 * ((size_t)k + 2) * sizeof(int) + (temp > place ? temp : place) + 1024;
 }
 
 int movae_vq_bwd(const float* x, const float* q, const int64_t* idx, const float* dq, const float* gc, const float* ge,
