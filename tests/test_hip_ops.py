@@ -902,3 +902,48 @@ def test_gram_upgrad_in_two_launches_equals_the_three(M, k, norm):
     g2 = a(J)
     h.remove()
     assert torch.equal(g1, g2) and len(seen) == 2 and torch.equal(seen[0], seen[1])
+
+
+_VQ_ORDER_CASES = [(20000, 64, 16, True), (8192 + 37, 512, 64, False), (3000, 1500, 8, False)]  # rows, K, D, skewed usage
+
+
+def _vq_codebook_grads(ops):
+    out = []
+    for i, (rows, K, D, skew) in enumerate(_VQ_ORDER_CASES):
+        g = torch.Generator().manual_seed(40 + i)
+        E = torch.randn(K, D, generator=g) * 2.0
+        pick = (torch.tensor([3, 3, 3, 41, 3, 17])[torch.randint(0, 6, (rows,), generator=g)] if skew
+                else torch.randint(0, K, (rows,), generator=g))
+        x = (E[pick] + 0.01 * torch.randn(rows, D, generator=g)).reshape(1, rows, 1, D)
+        xg, Eg = x.cuda().requires_grad_(True), E.cuda().requires_grad_(True)
+        q, c, e, idx, used = ops.vector_quantize(xg, Eg)
+        (0.25 * c + 2.0 * e).backward()
+        out.append(Eg.grad.cpu().numpy().copy())
+    return out
+
+
+def test_vq_counting_placement_equals_the_radix_sort(M, tmp_path):
+    """The codebook gradient's (code, row) order comes from a three-launch counting placement (vq.hip: vq_hist_k / vq_scan_k /
+    vq_place_k); MOVAE_VQ_RADIX=1 (read once per process: a child process here) keeps the radix sort it replaced.  Same order, so the
+    segmented sums are the same bits: skewed and uniform code usage, rows not a multiple of the 256-row blocks, more codes than one
+    scan round (K > 1024)."""
+    import subprocess
+    import sys
+
+    ops, _ = M
+    here = _vq_codebook_grads(ops)
+    code = f"""
+import os, sys, numpy as np
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})
+import movae_amd
+from movae_amd import ops
+import test_hip_ops as T
+np.savez({str(tmp_path / "radix.npz")!r}, *T._vq_codebook_grads(ops))
+"""
+    env = dict(os.environ, MOVAE_VQ_RADIX="1", MOVAE_NO_REBUILD="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ref = np.load(tmp_path / "radix.npz")
+    for i, a in enumerate(here):
+        assert np.array_equal(a, ref[f"arr_{i}"]), f"case {_VQ_ORDER_CASES[i]}: placement and radix sort give different codebook gradients"
