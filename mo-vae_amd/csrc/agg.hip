@@ -4,15 +4,16 @@
 // arithmetic intensity is K/4 flop per byte); the solves are single-wave kernels in fp64 so the
 // reference's host round trip (GPU -> numpy float64 -> quadprog -> GPU) never happens.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int MAXK = MOVAE_MAX_K;
-constexpr int GRAM_BLOCKS = 1024;
-
+// blocks of the streaming passes over J (gram_partial, combine, similarity): one per 2048 columns, at most MOVAE_GRAM_BLOCKS
 inline int gram_blocks(size_t m) {
+    static const size_t cap = getenv("MOVAE_GRAM_BLOCKS") ? (size_t)atol(getenv("MOVAE_GRAM_BLOCKS")) : 1024;
     size_t g = (m + 2047) / 2048;
-    return (int)(g > GRAM_BLOCKS ? GRAM_BLOCKS : (g < 1 ? 1 : g));
+    return (int)(g > cap ? cap : (g < 1 ? 1 : g));
 }
 
 template <int K, bool VEC>
