@@ -23,6 +23,18 @@ def _channels_last_param(t):
     return tnn.Parameter(t.detach().clone().contiguous(memory_format=torch.channels_last))
 
 
+def _take_lazy(x, fusion):
+    """(fusion, raw tensor) for a conv whose input is an unmaterialised BatchNorm / activation output (ops.LazyBN / ops.LazyAct): the
+    operand transform -- and a LazyAct's ActLink -- join whatever the caller already asked of this conv."""
+    if fusion is None:
+        fusion = x.fusion()
+    elif fusion.in_scale is None:
+        fusion.in_scale, fusion.in_shift, fusion.in_slope, fusion.link = x.scale, x.shift, x.slope, x.link
+        if getattr(x, "act_link", None) is not None:
+            fusion.act_in = x.act_link
+    return fusion, x.y
+
+
 class Conv2d(tnn.Module):
     def __init__(self, cin, cout, k, stride=1, padding=0, bias=True):
         super().__init__()
@@ -34,8 +46,7 @@ class Conv2d(tnn.Module):
 
     def forward(self, x, act=None, feeds_batchnorm=False, fusion=None):
         if isinstance(x, ops.LazyBN):  # the producer's BatchNorm + activation is applied while this conv loads its input
-            fusion = x.fusion(want_stats=fusion is not None and fusion.want_stats) if fusion is None or fusion.in_scale is None else fusion
-            x = x.y
+            fusion, x = _take_lazy(x, fusion)
         return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, act, LRELU_SLOPE, feeds_batchnorm, fusion)
 
     def extra_repr(self):
@@ -53,8 +64,7 @@ class ConvTranspose2d(tnn.Module):
 
     def forward(self, x, act=None, feeds_batchnorm=False, fusion=None):
         if isinstance(x, ops.LazyBN):
-            fusion = x.fusion(want_stats=fusion is not None and fusion.want_stats) if fusion is None or fusion.in_scale is None else fusion
-            x = x.y
+            fusion, x = _take_lazy(x, fusion)
         return ops.conv_transpose2d(x, self.weight, self.bias, self.stride, self.padding, self.output_padding, act, LRELU_SLOPE,
                                     feeds_batchnorm, fusion)
 
@@ -202,8 +212,7 @@ class Stack(tnn.Sequential):
                         # (a producer that can finishes this BatchNorm inside its own launch: ops.ConvFusion.bn_fin)
                         fusion.bn_fin = (nxt.weight, nxt.bias, nxt.running_mean, nxt.running_var, nxt.num_batches_tracked, nxt.eps, nxt.momentum)
                         if isinstance(x, ops.LazyBN):
-                            fusion.in_scale, fusion.in_shift, fusion.in_slope, fusion.link = x.scale, x.shift, x.slope, x.link
-                            x = x.y
+                            fusion, x = _take_lazy(x, fusion)
                         x = nxt.forward_lazy(m(x, None, True, fusion), kind, fusion)
                     else:
                         x = nxt(m(x, None, nxt.training, ops.ConvFusion(act_in=link, res_in=rin) if (link is not None or rin is not None) else None), kind)
@@ -212,16 +221,11 @@ class Stack(tnn.Sequential):
                 elif isinstance(nxt, _Act):
                     # (a tanh / sigmoid pair that ENDS the Stack gets a link too: the decoder's output activation, whose one reader
                     # is the reconstruction loss -- ops.VAELosses applies the derivative in its backward kernel)
-                    lazy = isinstance(x, ops.LazyBN)
                     ends = i + 2 == n and nxt.kind in ("tanh", "sigmoid")
-                    out = ops.ActLink() if ((nxt.kind in ("lrelu", "relu") and not lazy) or ends) else None
-                    if lazy and out is not None:  # the conv applies the producer's BatchNorm on load AND publishes its own activation
-                        f = x.fusion()
-                        f.act_out = out
-                        x = m(x, nxt.kind, False, f)
-                    else:
-                        x = m(x, nxt.kind, False, ops.ConvFusion(act_in=link, act_out=out, res_in=rin)
-                              if (link is not None or out is not None or rin is not None) else None)
+                    out = ops.ActLink() if (nxt.kind in ("lrelu", "relu") or ends) else None
+                    # (a LazyBN / LazyAct input adds its operand transform to this request: _take_lazy)
+                    x = m(x, nxt.kind, False, ops.ConvFusion(act_in=link, act_out=out, res_in=rin)
+                          if (link is not None or out is not None or rin is not None) else None)
                     link = out
                     i += 2
                 else:
@@ -234,7 +238,13 @@ class Stack(tnn.Sequential):
                   and not isinstance(x, ops.LazyBN)):
                 # a stand-alone activation whose output only the next conv reads: that conv's input gradient applies its derivative
                 link = ops.ActLink()
-                x = ops.activation(x, m.kind, LRELU_SLOPE, link, rin)
+                nxt = mods[i + 1]
+                if ops.LAZY_ACT and isinstance(nxt, (Conv2d, ConvTranspose2d)) and x.shape[-1] % 4 == 0:
+                    # not written at all: the conv applies it while loading (ops.LazyAct); the link travels inside the LazyAct
+                    x = ops.LazyAct(x, m.kind, LRELU_SLOPE, link, rin)
+                    link = None
+                else:
+                    x = ops.activation(x, m.kind, LRELU_SLOPE, link, rin)
                 i += 1
             else:
                 x = m(ops.materialize(x))

@@ -594,7 +594,8 @@ class Conv(Function):
         ctx.bias_grad_is_zero = bias_grad_is_zero
         ctx.in_slope = in_norm[2] if in_norm is not None else None
         ctx.bn_link = fusion.link if (fusion is not None and in_norm is not None) else None
-        ctx.act_in = fusion.act_in if (fusion is not None and in_norm is None) else None
+        # (with a transformed input: only the virtual stand-alone activation -- no BatchNorm link -- carries an ActLink too)
+        ctx.act_in = fusion.act_in if (fusion is not None and (in_norm is None or fusion.link is None)) else None
         ctx.res_in = fusion.res_in if fusion is not None else None
         ctx.res_out = res_out[1] if res_out is not None else None
         ctx.act_out = None
@@ -1004,6 +1005,41 @@ class LazyBN:
         return ScaleShiftAct.apply(self.y, self.scale, self.shift, self.slope)
 
 
+#: MOVAE_LAZY_ACT=1: a stand-alone ReLU / LeakyReLU in front of a conv is not written to memory -- the conv applies it while loading
+#: (LazyAct).  OFF by default: measured SLOWER (C4 4.56 vs 4.44 ms, C3 10.61 vs 10.56): the operand transform in the consumer's
+#: forward and weight-gradient kernels costs more than the twelve 6 us activation launches it removes.
+LAZY_ACT = os.environ.get("MOVAE_LAZY_ACT", "0") == "1"
+_UNIT_MAP = {}
+
+
+def _unit_map(c, device):
+    """(ones[c], zeros[c]): the identity scale / shift of a virtual activation, one pair per channel count and device for life"""
+    key = (c, device.type, device.index)
+    m = _UNIT_MAP.get(key)
+    if m is None:
+        m = _UNIT_MAP[key] = (torch.ones(c, dtype=torch.float32, device=device), torch.zeros(c, dtype=torch.float32, device=device))
+    return m
+
+
+class LazyAct(LazyBN):
+    """A stand-alone ReLU / LeakyReLU whose output only the next conv reads, NOT written to memory: the conv applies it while loading
+    (the fused-BatchNorm operand transform with scale 1, shift 0), its input-gradient epilogue applies the derivative (ActLink, read
+    off the sign of the raw x).  `y` is the raw x as an Activation tape node (virtual=True)."""
+    __slots__ = ("act_link",)
+
+    def __init__(self, x, act, slope, link, res_in):
+        sl = 0.0 if act == "relu" else float(slope)
+        y = Activation.apply(x, act, sl, link, res_in, True)
+        one, zero = _unit_map(x.shape[-1], x.device)
+        super().__init__(y, one, zero, sl, None)
+        self.act_link = link
+
+    def fusion(self, want_stats=False):
+        f = ConvFusion(self.scale, self.shift, self.slope, want_stats, None)
+        f.act_in = self.act_link
+        return f
+
+
 def materialize(x):
     return x.materialize() if isinstance(x, LazyBN) else x
 
@@ -1154,12 +1190,18 @@ class Activation(Function):
     may apply this activation's derivative itself (nn.Stack arranges that); the backward then passes the gradient through."""
 
     @staticmethod
-    def forward(ctx, x, act, slope, act_out=None, res_in=None):
+    def forward(ctx, x, act, slope, act_out=None, res_in=None, virtual=False):
         ctx.set_materialize_grads(False)  # an absent cotangent arrives as None: no zero-fill, no kernels on zeros
         L.require_gpu(x)
         x = _c(x)
-        y = torch.empty_like(x)
-        _call("movae_act_fwd", x.data_ptr(), y.data_ptr(), x.numel(), L.ACT[act], float(slope), _st(x))
+        if virtual:
+            # no kernel: the ONE consumer (a conv) applies the activation while it loads x (ops.LazyAct); `y` is x itself as a new
+            # tape node, and stands in for the output wherever only its SIGN matters (ReLU / LeakyReLU derivative: act'(x) from x)
+            assert act in ("relu", "lrelu") and act_out is not None
+            y = x.view_as(x)
+        else:
+            y = torch.empty_like(x)
+            _call("movae_act_fwd", x.data_ptr(), y.data_ptr(), x.numel(), L.ACT[act], float(slope), _st(x))
         ctx.act, ctx.slope = act, slope
         ctx.act_out, ctx.res_in = act_out, res_in  # res_in: this activation is the first op of a residual branch (ResCarrier)
         if act_out is not None:
@@ -1171,14 +1213,14 @@ class Activation(Function):
     @staticmethod
     def backward(ctx, dy):
         if dy is None:
-            return (None,) * 5
+            return (None,) * 6
         (y,) = ctx.saved_tensors
         dy = _c(dy)
         if _act_take(ctx, dy):
-            return Activation._add_res(ctx, dy, ctx.act_out.res_done), None, None, None, None
+            return Activation._add_res(ctx, dy, ctx.act_out.res_done), None, None, None, None, None
         dx = torch.empty_like(dy)
         _call("movae_act_bwd", dy.data_ptr(), y.data_ptr(), dx.data_ptr(), dy.numel(), L.ACT[ctx.act], float(ctx.slope), _st(dy))
-        return Activation._add_res(ctx, dx, False), None, None, None, None
+        return Activation._add_res(ctx, dx, False), None, None, None, None, None
 
     @staticmethod
     def _add_res(ctx, dx, already):
@@ -1194,7 +1236,7 @@ class Activation(Function):
         (y,) = ctx.saved_tensors
         dy = _stacked(dy, G)
         if _act_take(ctx, dy):
-            return Activation._add_res(ctx, dy, ctx.act_out.res_done), None, None, None, None
+            return Activation._add_res(ctx, dy, ctx.act_out.res_done), None, None, None, None, None
         dx = torch.empty_like(dy)
         c = y.shape[-1]
         if c % 4 == 0 and dy.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0:  # all groups in one launch
@@ -1205,7 +1247,7 @@ class Activation(Function):
             for g in range(G):
                 _call("movae_act_bwd", dy[g].data_ptr(), y.data_ptr(), dx[g].data_ptr(), y.numel(), L.ACT[ctx.act], float(ctx.slope),
                       _st(dy))
-        return Activation._add_res(ctx, dx, False), None, None, None, None
+        return Activation._add_res(ctx, dx, False), None, None, None, None, None
 
 
 def activation(x, act, slope=0.01, act_out=None, res_in=None):

@@ -308,6 +308,30 @@ def test_fused_loss_arithmetic_equals_tensor_arithmetic(tag, gpu_device, monkeyp
                 np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-9 * max(1.0, float(np.abs(b).max())), err_msg=f"{k} {n}")
 
 
+@pytest.mark.parametrize("tag", ["vq_vae2_tiny"])  # (its residual blocks open with a stand-alone ReLU: models/vq_vae2.py:13-28)
+def test_virtual_standalone_activation_opt_in(tag, gpu_device, monkeypatch):
+    """ops.LazyAct (MOVAE_LAZY_ACT=1, off by default: measured slower): a stand-alone ReLU in front of a conv is applied by that conv
+    while it loads.  The golden forward / loss / gradient / Adam fixture and the aggregated step against the oracle, with it ON --
+    and no activation-forward launch left in front of the residual blocks' convs."""
+    import movae_amd  # noqa: F401
+    from movae_amd import _lib as L
+    from movae_amd import ops
+
+    monkeypatch.setattr(ops, "LAZY_ACT", True)
+    calls = []
+    monkeypatch.setattr(L, "TRACE", lambda name, args: calls.append(name))
+    test_forward_losses_sum_backward_and_adam(tag, gpu_device)
+    n_act = calls.count("movae_act_fwd")
+    monkeypatch.setattr(L, "TRACE", None)
+    test_mtl_backward_matches_oracle(tag, "upgrad", gpu_device)
+    monkeypatch.setattr(ops, "LAZY_ACT", False)
+    calls2 = []
+    monkeypatch.setattr(L, "TRACE", lambda name, args: calls2.append(name))
+    test_forward_losses_sum_backward_and_adam(tag, gpu_device)
+    monkeypatch.setattr(L, "TRACE", None)
+    assert n_act < calls2.count("movae_act_fwd"), (n_act, calls2.count("movae_act_fwd"))
+
+
 def _full_case(tag):
     fx = load_golden("full_configs")
     m = {}
