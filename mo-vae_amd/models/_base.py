@@ -152,6 +152,13 @@ class HotPathModel(tnn.Module):
     noise_on_device = False
     _noise_state_t = None
 
+    def _recon(self, fn, inputs, recons, weight, plain_cls):
+        """The reconstruction objective; in the PLAIN model `plain_cls` (not a subclass that adds losses on `recons`: those would be
+        further readers) it is told that it is the one reader of the decoder's output activation (objectives._make: out_act)."""
+        if type(self) is plain_cls and getattr(fn, "kind", None) in ops.L.RECON:
+            return fn(inputs, recons, weight, out_act=True)
+        return fn(inputs, recons, weight)
+
     def _noise_state(self, device):
         st = self._noise_state_t
         if st is None or st.device != device:

@@ -91,7 +91,7 @@ class BetaTCVAE(HotPathModel):
     def loss_function(self, inputs, args: dict) -> dict:
         lw = self.lambda_weights
         z = args["z"]
-        rec = self.objectives["reconstruction_loss"](inputs, args["recons"], lw["reconstruction_loss"])
+        rec = self._recon(self.objectives["reconstruction_loss"], inputs, args["recons"], lw["reconstruction_loss"], BetaTCVAE)
         terms = ops.tc_decomposition(z, args["mu"], args["log_var"], self._log_importance_weights(z.shape[0], z.device))
         if os.environ.get("MOVAE_FUSE_LOSSES", "1") != "0" and rec.is_cuda:
             # weights, annealing and the total in one launch (ops.CombineLosses) instead of eight; the annealing counter is

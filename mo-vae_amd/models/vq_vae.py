@@ -137,7 +137,7 @@ class VQVAE(HotPathModel):
         if keys == ["reconstruction_loss", "embedding_loss", "commitment_loss"] and os.environ.get("MOVAE_FUSE_LOSSES", "1") != "0" \
                 and args["recons"].is_cuda:
             # the two weights and the total in one launch (ops.CombineLosses) instead of four
-            rec = self.objectives["reconstruction_loss"](inputs, args["recons"], lw["reconstruction_loss"])
+            rec = self._recon(self.objectives["reconstruction_loss"], inputs, args["recons"], lw["reconstruction_loss"], VQVAE)
             coef = [[1.0, 0, 0], [0, lw["embedding_loss"], 0], [0, 0, lw["commitment_loss"]]]
             rec, emb, com, total = ops.combine_losses([rec, args["embedding_loss"], args["commitment_loss"]], coef)
             return {"reconstruction_loss": rec, "embedding_loss": emb, "commitment_loss": com, "total_loss": total}

@@ -150,7 +150,7 @@ class VQVAE2(HotPathModel):
 
     def loss_function(self, inputs, args: dict) -> dict:
         lw = self.lambda_weights
-        rec = self.recon_obj(inputs, args["recons"], lw["reconstruction_loss"])
+        rec = self._recon(self.recon_obj, inputs, args["recons"], lw["reconstruction_loss"], VQVAE2)
         terms = args.get("_vq_terms") if os.environ.get("MOVAE_FUSE_LOSSES", "1") != "0" and rec.is_cuda else None
         if terms is not None:
             # top + bottom, the weights and the total in one launch (ops.CombineLosses); `terms` = (c_t, c_b, e_t, e_b)

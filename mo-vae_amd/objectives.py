@@ -13,9 +13,12 @@ def _pair(inputs, recons):
 
 
 def _make(kind):
-    def fn(inputs, recons, scale=1.0):
+    def fn(inputs, recons, scale=1.0, out_act=False):
+        """out_act: the caller vouches that this loss is the ONE reader of `recons` on the tape (the plain VQ-VAE / VQ-VAE-2 / BetaTC
+        models): when `recons` is the output of a conv + tanh / sigmoid pair, the loss's backward kernel applies the activation's
+        derivative itself (ops.ReconLoss, ops.OUT_ACT_LINKS)."""
         x, r = _pair(inputs, recons)
-        return ops.recon_loss(r, x, kind, scale)
+        return ops.recon_loss(r, x, kind, scale, ops.out_act_link(r) if out_act else None)
 
     fn.kind = kind
     return fn

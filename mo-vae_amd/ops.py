@@ -342,6 +342,18 @@ def _defer_ws(t, sunk):
     return None
 
 
+#: data_ptr of the output of a conv + tanh / sigmoid pair that ends its nn.Stack -> that pair's ActLink: a reconstruction loss that is the
+#: output's one reader looks the link up (out_act_link) and applies the derivative in its own backward kernel
+OUT_ACT_LINKS = {}
+
+
+def out_act_link(recons):
+    link = OUT_ACT_LINKS.get(recons.data_ptr()) if FUSE_ACT else None
+    if link is None or link.y is None or link.y.data_ptr() != recons.data_ptr() or link.y.shape != recons.shape:
+        return None
+    return link
+
+
 class ActLink:
     """Shared by a conv whose epilogue applied an activation (the producer) and the ONE conv that consumes its output (nn.Stack
     hands it to the next module only, so the output has no other reader): the consumer's input-gradient pass multiplies its
@@ -602,6 +614,10 @@ class Conv(Function):
         if fusion is not None and fusion.act_out is not None and L.ACT[act]:
             ctx.act_out = fusion.act_out
             ctx.act_out.y, ctx.act_out.act, ctx.act_out.slope, ctx.act_out.applied = y.detach(), act, slope, None
+            if act in ("tanh", "sigmoid"):
+                if len(OUT_ACT_LINKS) > 64:
+                    OUT_ACT_LINKS.clear()
+                OUT_ACT_LINKS[y.data_ptr()] = ctx.act_out
         ctx.save_for_backward(x, w, y if L.ACT[act] else None, b, *(in_norm[:2] if in_norm is not None else ()))
         return y
 
@@ -1419,7 +1435,7 @@ class ReconLoss(Function):
     """scale * mean(objective(recons, inputs)); both tensors must share one memory order."""
 
     @staticmethod
-    def forward(ctx, recons, inputs, kind, scale):
+    def forward(ctx, recons, inputs, kind, scale, act_link=None):
         ctx.set_materialize_grads(False)  # an absent cotangent arrives as None: no zero-fill, no kernels on zeros
         L.require_gpu(recons)
         recons, inputs = _c(recons), _c(inputs)
@@ -1429,19 +1445,28 @@ class ReconLoss(Function):
         _call("movae_recon_loss_fwd", recons.data_ptr(), inputs.data_ptr(), out.data_ptr(), recons.numel(), L.RECON[kind],
               float(scale), wsp, wsb, _st(recons))
         ctx.kind, ctx.scale = kind, scale
+        # recons = act(pre), this loss its one reader (ActLink): the backward kernel hands the producing conv the PRE-activation gradient
+        ctx.act_link = act_link if (FUSE_ACT and act_link is not None and act_link.act in ("tanh", "sigmoid") and act_link.y is not None
+                                    and act_link.y.data_ptr() == recons.data_ptr()) else None
         ctx.save_for_backward(recons, inputs)
         return out
 
     @staticmethod
     def backward(ctx, g):
         if g is None:
-            return (None,) * 4
+            return (None,) * 5
         recons, inputs = ctx.saved_tensors
         g = _c(g)
         dr = torch.empty_like(recons)
-        _call("movae_recon_loss_bwd", recons.data_ptr(), inputs.data_ptr(), g.data_ptr(), dr.data_ptr(), recons.numel(),
-              L.RECON[ctx.kind], float(ctx.scale), _st(recons))
-        return dr, None, None, None
+        link = ctx.act_link
+        if link is not None:
+            _call("movae_recon_loss_bwd_act", recons.data_ptr(), inputs.data_ptr(), g.data_ptr(), dr.data_ptr(), recons.numel(),
+                  L.RECON[ctx.kind], float(ctx.scale), L.ACT[link.act], float(link.slope), _st(recons))
+            link.applied = dr.data_ptr()
+        else:
+            _call("movae_recon_loss_bwd", recons.data_ptr(), inputs.data_ptr(), g.data_ptr(), dr.data_ptr(), recons.numel(),
+                  L.RECON[ctx.kind], float(ctx.scale), _st(recons))
+        return dr, None, None, None, None
 
 
 class EdgeWeightedPixelLoss(Function):
@@ -1521,8 +1546,8 @@ def edge_matching_loss(recons, inputs, scale=1.0, mode="mag"):
     return EdgeMatchingLoss.apply(recons, inputs, scale, mode)
 
 
-def recon_loss(recons, inputs, kind, scale=1.0):
-    return ReconLoss.apply(recons, inputs, kind, scale)
+def recon_loss(recons, inputs, kind, scale, act_link=None):
+    return ReconLoss.apply(recons, inputs, kind, scale, act_link)
 
 
 class KLDivergence(Function):
