@@ -35,6 +35,24 @@ def test_library_exports_every_declared_symbol(pkg):
     assert lib.movae_bn_ws_bytes(1024, 64) > 0 and lib.movae_gram_ws_bytes(4, 1 << 20) > 0
 
 
+def test_deferred_reduce_policy_names_and_switches(pkg):
+    """Host logic of the deferred weight-gradient reduces (no GPU): every call the policy lets pass while a reduce may be parked is
+    an entry point that exists and is one of the backward's own ops -- never an aggregation / optimizer / forward-statistics call,
+    which must flush first -- and the switch nests and restores."""
+    from movae_amd import _lib as L
+    from movae_amd import ops
+
+    assert L.DEFER_PASS <= set(L.SIGNATURES), L.DEFER_PASS - set(L.SIGNATURES)
+    readers = {n for n in L.SIGNATURES if n.startswith(("movae_gram", "movae_combine", "movae_weights", "movae_adam", "movae_clip", "movae_sumsq",
+                                                          "movae_scale_by", "movae_gd_"))}
+    assert readers and not (readers - {"movae_combine_losses_bwd"}) & L.DEFER_PASS
+    assert not any(n.endswith(("_fwd", "_fwd_f", "_fwd_mse")) for n in L.DEFER_PASS)
+    assert L.DEFER_ON[0] is False
+    with ops.deferred_reduces(enabled=False):
+        assert L.DEFER_ON[0] is False
+    assert L.DEFER_ON[0] is False
+
+
 def test_no_cpu_fallback(pkg):
     from movae_amd import aggregation, ops
 
