@@ -171,13 +171,22 @@ __global__ __launch_bounds__(256) void vq_nearest_generic(const float* __restric
     if (threadIdx.x == 0) sse_part[blockIdx.x] = sse;
 }
 
-__global__ __launch_bounds__(256) void vq_finalize(const double* __restrict__ part, int nblk, const int* __restrict__ used,
+// The "code i was chosen" flags of the nearest-code kernels.  They must read zero when a lookup starts: kept in a device array of the
+// library's own (not in the caller's scratch arena, which other calls overwrite) they are cleared by vq_finalize right after it has
+// counted them -- no memset launch in front of every lookup.  (Up to VQ_FLAGS_MAX codes; one lookup at a time per process.)
+constexpr int VQ_FLAGS_MAX = 16384;
+__device__ int g_vq_used[VQ_FLAGS_MAX];
+
+__global__ __launch_bounds__(256) void vq_finalize(const double* __restrict__ part, int nblk, int* __restrict__ used,
                                                    int K, float* __restrict__ sse, int* __restrict__ used_count,
-                                                   float* __restrict__ mse2, float numel) {
+                                                   float* __restrict__ mse2, float numel, int clear) {
     __shared__ double shd[4];
     double s = 0.0, u = 0.0;
     for (int i = threadIdx.x; i < nblk; i += 256) s += part[i];
-    for (int i = threadIdx.x; i < K; i += 256) u += used[i] ? 1.0 : 0.0;
+    for (int i = threadIdx.x; i < K; i += 256) {
+        u += used[i] ? 1.0 : 0.0;
+        if (clear) used[i] = 0;
+    }
     s = block_sum_256(s, shd);
     u = block_sum_256(u, shd);
     if (threadIdx.x == 0) {
@@ -481,7 +490,12 @@ static int vq_nearest_impl(const float* x, const float* e, float* q, int64_t* id
     MOVAE_CHECK_ARG(ws && ws_bytes >= need, "movae_vq_nearest_fwd: workspace too small (%zu < %zu)", ws_bytes, need);
     double* part = static_cast<double*>(ws);
     int* used = reinterpret_cast<int*>(part + nblk);
-    if (hipMemsetAsync(used, 0, (size_t)k * sizeof(int), st) != hipSuccess) {
+    static int* own_flags = nullptr;  // g_vq_used's device address (zero-initialised with the code object, self-cleaning afterwards)
+    if (!own_flags && hipGetSymbolAddress(reinterpret_cast<void**>(&own_flags), HIP_SYMBOL(g_vq_used)) != hipSuccess) own_flags = nullptr;
+    const bool self_clean = own_flags != nullptr && k <= VQ_FLAGS_MAX;
+    if (self_clean) {
+        used = own_flags;
+    } else if (hipMemsetAsync(used, 0, (size_t)k * sizeof(int), st) != hipSuccess) {
         movae_set_error("movae_vq_nearest_fwd: memset failed");
         return MOVAE_ELAUNCH;
     }
@@ -495,7 +509,8 @@ static int vq_nearest_impl(const float* x, const float* e, float* q, int64_t* id
             hipLaunchKernelGGL(vq_nearest_generic, dim3(nblk), dim3(256), 0, st, x, e, q, idx, part, used, rows, k, d);
     }
     MOVAE_CHECK_LAUNCH("vq_nearest");
-    hipLaunchKernelGGL(vq_finalize, dim3(1), dim3(256), 0, st, part, nblk, used, k, sse, used_count, mse2, (float)rows * (float)d);
+    hipLaunchKernelGGL(vq_finalize, dim3(1), dim3(256), 0, st, part, nblk, used, k, sse, used_count, mse2, (float)rows * (float)d,
+                       self_clean ? 1 : 0);
     MOVAE_CHECK_LAUNCH("vq_finalize");
     return MOVAE_OK;
 }
