@@ -908,6 +908,7 @@ inline long reduce_vec_min() {  // outputs from which the 16-byte reduce serves 
 // launched.  The next implicit-GEMM launch on the same stream takes it along (defer_take -> extra blocks); movae_reduce_flush(),
 // any second parked reduce, or a call that cannot carry it launch it stand-alone.  At most one is parked.
 struct DeferredReduce {
+    size_t bytes = 0;     // of the parked reduce's slabs
     bool armed = false, pending = false;
     unsigned serial = 0;  // counts parked reduces (DeferScope: was the one parked at entry carried?)
     RSide r{};
@@ -945,10 +946,22 @@ inline int defer_flush() {
     return reduce_launch(g_defer.r, nullptr, 0, 0.f, ActMul{nullptr, 0, 0.f, 0, 0, nullptr}, g_defer.st);
 }
 
-// the parked reduce, if this launch (on stream st) can carry it; r.nblk == 0 otherwise
-inline RSide defer_take(hipStream_t st) {
+// a parked reduce is a few blocks' work in a launch built for something else (its occupancy, not the reduce's): the size gates.
+// Paired launches (100-130 registers, 3-4 blocks per CU) carry more than the tiled 3-D ones (33 MB of slabs behind a 185 us
+// igemm2_bwd<128,64> cost it 49 us).  A reduce its next carrier refuses is launched stand-alone by that carrier's call.
+static size_t g_defer_max_bytes = getenv("MOVAE_DEFER_MAX_BYTES") ? (size_t)atol(getenv("MOVAE_DEFER_MAX_BYTES")) : (size_t)(12u << 20);
+static size_t g_defer_max_bytes_pair = getenv("MOVAE_DEFER_MAX_BYTES_PAIR") ? (size_t)atol(getenv("MOVAE_DEFER_MAX_BYTES_PAIR")) : (size_t)(12u << 20);
+inline size_t defer_max_bytes() { return g_defer_max_bytes; }
+inline size_t defer_max_bytes_pair() { return g_defer_max_bytes_pair; }
+
+// the parked reduce, if this launch (on stream st; `pair`: a paired dgrad + wgrad launch) can carry it; r.nblk == 0 otherwise
+inline RSide defer_take(hipStream_t st, bool pair = true) {
     RSide none{};
     if (!g_defer.pending || g_defer.st != st || g_bench_main_only) return none;
+    if (g_defer.bytes > (pair ? defer_max_bytes_pair() : defer_max_bytes())) {
+        (void)defer_flush();  // too large for this carrier: stand-alone, in front of it
+        return none;
+    }
     g_defer.pending = false;
     ++g_defer_stats[1];
     return g_defer.r;
@@ -963,14 +976,13 @@ inline RSide defer_take_3d(hipStream_t st, dim3* g, int* gz) {
     if (!g_defer.pending || g_defer.st != st || g_bench_main_only) return none;
     const long layers = ((long)g_defer.r.nblk + (long)g->x * g->y - 1) / ((long)g->x * g->y);
     if ((long)g->z + layers > 65535) return none;
+    if (g_defer.bytes > defer_max_bytes()) {
+        (void)defer_flush();
+        return none;
+    }
     g->z += (unsigned)layers;
-    return defer_take(st);
+    return defer_take(st, false);
 }
-
-// a parked reduce is a few blocks' work in a launch built for something else (its occupancy, not the reduce's): only reduces that
-// are launch-bound on their own are parked -- slabs of at most this many bytes (33 MB of slabs behind a 185 us kernel cost it 49 us)
-static size_t g_defer_max_bytes = getenv("MOVAE_DEFER_MAX_BYTES") ? (size_t)atol(getenv("MOVAE_DEFER_MAX_BYTES")) : (size_t)(12u << 20);
-inline size_t defer_max_bytes() { return g_defer_max_bytes; }
 
 inline int launch_reduce_groups(const float* slab, const RGroups& rg, int G, long n1, long n2, int S, int N, const float* bias, int act,
                                 float slope, int accumulate, hipStream_t st, ActMul am = ActMul{nullptr, 0, 0.f, 0, 0, nullptr},
@@ -994,9 +1006,9 @@ inline int launch_reduce_groups(const float* slab, const RGroups& rg, int G, lon
     }
     r.nblk = r.nbx * G;
     if (deferrable && g_defer.armed && !bias && act == MOVAE_ACT_NONE && !am.y && !am.res &&
-        (size_t)total * S * G * sizeof(float) <= defer_max_bytes()) {
+        (size_t)total * S * G * sizeof(float) <= (defer_max_bytes() > defer_max_bytes_pair() ? defer_max_bytes() : defer_max_bytes_pair())) {
         if (int rc = defer_flush()) return rc;  // (one slot)
-        g_defer.r = r, g_defer.st = st, g_defer.pending = true;
+        g_defer.r = r, g_defer.st = st, g_defer.pending = true, g_defer.bytes = (size_t)total * S * G * sizeof(float);
         ++g_defer.serial;
         ++g_defer_stats[0];
         return MOVAE_OK;
@@ -1499,7 +1511,7 @@ int movae_reduce_flush(void) { return defer_flush(); }
 
 long long movae_reduce_defer_max_bytes(long long bytes) {
     const long long prev = (long long)g_defer_max_bytes;
-    if (bytes >= 0) g_defer_max_bytes = (size_t)bytes;
+    if (bytes >= 0) g_defer_max_bytes = g_defer_max_bytes_pair = (size_t)bytes;  // (both carrier kinds)
     return prev;
 }
 
